@@ -1,0 +1,316 @@
+"""TEST INFRASTRUCTURE -- golden-vector generator.  Runs ONLY in the build container:
+
+    cd /root/repo && python -m oracle.capture_golden            # rewrites tests/golden/*.npz
+
+It imports the reference's own Python from /root/reference/src on CPU (oracle/ref_shims.py),
+feeds it seeded synthetic inputs and weights (oracle/golden_util.synth_state) and stores inputs +
+the reference's outputs / gradients / buffers as small .npz files.  Nothing from the reference is
+copied: fixtures are data (tensors), and this script is ours.  The reference has no tests or golden
+vectors of its own, so these captures are what pins the oracle.
+"""
+import copy
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shims  # noqa: E402
+from oracle.golden_util import synth_state, state_spec, summarize, pack_mask  # noqa: E402
+from c2m_amd.config import default_config, normalize_config  # noqa: E402
+from c2m_amd.synthetic import make_batch, GraphBatch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def save(name, meta, arrays):
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def run_module(mod, seed, inputs, call=None, train=True, grad_inputs=()):
+    """Load synth weights into a reference module, run fwd+bwd against a fixed upstream gradient."""
+    spec = state_spec(mod.state_dict())
+    mod.load_state_dict(synth_state(spec, seed))
+    mod.train(train)
+    inputs = {k: v.clone() for k, v in inputs.items()}
+    for k in grad_inputs:
+        inputs[k].requires_grad_(True)
+    out = call(mod, **inputs) if call else mod(**inputs)
+    outs = out if isinstance(out, dict) else {"y": out}
+    outs = {k: v for k, v in outs.items() if torch.is_tensor(v)}
+    total = 0
+    for i, (k, v) in enumerate(sorted(outs.items())):
+        if v.requires_grad:
+            total = total + (v * rnd(seed + 100 + i, *v.shape)).sum()
+    if torch.is_tensor(total):
+        total.backward()
+    arrays = {}
+    for k, v in inputs.items():
+        if torch.is_tensor(v):
+            arrays["in." + k] = v
+            if v.grad is not None:
+                arrays["gin." + k] = v.grad
+    for k, v in outs.items():
+        arrays["out." + k] = v
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            arrays["grad." + k] = p.grad
+    for k, b in mod.named_buffers():
+        arrays["buf." + k] = b
+    return spec, arrays
+
+
+# ------------------------------------------------------------------------------------------------
+def capture_ops(ref_utils):
+    from modules.motion_estimator.dense_motion import DenseMotionNetwork
+    # resample (utils/ops.py:187-193): fwd + both gradients
+    for tag, (n, c, h, w), mag in (("a", (2, 3, 12, 20), 3.0), ("b", (3, 5, 4, 8), 1.5), ("c", (1, 2, 9, 7), 6.0)):
+        img = rnd(1, n, c, h, w).requires_grad_(True)
+        flow = rnd(2, n, 2, h, w, scale=mag).requires_grad_(True)
+        out = ref_utils.resample(img, flow)
+        gout = rnd(3, *out.shape)
+        (out * gout).sum().backward()
+        save(f"op_resample_{tag}", {"op": "resample"},
+             {"in.image": img, "in.flow": flow, "in.gout": gout, "out.y": out, "gin.image": img.grad, "gin.flow": flow.grad})
+    # zero flow is NOT identity (align-corners mismatch) -- pin it
+    img = rnd(4, 1, 1, 4, 8)
+    save("op_resample_zero", {"op": "resample"},
+         {"in.image": img, "in.flow": torch.zeros(1, 2, 4, 8), "out.y": ref_utils.resample(img, torch.zeros(1, 2, 4, 8))})
+    # forward-splat occlusion map (utils/ops.py:205-275)
+    for tag, (b, h, w), mag in (("a", (2, 16, 24), 2.0), ("b", (1, 8, 8), 6.0), ("c", (2, 32, 64), 0.7)):
+        flow = rnd(5, b, 2, h, w, scale=mag)
+        flow[:, :, : h // 3] = 0  # a zero-flow band (weights exactly 1/0)
+        flow[:, :, h // 3: h // 2] = torch.round(flow[:, :, h // 3: h // 2] * 2) / 2  # half-pixel flows: exact .5 sums
+        occ = ref_utils.get_occlusion_map(flow)
+        save(f"op_occlusion_{tag}", {"op": "occlusion"},
+             {"in.flow": flow, "out.y": occ, "out.clip": DenseMotionNetwork.clip_mask(occ)})
+    # resize_flow (utils/utils.py:346-354)
+    flow = rnd(6, 2, 2, 16, 32, scale=3.0)
+    for tag, hw in (("a", [4, 8]), ("b", [8, 16]), ("c", [16, 32])):
+        save(f"op_resize_flow_{tag}", {"op": "resize_flow", "size": hw},
+             {"in.flow": flow, "out.y": ref_utils.resize_flow(flow.clone(), hw)})
+    # sparse-motion rasteriser (dense_motion.py:94-168), gt and predicted thetas
+    for tag, (B, H, W) in (("a", (2, 32, 64)), ("b", (1, 128, 256))):
+        batch = make_batch(B, H, W, 1, seed=7)
+        gnn = batch["tracking_gnn"]
+        gnn.targets_theta = gnn.targets_theta.clone()
+        g = torch.Generator().manual_seed(8)
+        gnn.targets_theta[:, :, 0] = 1 + 0.1 * torch.randn(gnn.targets_theta.shape[:2], generator=g)
+        gnn.targets_theta[:, :, 4] = 1 + 0.1 * torch.randn(gnn.targets_theta.shape[:2], generator=g)
+        gnn.targets_theta[:, :, 1] = 0.05 * torch.randn(gnn.targets_theta.shape[:2], generator=g)
+        gnn.targets_theta[0, 0] = torch.tensor([1.0, 0, 0, 0, 1.0, 0])  # identity theta: flow is NOT zero
+        self_ = types.SimpleNamespace(train_params={"num_predicted_frames": 5, "use_fw_of": True},
+                                      warp=DenseMotionNetwork.warp, clip_mask=DenseMotionNetwork.clip_mask)
+        inst = batch["instance_mask"][:, :, 0].float()
+        thetas = {f"theta_{t}": gnn.targets_theta[:, t] * 1.01 for t in range(5)}
+        for use_gt in (True, False):
+            out = DenseMotionNetwork.generate_sparse_motion(self_, gnn, thetas, inst, use_gt)
+            arrays = {"in.instance": inst, "in.targets_theta": gnn.targets_theta, "in.batch": gnn.batch,
+                      "in.ids": gnn.source_frames_nodes_instance_ids,
+                      "out.sparse_motion_bw": out["sparse_motion_bw"], "out.sparse_motion_fw": out["sparse_motion_fw"]}
+            for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+                bits, shp = pack_mask(out[k])
+                arrays["mask." + k] = bits
+                arrays["maskshape." + k] = shp
+            save(f"op_raster_{tag}_{'gt' if use_gt else 'pred'}", {"op": "raster", "use_gt": use_gt}, arrays)
+
+
+def capture_blocks():
+    from modules.layers.down_block import DownBlock2d, DownBlock3d
+    from modules.layers.same_block import SameBlock2d, SameBlockTwoConv2d, SameBlock3d
+    from modules.layers.up_block import UpBlock2d
+    from modules.layers.residual_block import ResidualBlock, ResidualSpadeBlock
+    from modules.layers.spade_block import SpatiallyAdaptiveNorm
+    from modules.motion_estimator.motion_autoencoder import FlowPredictor, OcclusionPredictor
+    from modules.generator.flowembedder import FlowEmbedder
+    from modules.discriminator.discriminator import define_d, GANLoss
+    import losses.losses as L
+    cases = [
+        ("down2d", lambda: DownBlock2d(6, 8, kernel_size=4, stride=2, padding=1, padding_mode="reflect"),
+         {"x": rnd(11, 2, 6, 12, 16)}, dict(k=4, stride=2, padding_mode="reflect")),
+        ("down2d_zeros", lambda: DownBlock2d(3, 5, kernel_size=4, stride=2, padding=1, padding_mode="zeros"),
+         {"x": rnd(12, 2, 3, 8, 8)}, dict(k=4, stride=2, padding_mode="zeros")),
+        ("same2d_k3", lambda: SameBlock2d(5, 7, kernel_size=3, padding=1, padding_mode="reflect"),
+         {"x": rnd(13, 2, 5, 9, 11)}, dict(k=3, padding_mode="reflect", use_norm=True)),
+        ("same2d_k7", lambda: SameBlock2d(3, 4, kernel_size=7, padding=3, padding_mode="reflect"),
+         {"x": rnd(14, 2, 3, 10, 12)}, dict(k=7, padding_mode="reflect", use_norm=True)),
+        ("same2d_nonorm", lambda: SameBlock2d(6, 5, kernel_size=3, padding=1, padding_mode="reflect", use_norm=False),
+         {"x": rnd(15, 1, 6, 8, 8)}, dict(k=3, padding_mode="reflect", use_norm=False)),
+        ("same2conv", lambda: SameBlockTwoConv2d(6, 10, 3, 1, 1, padding_mode="reflect"),
+         {"x": rnd(16, 2, 6, 2, 4)}, {}),
+        ("down3d_k444", lambda: DownBlock3d(5, 6, [4, 4, 4], [2, 2, 2], [1] * 6, "reflect"),
+         {"x": rnd(17, 1, 5, 5, 12, 16)}, dict(stride=[2, 2, 2], pad3=[1, 1, 1])),
+        ("down3d_k344", lambda: DownBlock3d(2, 4, [3, 4, 4], [1, 2, 2], 1, "reflect"),
+         {"x": rnd(18, 2, 2, 5, 8, 12)}, dict(stride=[1, 2, 2], pad3=[1, 1, 1])),
+        ("down3d_k144", lambda: DownBlock3d(4, 6, [1, 4, 4], [1, 2, 2], [1, 1, 1, 1, 0, 0], "reflect"),
+         {"x": rnd(19, 2, 4, 1, 4, 8)}, dict(stride=[1, 2, 2], pad3=[0, 1, 1])),
+        ("down3d_k133", lambda: DownBlock3d(4, 4, [1, 3, 3], [1, 1, 1], [1, 1, 1, 1, 0, 0], "reflect"),
+         {"x": rnd(20, 2, 4, 1, 2, 4)}, dict(stride=[1, 1, 1], pad3=[0, 1, 1])),
+        ("same3d", lambda: SameBlock3d(6, 4, 3, 1, 1, padding_mode="reflect"),
+         {"x": rnd(21, 2, 6, 5, 6, 8)}, dict(stride=[1, 1, 1], pad3=[1, 1, 1])),
+        ("up2d", lambda: UpBlock2d(6, 4, padding_mode="reflect"), {"x": rnd(22, 2, 6, 5, 4, 6)}, {}),
+        ("resblock", lambda: ResidualBlock(8, 8, 3, 1), {"x": rnd(23, 2, 8, 6, 8)}, {}),
+        ("spade_res_sc", lambda: ResidualSpadeBlock([6], 8, 4, 3, 1, None),
+         {"x": rnd(24, 2, 8, 6, 8), "c": rnd(25, 2, 6, 6, 8)}, {}),
+        ("spade_res_id", lambda: ResidualSpadeBlock([6], 4, 4, 3, 1, None),
+         {"x": rnd(26, 2, 4, 6, 8), "c": rnd(27, 2, 6, 6, 8)}, {}),
+        ("spade_norm", lambda: SpatiallyAdaptiveNorm(5, [3]), {"x": rnd(28, 2, 5, 6, 8), "c": rnd(29, 2, 3, 6, 8)}, {}),
+        ("flow_head", lambda: FlowPredictor(2, 6), {"x": rnd(30, 2, 6, 8, 12)}, {}),
+        ("occ_head", lambda: OcclusionPredictor(6, 0), {"x": rnd(31, 2, 6, 8, 12)}, {}),
+    ]
+    for name, ctor, inputs, meta in cases:
+        mod = ctor()
+        if name.startswith("spade"):
+            call = lambda m, x, c: m(x, c)
+        else:
+            call = None
+        spec, arrays = run_module(mod, 1000 + len(name), inputs, call=call, grad_inputs=("x",))
+        meta = dict(meta, block=name, spec=spec, seed=1000 + len(name))
+        save("blk_" + name, meta, arrays)
+
+    # FlowEmbedder (flowembedder.py)
+    fp = dict(input_channel=6, block_expansion=4, num_down_blocks=3, max_expansion=32, padding_mode="reflect", use_decoder=True)
+    mod = FlowEmbedder(fp)
+    spec, arrays = run_module(mod, 2001, {"x": rnd(40, 2, 6, 16, 32)}, call=lambda m, x: {f"f{i}": v for i, v in enumerate(m(x))},
+                              grad_inputs=("x",))
+    save("blk_flowembedder", dict(block="flowembedder", spec=spec, seed=2001, flow_embedder=fp), arrays)
+
+    # Discriminator + LSGAN (discriminator.py)
+    mod = define_d(3, 4, 4, 1, "reflect")
+    gan = GANLoss()
+
+    def call_d(m, x):
+        o = m(x)
+        feats = {f"feat{i}": f for i, f in enumerate(o["feature_maps_0"])}
+        feats["pred"] = o["prediction_map_0"]
+        feats["gan_real"] = gan(o["prediction_map_0"], True)
+        feats["gan_fake"] = gan(o["prediction_map_0"], False)
+        return feats
+    spec, arrays = run_module(mod, 2002, {"x": rnd(41, 3, 3, 32, 64)}, call=call_d, grad_inputs=("x",))
+    save("blk_discriminator", dict(block="discriminator", spec=spec, seed=2002, ndf=4), arrays)
+
+    # scalar losses (losses.py)
+    a, b = torch.rand(2, 3, 5, 12, 16, generator=torch.Generator().manual_seed(50)), torch.rand(
+        2, 3, 5, 12, 16, generator=torch.Generator().manual_seed(51))
+    m = (torch.rand(2, 1, 5, 12, 16, generator=torch.Generator().manual_seed(52)) > 0.3).float()
+    a.requires_grad_(True)
+    ssim = L.SSIMLoss()(a, b)
+    l1 = L.L1MaskedLoss()(a, b)
+    l1m = L.L1MaskedLoss()(a, b, m)
+    (ssim * 1.5 + l1 * 0.7 + l1m * 2.0).backward()
+    mu, lv = rnd(53, 3, 16).requires_grad_(True), rnd(54, 3, 16, scale=0.3).requires_grad_(True)
+    kl = L.KLLoss()(mu, lv)
+    kl.backward()
+    save("op_losses", {"op": "losses"},
+         {"in.a": a, "in.b": b, "in.mask": m, "in.mu": mu, "in.logvar": lv, "out.ssim": ssim, "out.l1": l1,
+          "out.l1_masked": l1m, "out.kl": kl, "gin.a": a.grad, "gin.mu": mu.grad, "gin.logvar": lv.grad})
+
+    # perceptual loss / VGG-19 (losses.py:23-70, vgg.py); weights synthesised (20 M params are not stored)
+    tp = {"num_predicted_frames": 5, "loss_weights": {"perceptual": 10, "style": 0}}
+    mod = L.PerceptualLoss(tp)
+    gt = torch.rand(1, 3, 5, 32, 64, generator=torch.Generator().manual_seed(60))
+    fk = torch.rand(1, 3, 5, 32, 64, generator=torch.Generator().manual_seed(61))
+    spec, arrays = run_module(mod, 2003, {"gt": gt, "fake": fk}, grad_inputs=("fake",))
+    taps = mod.vgg19(fk[:, :, 0])
+    for k in ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1"):
+        arrays["sum.tap_" + k] = summarize(taps[k])
+    arrays = {k: v for k, v in arrays.items() if not k.startswith("buf.")}
+    save("blk_perceptual", dict(block="perceptual", spec=spec, seed=2003), arrays)
+
+
+def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed):
+    from modules.model import GeneratorFullModel
+    cfg = normalize_config(default_config(num_input_frames=t_in, block_expansion=4, max_expansion=32, h_dim=32,
+                                          z_dim=16, out_channel=16, ndf=4, use_spade=use_spade,
+                                          use_image_discriminator=use_d, use_video_discriminator=use_d))
+    cfg["train_params"]["use_gt_training"] = use_gt_training
+    ref_cfg = copy.deepcopy(cfg)
+    model = GeneratorFullModel(train_params=ref_cfg["train_params"], model_params=ref_cfg["model_params"],
+                               dataset="cityscapes")
+    spec = state_spec(model.state_dict())
+    model.load_state_dict(synth_state(spec, seed))
+    model.train()
+    batch = make_batch(batch_size, 128, 256, t_in, seed=seed)
+    gnn = batch["tracking_gnn"]
+    N, B = gnn.x.shape[0], batch_size
+    # replicate the reference's three random draws so the oracle/product can be fed the same values
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    latent = torch.FloatTensor(N, 5, 16).normal_(0, 1)
+    eps = torch.randn(B, 32)
+    clicks, tot = [], 0
+    for n in gnn.num_real_nodes:
+        clicks.append(np.random.random_integers(0, int(n) - 1) + tot)
+        tot += int(n)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    ref_batch = dict(batch)
+    ref_batch["tracking_gnn"] = gnn.clone()
+    out, lg, ldi, ldv = model(ref_batch)
+    w = cfg["train_params"]["loss_weights"]
+    total = torch.tensor(0.0)
+    for k in lg:
+        total = total + lg[k] * w[k]
+    if ldi:
+        ((ldi["d_real"] + ldi["d_fake"]) * 0.5).backward()
+    if ldv:
+        ((ldv["d_real"] + ldv["d_fake"]) * 0.5).backward()
+    total.backward()
+    arrays = {"rng.latent_traj": latent, "rng.eps": eps, "rng.click_index": torch.tensor(clicks)}
+    for k, v in lg.items():
+        arrays["loss." + k] = v.detach() if torch.is_tensor(v) else torch.tensor(float(v))
+    for k, v in ldi.items():
+        arrays["loss_d_image." + k] = v.detach()
+    for k, v in ldv.items():
+        arrays["loss_d_video." + k] = v.detach()
+    arrays["loss.total_gen"] = total.detach()
+    for k, v in out.items():
+        if k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+            arrays["mask." + k], arrays["maskshape." + k] = pack_mask(v)
+        else:
+            arrays["sum.out." + k] = summarize(v)
+            if v.dim() == 5:
+                arrays["sub.out." + k] = v[:, :, :, ::16, ::16].detach()
+            else:
+                arrays["out." + k] = v.detach()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            arrays["sum.grad." + k] = summarize(p.grad)
+    arrays["nograd"] = np.frombuffer(json.dumps(
+        [k for k, p in model.named_parameters() if p.requires_grad and p.grad is None]).encode(), dtype=np.uint8)
+    for k, b in model.named_buffers():
+        if k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+            arrays["sum.buf." + k] = summarize(b)
+    meta = dict(t_in=t_in, use_spade=use_spade, batch_size=batch_size, use_gt_training=use_gt_training,
+                use_d=use_d, seed=seed, spec=spec, cfg=cfg)
+    save(name, meta, arrays)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_utils = ref_shims.install()
+    torch.set_num_threads(8)
+    print("ops");      capture_ops(ref_utils)
+    print("blocks");   capture_blocks()
+    print("e2e")
+    capture_e2e("e2e_tin2_spade_full", 2, True, 2, True, True, 3)
+    capture_e2e("e2e_tin1_nospade_pred", 1, False, 1, False, False, 4)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,225 @@
+"""Pins the oracle (oracle/c2m_oracle.py) against golden vectors captured from the live reference.
+
+CPU only.  Float comparisons use rtol 1e-5 / atol 1e-6 (bitwise-equal in the capture container; a
+different host CPU may pick other oneDNN kernels); index/mask paths are compared bit for bit.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c2m_oracle as O
+from oracle.golden_util import synth_state, summarize
+from c2m_amd.synthetic import make_batch, GraphBatch
+from golden_io import Case, names
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, what=""):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    torch.testing.assert_close(a.double(), b.double(), rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+def rnd(seed, *shape):
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(seed))
+
+
+# ----------------------------------------------------------------------------------- ops
+@pytest.mark.parametrize("name", names("op_resample"))
+def test_resample(name):
+    c = Case(name)
+    i = c.group("in")
+    img = i["image"].clone().requires_grad_(True)
+    flow = i["flow"].clone().requires_grad_(True)
+    y = O.resample(img, flow)
+    close(y, c.group("out")["y"], what="resample fwd")
+    if "gout" in i:
+        (y * i["gout"]).sum().backward()
+        g = c.group("gin")
+        close(img.grad, g["image"], what="d/d image")
+        close(flow.grad, g["flow"], rtol=1e-4, atol=1e-5, what="d/d flow")
+
+
+def test_resample_zero_flow_is_not_identity():
+    c = Case("op_resample_zero")
+    i = c.group("in")
+    y = O.resample(i["image"], i["flow"])
+    close(y, c.group("out")["y"])
+    assert (y - i["image"]).abs().max() > 0.05  # align-corners mismatch
+
+
+@pytest.mark.parametrize("name", names("op_occlusion"))
+def test_occlusion_map(name):
+    c = Case(name)
+    occ = O.occlusion_map(c.group("in")["flow"])
+    o = c.group("out")
+    close(occ, o["y"], what="occlusion map")
+    assert torch.equal(O.clip_mask(occ), o["clip"]), "clip_mask must be bit-exact"
+
+
+@pytest.mark.parametrize("name", names("op_resize_flow"))
+def test_resize_flow(name):
+    c = Case(name)
+    close(O.resize_flow(c.group("in")["flow"], c.meta["size"]), c.group("out")["y"])
+
+
+@pytest.mark.parametrize("name", names("op_raster"))
+def test_sparse_motion_raster(name):
+    c = Case(name)
+    i = c.group("in")
+    gnn = GraphBatch(targets_theta=i["targets_theta"], batch=i["batch"], source_frames_nodes_instance_ids=i["ids"])
+    thetas = {f"theta_{t}": i["targets_theta"][:, t] * 1.01 for t in range(5)}
+    cfg = {"train_params": {"num_predicted_frames": 5}}
+    out = O.generate_sparse_motion(cfg, gnn, thetas, i["instance"], c.meta["use_gt"])
+    o = c.group("out")
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+        mism = int((out[k] != c.mask(k)).sum())
+        assert mism == 0, f"{k}: {mism} mismatching pixels (index/mask path must be bit-exact)"
+    assert torch.equal(out["sparse_motion_bw"] != 0, o["sparse_motion_bw"] != 0), "flow support differs"
+    close(out["sparse_motion_bw"], o["sparse_motion_bw"], what="sparse_motion_bw")
+    close(out["_sparse_motion_fw"], o["sparse_motion_fw"], what="sparse_motion_fw")
+
+
+def test_losses():
+    c = Case("op_losses")
+    i, o, g = c.group("in"), c.group("out"), c.group("gin")
+    a = i["a"].clone().requires_grad_(True)
+    ssim = O.ssim_loss(O.fold_time(a), O.fold_time(i["b"]))
+    l1 = O.masked_l1(a, i["b"])
+    l1m = O.masked_l1(a, i["b"], i["mask"])
+    (ssim * 1.5 + l1 * 0.7 + l1m * 2.0).backward()
+    mu, lv = i["mu"].clone().requires_grad_(True), i["logvar"].clone().requires_grad_(True)
+    kl = O.kl_loss(mu, lv)
+    kl.backward()
+    for got, key in ((ssim, "ssim"), (l1, "l1"), (l1m, "l1_masked"), (kl, "kl")):
+        close(got, o[key], what=key)
+    close(a.grad, g["a"], what="d a")
+    close(mu.grad, g["mu"])
+    close(lv.grad, g["logvar"])
+
+
+# ----------------------------------------------------------------------------------- blocks
+def _block_call(c, S, x, extra):
+    m, b = c.meta, c.meta["block"]
+    if b.startswith("down2d"):
+        return {"y": O.down_block2d(S, "", x, m["padding_mode"])}
+    if b.startswith("same2d"):
+        return {"y": O.same_block2d(S, "", x, m["k"], m["padding_mode"], m["use_norm"])}
+    if b == "same2conv":
+        return {"y": O.same_block_two_conv2d(S, "", x, "reflect")}
+    if b.startswith(("down3d", "same3d")):
+        return {"y": O.block3d(S, "", x, tuple(m["stride"]), tuple(m["pad3"]), "reflect")}
+    if b == "up2d":
+        return {"y": O.unfold_time(O.up_block2d(S, "", O.fold_time(x), "reflect"), 5)}
+    if b == "resblock":
+        return {"y": O.residual_block(S, "", x)}
+    if b.startswith("spade_res"):
+        return {"y": O.residual_spade_block(S, "", x, extra["c"])}
+    if b == "spade_norm":
+        return {"y": O.spade_norm(S, "", x, extra["c"])}
+    if b == "flow_head":
+        return {"y": O.predictor_head(S, "", x, "flow_predictor", False)}
+    if b == "occ_head":
+        return {"y": O.predictor_head(S, "", x, "occlusion_predictor", True)}
+    if b == "flowembedder":
+        cfg = {"model_params": {"flow_embedder": m["flow_embedder"]}}
+        return {f"f{i}": v for i, v in enumerate(O.flow_embedder(S, "", cfg, x))}
+    if b == "discriminator":
+        cfg = {"model_params": {"discriminator": {"n_layers_D": 4, "padding_mode": "reflect"}}}
+        feats, pred = O.discriminator(S, "", cfg, x)
+        out = {f"feat{i}": f for i, f in enumerate(feats)}
+        out.update(pred=pred, gan_real=O.lsgan(pred, True), gan_fake=O.lsgan(pred, False))
+        return out
+    raise KeyError(b)
+
+
+@pytest.mark.parametrize("name", [n for n in names("blk_") if n != "blk_perceptual"])
+def test_block(name):
+    c = Case(name)
+    seed = c.meta["seed"]
+    S = O.State(synth_state(c.meta["spec"], seed))
+    i = c.group("in")
+    x = i["x"].clone().requires_grad_(True)
+    outs = _block_call(c, S, x, i)
+    total = 0
+    for j, (k, v) in enumerate(sorted(outs.items())):
+        if v.requires_grad:
+            total = total + (v * rnd(seed + 100 + j, *v.shape)).sum()
+    total.backward()
+    for k, ref in c.group("out").items():
+        close(outs[k], ref, what=f"{name} out.{k}")
+    close(x.grad, c.group("gin")["x"], rtol=1e-4, atol=1e-5, what=f"{name} dx")
+    grads = S.grads()
+    ref_grads = c.group("grad")
+    assert set(grads) == set(ref_grads), f"{name}: params with grads differ: {set(grads) ^ set(ref_grads)}"
+    for k, ref in ref_grads.items():
+        close(grads[k], ref, rtol=1e-4, atol=1e-5, what=f"{name} grad.{k}")
+    for k, ref in c.group("buf").items():
+        close(S[k], ref, what=f"{name} buf.{k}")
+
+
+def test_perceptual_vgg():
+    c = Case("blk_perceptual")
+    S = O.State(synth_state(c.meta["spec"], c.meta["seed"]), frozen_prefixes=("vgg19.",))
+    i = c.group("in")
+    fake = i["fake"].clone().requires_grad_(True)
+    loss = O.perceptual_loss(S, "", i["gt"], fake, 5)
+    close(loss, c.group("out")["perceptual"], what="perceptual")
+    (loss * rnd(c.meta["seed"] + 100)).sum().backward()
+    close(fake.grad, c.group("gin")["fake"], rtol=1e-4, atol=1e-6)
+    taps = O.vgg19_taps(S, "vgg19", i["fake"][:, :, 0])
+    for k in ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1"):
+        close(summarize(taps[k]), c.arr["sum.tap_" + k], rtol=1e-5, atol=1e-5, what=k)
+
+
+# ----------------------------------------------------------------------------------- whole step
+@pytest.mark.parametrize("name", names("e2e_"))
+def test_end_to_end_step(name):
+    c = Case(name)
+    m = c.meta
+    cfg = m["cfg"]
+    S = O.State(synth_state(m["spec"], m["seed"]))
+    batch = make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"])
+    rng = c.group("rng")
+    rng["click_index"] = rng["click_index"].long()
+    out, lg, ldi, ldv = O.forward(S, cfg, batch, rng)
+    tot = O.train_step_backward(cfg, lg, ldi, ldv)
+    ref_l = c.group("loss")
+    assert list(lg.keys()) == [k for k in ref_l if k != "total_gen"], "loss dict keys / order"
+    for k, v in lg.items():
+        close(v, ref_l[k], what=f"loss {k}")
+    close(tot["total_gen"], ref_l["total_gen"], what="total_gen")
+    for k, v in c.group("loss_d_image").items():
+        close(ldi[k], v)
+    for k, v in c.group("loss_d_video").items():
+        close(ldv[k], v)
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+        assert int((out[k] != c.mask(k)).sum()) == 0, f"{k} not bit-exact"
+    for k, ref in c.group("sub.out").items():
+        close(out[k][:, :, :, ::16, ::16], ref, rtol=1e-4, atol=1e-5, what=f"out {k}")
+    for k, ref in c.group("out").items():
+        close(out[k], ref, rtol=1e-4, atol=1e-5, what=f"out {k}")
+    for k, ref in c.group("sum.out").items():
+        close(summarize(out[k]), ref, rtol=1e-4, atol=1e-4, what=f"sum out {k}")
+    grads = S.grads()
+    ref_g = c.group("sum.grad")
+    assert set(grads) == set(ref_g), f"grad key set differs: {sorted(set(grads) ^ set(ref_g))[:5]}"
+    for k, ref in ref_g.items():
+        close(summarize(grads[k]), ref, rtol=2e-3, atol=1e-5, what=f"grad {k}")
+    nograd = [k for k, v in S.t.items() if v.requires_grad and v.grad is None]
+    assert sorted(nograd) == sorted(c.json("nograd")), "set of trainable params that never get a gradient"
+    for k, ref in c.group("sum.buf").items():
+        close(summarize(S[k]), ref, rtol=1e-4, atol=1e-5, what=f"buf {k}")
+
+
+def test_state_dict_surface():
+    """The full-model key surface (724 entries at t_in=2) is a compatibility contract."""
+    c = Case("e2e_tin2_spade_full")
+    keys = [k for k, _, _ in c.meta["spec"]]
+    assert len(keys) == 724
+    for prefix in ("appearance_encoder.", "motion_encoder.sparse_motion_estimator.", "motion_encoder.dense_generator_bw.",
+                   "generator.flowembedder.", "objective_func.perceptual_loss.vgg19.", "netD_image.discs.0.",
+                   "netD_video.discs.0."):
+        assert any(k.startswith(prefix) for k in keys), prefix
+    assert "netD_image.discs.0.conv.weight_orig" in keys and "netD_image.discs.0.conv.weight_u" in keys
