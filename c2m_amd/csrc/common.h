@@ -1,0 +1,66 @@
+// Shared helpers for the c2m_amd HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define C2M_API extern "C" __attribute__((visibility("default")))
+
+// Every entry point returns hipError_t as int; kernels never allocate or synchronise.
+#define C2M_LAUNCH_CHECK()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+static inline int c2m_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// memory-bound kernels: cap the grid and grid-stride (cdna guide, Guideline 11)
+static inline int c2m_grid(long work_items, int block) {
+    long g = (work_items + block - 1) / block;
+    const long cap = 256L * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). Result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* smem /* >= 4 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    return smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+__device__ __forceinline__ double block_sum_256_d(double v, double* smem /* >= 4 doubles */) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    return smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float c2m_act(float v, int act, float slope) {
+    switch (act) {
+        case C2M_ACT_RELU: return v > 0.f ? v : 0.f;
+        case C2M_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case C2M_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}

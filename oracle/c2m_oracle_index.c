@@ -1,0 +1,176 @@
+/* TEST INFRASTRUCTURE -- plain-C restatement of the index/mask arithmetic of the C2M hot path.
+ *
+ * Only tests/, __graft_entry__ (build + smoke) and bench.py's cpu_baseline leg may load this library.
+ * It restates, scalar and in IEEE fp32 with the operation order spelled out (so that a GPU kernel can
+ * be written to the same order), what ATen's CPU kernels compute for:
+ *
+ *   oc_resample          utils/ops.py:183-202  (get_grid + grid_sample bilinear/border, align_corners False)
+ *   oc_affine_warp_mask  motion_estimator/dense_motion.py:162-168 (affine_grid + grid_sample zeros pad)
+ *   oc_sparse_raster     motion_estimator/dense_motion.py:94-153 (object loop, where(warped==1,...))
+ *   oc_occlusion_splat   utils/ops.py:205-275 (forward splat via scatter_add_, sequential index order)
+ *
+ * The arithmetic variants (`fma_mode` bit flags) exist because "warped == 1" is a float equality on a
+ * bilinear sum: the golden vectors decide which variant is the reference's, and
+ * tests/test_oracle_golden.py freezes it (see ORACLE_FMA_MODE in tests).
+ *   bit0: unnormalize as fma(g+1, size/2, -0.5)      (else mul then sub)
+ *   bit1: bilinear accumulate with fma chain         (else mul/add)
+ *   bit2: affine_grid 3-term dot as fma chain        (else mul/add, x*t0 + y*t1 + t2)
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC (contraction off: every fma here is explicit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static float linspace_m1_1(int i, int steps) {
+    /* at::linspace CPU kernel: step = (end-start)/(steps-1) in fp32; first half fma(step, i, start), second half
+     * fma(-step, steps-1-i, end) -- the contraction is what this build's ATen does (probed bit-exact for every size tried) */
+    if (steps <= 1) return -1.0f;
+    float step = 2.0f / (float)(steps - 1);
+    int half = steps / 2;
+    if (i < half) return fmaf(step, (float)i, -1.0f);
+    return fmaf(-step, (float)(steps - 1 - i), 1.0f);
+}
+
+static float unnormalize(float g, int size, int mode) {
+    float sf = (float)size / 2.0f;
+    if (mode & 1) return fmaf(g + 1.0f, sf, -0.5f);
+    return (g + 1.0f) * sf - 0.5f;
+}
+
+static float bilinear4(float nw, float ne, float sw, float se, float vnw, float vne, float vsw, float vse, int mode) {
+    if (mode & 2) {
+        float o = vnw * nw;
+        o = fmaf(vne, ne, o);
+        o = fmaf(vsw, sw, o);
+        o = fmaf(vse, se, o);
+        return o;
+    }
+    return ((vnw * nw + vne * ne) + vsw * sw) + vse * se;
+}
+
+/* image [N,C,H,W], flow [N,2,H,W] (pixels) -> out [N,C,H,W]; optional occ [N,1,H,W] multiplied in */
+void oc_resample(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H, int W,
+                 int mode) {
+    const float cx = (float)(((double)W - 1.0) / 2.0), cy = (float)(((double)H - 1.0) / 2.0);
+    for (int n = 0; n < N; ++n)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float gx = linspace_m1_1(x, W) + flow[((long)(n * 2 + 0) * H + y) * W + x] / cx;
+                float gy = linspace_m1_1(y, H) + flow[((long)(n * 2 + 1) * H + y) * W + x] / cy;
+                float ix = unnormalize(gx, W, mode), iy = unnormalize(gy, H, mode);
+                ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+                iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+                float xw = floorf(ix), yn = floorf(iy);
+                float w_ = ix - xw, e_ = 1.0f - w_, n_ = iy - yn, s_ = 1.0f - n_;
+                float nw = s_ * e_, ne = s_ * w_, sw = n_ * e_, se = n_ * w_;
+                int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+                int okx1 = x1 < W, oky1 = y1 < H;
+                for (int c = 0; c < C; ++c) {
+                    const float* p = img + (long)(n * C + c) * H * W;
+                    float vnw = p[y0 * W + x0];
+                    float vne = okx1 ? p[y0 * W + x1] : 0.0f;
+                    float vsw = oky1 ? p[y1 * W + x0] : 0.0f;
+                    float vse = (okx1 && oky1) ? p[y1 * W + x1] : 0.0f;
+                    float o = bilinear4(nw, ne, sw, se, vnw, vne, vsw, vse, mode);
+                    if (occ) o = o * occ[((long)n * H + y) * W + x];
+                    out[((long)(n * C + c) * H + y) * W + x] = o;
+                }
+            }
+}
+
+/* affine_grid(theta[2x3], align_corners False) coordinate for output pixel (y,x) */
+static void affine_coord(const float* th, int y, int x, int H, int W, int mode, float* gx, float* gy) {
+    /* base = linspace(-1,1,n) * (n-1) / n */
+    float bx = linspace_m1_1(x, W) * (float)(W - 1) / (float)W;
+    float by = linspace_m1_1(y, H) * (float)(H - 1) / (float)H;
+    if (W <= 1) bx = 0.0f;
+    if (H <= 1) by = 0.0f;
+    if (mode & 4) {
+        *gx = fmaf(1.0f, th[2], fmaf(by, th[1], bx * th[0]));
+        *gy = fmaf(1.0f, th[5], fmaf(by, th[4], bx * th[3]));
+    } else {
+        *gx = (bx * th[0] + by * th[1]) + th[2];
+        *gy = (bx * th[3] + by * th[4]) + th[5];
+    }
+}
+
+/* warped = grid_sample(mask, affine_grid(theta), zeros pad, align False); flow = (grid - base_alignTrue)*((W-1)/2,(H-1)/2) */
+void oc_affine_warp_mask(const float* mask, const float* theta, float* warped, float* flow, int H, int W, int mode) {
+    const float cx = (float)(((double)W - 1.0) / 2.0), cy = (float)(((double)H - 1.0) / 2.0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float gx, gy;
+            affine_coord(theta, y, x, H, W, mode, &gx, &gy);
+            flow[(0 * H + y) * W + x] = (gx - linspace_m1_1(x, W)) * cx;
+            flow[(1 * H + y) * W + x] = (gy - linspace_m1_1(y, H)) * cy;
+            float ix = unnormalize(gx, W, mode), iy = unnormalize(gy, H, mode);
+            float xw = floorf(ix), yn = floorf(iy);
+            float w_ = ix - xw, e_ = 1.0f - w_, n_ = iy - yn, s_ = 1.0f - n_;
+            float nw = s_ * e_, ne = s_ * w_, sw = n_ * e_, se = n_ * w_;
+            long x0 = (long)xw, y0 = (long)yn, x1 = x0 + 1, y1 = y0 + 1;
+            int ox0 = x0 >= 0 && x0 < W, ox1 = x1 >= 0 && x1 < W, oy0 = y0 >= 0 && y0 < H, oy1 = y1 >= 0 && y1 < H;
+            float vnw = (ox0 && oy0) ? mask[y0 * W + x0] : 0.0f;
+            float vne = (ox1 && oy0) ? mask[y0 * W + x1] : 0.0f;
+            float vsw = (ox0 && oy1) ? mask[y1 * W + x0] : 0.0f;
+            float vse = (ox1 && oy1) ? mask[y1 * W + x1] : 0.0f;
+            warped[y * W + x] = bilinear4(nw, ne, sw, se, vnw, vne, vsw, vse, mode);
+        }
+}
+
+/* instance [B,H,W] (float ids), per-object inst_id / batch index / thetas [K,T,6] -> bw, fw [B,2,T,H,W], bin [B,1,T,H,W]
+ * Objects are applied in order; later objects overwrite earlier ones (torch.where chain). scratch: 4*H*W floats. */
+void oc_sparse_raster(const float* instance, const int64_t* inst_id, const int64_t* batch_id, const float* thetas,
+                      float* bw, float* fw, float* bin, float* scratch, int B, int K, int T, int H, int W, int mode) {
+    const long HW = (long)H * W;
+    memset(bw, 0, sizeof(float) * B * 2 * T * HW);
+    memset(fw, 0, sizeof(float) * B * 2 * T * HW);
+    memset(bin, 0, sizeof(float) * B * T * HW);
+    float* mask = scratch;
+    float* warped = scratch + HW;
+    float* flow = scratch + 2 * HW; /* needs 2*HW */
+    for (int k = 0; k < K; ++k) {
+        if (inst_id[k] == 0) continue;
+        const int b = (int)batch_id[k];
+        for (long i = 0; i < HW; ++i) mask[i] = instance[b * HW + i] == (float)inst_id[k] ? 1.0f : 0.0f;
+        for (int t = 0; t < T; ++t) {
+            oc_affine_warp_mask(mask, thetas + ((long)k * T + t) * 6, warped, flow, H, W, mode);
+            for (int c = 0; c < 2; ++c)
+                for (long i = 0; i < HW; ++i) {
+                    const long o = (((long)b * 2 + c) * T + t) * HW + i;
+                    if (warped[i] == 1.0f) bw[o] = flow[c * HW + i];
+                    if (mask[i] == 1.0f) fw[o] = flow[c * HW + i] * -1.0f;
+                }
+            for (long i = 0; i < HW; ++i)
+                if (warped[i] == 1.0f) bin[((long)b * T + t) * HW + i] = warped[i];
+        }
+    }
+}
+
+/* flow [B,2,H,W] -> occ [B,1,H,W] = clamp(scatter_add of bilinear splat weights, 0, 1); sequential order of the
+ * reference's index list: all (x_ceil,y_ceil) contributions in pixel order, then (x_ceil,y_floor), (x_floor,y_ceil),
+ * (x_floor,y_floor). */
+void oc_occlusion_splat(const float* flow, float* occ, int B, int H, int W) {
+    const long HW = (long)H * W;
+    for (int b = 0; b < B; ++b) {
+        float* acc = occ + b * HW;
+        for (long i = 0; i < HW; ++i) acc[i] = 0.0f;
+        for (int cls = 0; cls < 4; ++cls)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    const float px = (float)x + flow[((long)(b * 2 + 0) * H + y) * W + x];
+                    const float py = (float)y + flow[((long)(b * 2 + 1) * H + y) * W + x];
+                    const float xf0 = floorf(px), yf0 = floorf(py), xc0 = xf0 + 1.0f, yc0 = yf0 + 1.0f;
+                    const float xf = fminf(fmaxf(xf0, 0.0f), (float)(W - 1)), yf = fminf(fmaxf(yf0, 0.0f), (float)(H - 1));
+                    const float xc = fminf(fmaxf(xc0, 0.0f), (float)(W - 1)), yc = fminf(fmaxf(yc0, 0.0f), (float)(H - 1));
+                    const int use_xc = cls < 2, use_yc = (cls & 1) == 0;
+                    const float tx = use_xc ? xc : xf, ty = use_yc ? yc : yf;
+                    const int bad = (use_xc ? xc0 != xc : xf0 != xf) || (use_yc ? yc0 != yc : yf0 != yf);
+                    float v = (1.0f - fabsf(px - tx)) * (1.0f - fabsf(py - ty));
+                    if (bad) v = 0.0f;
+                    /* index = (tx + ty*w).long(), computed in float like the reference */
+                    const long idx = (long)(tx + ty * (float)W);
+                    acc[idx] += v;
+                }
+        for (long i = 0; i < HW; ++i) acc[i] = fminf(fmaxf(acc[i], 0.0f), 1.0f);
+    }
+}

@@ -223,3 +223,87 @@ def test_state_dict_surface():
                    "netD_video.discs.0."):
         assert any(k.startswith(prefix) for k in keys), prefix
     assert "netD_image.discs.0.conv.weight_orig" in keys and "netD_image.discs.0.conv.weight_u" in keys
+
+
+# ----------------------------------------------------------------------------------- C restatement (index paths)
+def _c_lib():
+    from oracle import build as ob
+    return ob.load(), ob.FMA_MODE
+
+
+def _ptr(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("name", names("op_resample"))
+def test_c_oracle_resample_bitexact(name):
+    lib, mode = _c_lib()
+    c = Case(name)
+    img, flow = c.arr["in.image"], c.arr["in.flow"]
+    out = np.zeros_like(c.arr["out.y"])
+    n, ch, h, w = img.shape
+    lib.oc_resample(_ptr(np.ascontiguousarray(img)), _ptr(np.ascontiguousarray(flow)), None, _ptr(out), n, ch, h, w, mode)
+    assert np.array_equal(out, c.arr["out.y"]), f"{int((out != c.arr['out.y']).sum())} elements differ"
+
+
+@pytest.mark.parametrize("name", names("op_raster"))
+def test_c_oracle_raster_bitexact(name):
+    lib, mode = _c_lib()
+    c = Case(name)
+    inst = np.ascontiguousarray(c.arr["in.instance"][:, 0])
+    B, H, W = inst.shape
+    th = c.arr["in.targets_theta"]
+    thetas = np.ascontiguousarray(th if c.meta["use_gt"] else (th * np.float32(1.01)).astype(np.float32))
+    ids = np.ascontiguousarray(c.arr["in.ids"][:, -1].astype(np.int64))
+    bidx = np.ascontiguousarray(c.arr["in.batch"].astype(np.int64))
+    K, T = thetas.shape[0], thetas.shape[1]
+    bw = np.zeros((B, 2, T, H, W), np.float32)
+    fw = np.zeros_like(bw)
+    binm = np.zeros((B, 1, T, H, W), np.float32)
+    scratch = np.zeros(4 * H * W, np.float32)
+    lib.oc_sparse_raster(_ptr(inst), _ptr(ids), _ptr(bidx), _ptr(thetas), _ptr(bw), _ptr(fw), _ptr(binm), _ptr(scratch),
+                         B, K, T, H, W, mode)
+    assert np.array_equal(binm, c.mask("sparse_motion_bin").numpy())
+    assert np.array_equal(bw, c.arr["out.sparse_motion_bw"])
+    assert np.array_equal(fw, c.arr["out.sparse_motion_fw"])
+    for key, flow in (("sparse_occ_bw", fw), ("sparse_occ_fw", bw)):
+        ref = c.mask(key).numpy()
+        for t in range(T):
+            occ = np.zeros((B, 1, H, W), np.float32)
+            lib.oc_occlusion_splat(_ptr(np.ascontiguousarray(flow[:, :, t])), _ptr(occ), B, H, W)
+            assert np.array_equal((occ > 0.5).astype(np.float32), ref[:, :, t]), f"{key} t={t}"
+
+
+@pytest.mark.parametrize("name", names("op_occlusion"))
+def test_c_oracle_occlusion_bitexact(name):
+    lib, _ = _c_lib()
+    c = Case(name)
+    flow = np.ascontiguousarray(c.arr["in.flow"])
+    B, _, H, W = flow.shape
+    occ = np.zeros((B, 1, H, W), np.float32)
+    lib.oc_occlusion_splat(_ptr(flow), _ptr(occ), B, H, W)
+    assert np.array_equal(occ, c.arr["out.y"]), f"{int((occ != c.arr['out.y']).sum())} differ"
+
+
+def test_c_oracle_fma_mode_is_pinned():
+    """Only FMA mode 7 (fused unnormalize, fused bilinear chain, fused affine dot) reproduces the reference's
+    float-equality mask on the big raster fixture; the non-contracted variant must NOT."""
+    lib, mode = _c_lib()
+    assert mode == 7
+    c = Case("op_raster_b_pred")
+    inst = np.ascontiguousarray(c.arr["in.instance"][:, 0])
+    B, H, W = inst.shape
+    thetas = np.ascontiguousarray((c.arr["in.targets_theta"] * np.float32(1.01)).astype(np.float32))
+    ids = np.ascontiguousarray(c.arr["in.ids"][:, -1].astype(np.int64))
+    bidx = np.ascontiguousarray(c.arr["in.batch"].astype(np.int64))
+    K, T = thetas.shape[:2]
+    res = {}
+    for m in (0, 7):
+        bw = np.zeros((B, 2, T, H, W), np.float32)
+        fw = np.zeros_like(bw)
+        binm = np.zeros((B, 1, T, H, W), np.float32)
+        lib.oc_sparse_raster(_ptr(inst), _ptr(ids), _ptr(bidx), _ptr(thetas), _ptr(bw), _ptr(fw), _ptr(binm),
+                             _ptr(np.zeros(4 * H * W, np.float32)), B, K, T, H, W, m)
+        res[m] = int((binm != c.mask("sparse_motion_bin").numpy()).sum())
+    assert res[7] == 0 and res[0] > 0, res
