@@ -1,0 +1,67 @@
+"""ctypes binding of libc2m_hip.so (include/c2m_hip.h).  There is NO fallback: if the library is missing or a tensor
+is not on a HIP device, the op raises -- the product path never silently runs anything else."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libc2m_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "c2m_hip.h")
+_lib = None
+
+c_void_p, c_int, c_long, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+
+_SIGS = {
+    "c2m_conv_igemm": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),
+    "c2m_conv_wgrad_splits": (c_int, [c_int, c_int, c_int]),
+    "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
+    "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
+    "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),
+    "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_void_p]),
+    "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
+    "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
+    "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_void_p]),
+    "c2m_flow_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "c2m_flow_warp_bwd_needs_zero": (c_int, [c_int] * 4),
+    "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_void_p]),
+    "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_maxpool2x2_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p]),
+    "c2m_sparse_raster": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "c2m_occlusion_splat_workspace_bytes": (c_long, [c_long, c_int, c_int]),
+    "c2m_occlusion_splat": (c_int, [c_void_p, c_long, c_long, c_long] + [c_int] * 4 + [c_void_p] * 4),
+    "c2m_l1_mean_fwd": (c_int, [c_void_p] * 4 + [c_long, c_int, c_long, c_void_p, c_void_p]),
+    "c2m_l1_mean_bwd": (c_int, [c_void_p] * 6 + [c_long, c_int, c_long, c_void_p]),
+    "c2m_ssim_fwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p, c_void_p]),
+    "c2m_ssim_bwd": (c_int, [c_void_p] * 5 + [c_long, c_int, c_int, c_void_p]),
+}
+
+
+def declared_symbols():
+    """Every function name declared in include/c2m_hip.h."""
+    with open(HEADER) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(c2m_\w+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"c2m_amd: HIP kernel library not found at {LIB_PATH}. Build it with "
+                "`python -m c2m_amd.build` (needs hipcc); there is no CPU/PyTorch fallback for these ops.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"c2m_amd: {what} failed with hipError_t={rc}")

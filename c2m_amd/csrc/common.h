@@ -60,7 +60,7 @@ __device__ __forceinline__ float c2m_act(float v, int act, float slope) {
     switch (act) {
         case C2M_ACT_RELU: return v > 0.f ? v : 0.f;
         case C2M_ACT_LRELU: return v > 0.f ? v : v * slope;
-        case C2M_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case C2M_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         default: return v;
     }
 }

@@ -1,0 +1,299 @@
+// Normalisation + activation kernels (HBM-bound), gfx950.
+//
+// Fuses what the reference runs as separate ATen ops around every convolution:
+//   BatchNorm2d/3d (train mode, running-stat update)  -> LeakyReLU(0.2)/ReLU   layers/down_block.py:19-22,44-47
+//                                                                              same_block.py:64-67 up_block.py:11-12
+//                                                                              residual_block.py:20-28
+//   InstanceNorm2d(affine)                             -> LeakyReLU            same_block.py:19-22,41-44
+//   SPADE: InstanceNorm2d(affine=False)(x)*(1+gamma)+beta -> LeakyReLU         spade_block.py:68-77,
+//                                                                              residual_block.py:56-70
+// Layout: [N][C][S] with S = (T*)H*W contiguous ("planes").  mode: 0 = per-plane statistics (instance norm),
+// 1 = per-channel statistics over N*S (batch norm).
+//
+// Statistics are a deterministic 3-stage reduction: (plane, chunk) partials (two passes over an L2-resident chunk:
+// mean, then centred sum of squares) -> Chan combination in a fixed order -> mean / invstd (+ running stats).
+// Backward: one reduction pass (sum g', sum g'*xhat, and the SPADE gamma/beta map gradients) + one apply pass.
+#include "common.h"
+
+#define NORM_CHUNK 8192
+
+struct NormShape { int N, C; long S; int mode; int chunks; };
+
+static inline int norm_chunks(long S) { return (int)((S + NORM_CHUNK - 1) / NORM_CHUNK); }
+
+// partial[(plane*chunks + chunk)*2 + {0: mean, 1: M2}]
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                            long S, int chunks) {
+    __shared__ float sm[4];
+    const long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const long beg = (long)chunk * NORM_CHUNK;
+    const long end = beg + NORM_CHUNK < S ? beg + NORM_CHUNK : S;
+    const float* __restrict__ p = x + plane * S;
+    const int cnt = (int)(end - beg);
+    float s = 0.f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) s += p[i];
+    s = block_sum_256(s, sm);
+    const float mean = s / (float)cnt;
+    float m2 = 0.f;
+    for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = p[i] - mean; m2 += d * d; }
+    m2 = block_sum_256(m2, sm);
+    if (threadIdx.x == 0) {
+        partial[(long)blockIdx.x * 2 + 0] = mean;
+        partial[(long)blockIdx.x * 2 + 1] = m2;
+    }
+}
+
+// one thread per statistic (plane for mode 0, channel for mode 1)
+__global__ void norm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean_out,
+                                     float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, NormShape sh, float eps, float momentum) {
+    const int nstat = sh.mode == 0 ? sh.N * sh.C : sh.C;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstat) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int nrep = sh.mode == 0 ? 1 : sh.N;
+    for (int r = 0; r < nrep; ++r) {
+        const long plane = sh.mode == 0 ? i : (long)r * sh.C + i;
+        for (int c = 0; c < sh.chunks; ++c) {
+            const long beg = (long)c * NORM_CHUNK;
+            const double nb = (double)((beg + NORM_CHUNK < sh.S ? beg + NORM_CHUNK : sh.S) - beg);
+            const double mb = partial[(plane * sh.chunks + c) * 2 + 0];
+            const double vb = partial[(plane * sh.chunks + c) * 2 + 1];
+            const double tot = n + nb;
+            const double delta = mb - mean;
+            mean += delta * nb / tot;
+            m2 += vb + delta * delta * n * nb / tot;
+            n = tot;
+        }
+    }
+    const double var = m2 / n;
+    mean_out[i] = (float)mean;
+    invstd_out[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+        running_mean[i] = (float)((1.0 - momentum) * running_mean[i] + momentum * mean);
+        running_var[i] = (float)((1.0 - momentum) * running_var[i] + momentum * unbiased);
+    }
+}
+
+C2M_API long c2m_norm_workspace_floats(int N, int C, long S) { return (long)N * C * norm_chunks(S) * 4; }
+
+C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                           float* workspace, int N, int C, long S, int mode, float eps, float momentum, void* stream) {
+    if ((long)N * C * S <= 0) return 0;
+    NormShape sh{N, C, S, mode, norm_chunks(S)};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(norm_partial_kernel, dim3((unsigned)((long)N * C * sh.chunks)), dim3(256), 0, s, x, workspace, S,
+                       sh.chunks);
+    const int nstat = mode == 0 ? N * C : C;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(c2m_cdiv(nstat, 128)), dim3(128), 0, s, workspace, mean, invstd,
+                       running_mean, running_var, sh, eps, momentum);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- apply (forward)
+// y = act( xhat * scale + shift ), xhat = (x - mean)*invstd
+//   affine: scale = gamma[c], shift = beta[c];  plain: 1, 0;  SPADE: scale = 1 + gb[n, c, s], shift = gb[n, C + c, s]
+struct ApplyP {
+    const float* x; const float* mean; const float* invstd; const float* gamma; const float* beta; const float* gb;
+    float* y;
+    int N, C; long S; int mode; int act; float slope;
+};
+
+__global__ void norm_apply_kernel(const ApplyP p) {
+    const long total = (long)p.N * p.C * p.S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long plane = i / p.S;
+        const long s = i - plane * p.S;
+        const int c = (int)(plane % p.C);
+        const int n = (int)(plane / p.C);
+        const int st = p.mode == 0 ? (int)plane : c;
+        const float xhat = (p.x[i] - p.mean[st]) * p.invstd[st];
+        float v;
+        if (p.gb) {
+            const long gbase = ((long)n * 2 * p.C + c) * p.S + s;
+            v = xhat * (1.0f + p.gb[gbase]) + p.gb[gbase + (long)p.C * p.S];
+        } else if (p.gamma) {
+            v = xhat * p.gamma[c] + p.beta[c];
+        } else {
+            v = xhat;
+        }
+        p.y[i] = c2m_act(v, p.act, p.slope);
+    }
+}
+
+C2M_API int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const float* gb, float* y, int N, int C, long S, int mode, int act,
+                           float slope, void* stream) {
+    const long total = (long)N * C * S;
+    if (total <= 0) return 0;
+    ApplyP p{x, mean, invstd, gamma, beta, gb, y, N, C, S, mode, act, slope};
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- backward
+struct BwdP {
+    const float* x; const float* gy; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    const float* gb;
+    float* ggb;      // SPADE map gradients [N,2C,S] (written in the reduce pass)
+    float* partial;  // [(plane*chunks + chunk)*2]: sum g'*m, sum g'*m*xhat  (m = 1+gamma_map for SPADE else 1)
+    float* coef;     // [nstat*2]: c1, c2 of dx = invstd*(g'*scale - c1 - xhat*c2)
+    float* dgamma; float* dbeta;
+    float* dx;
+    int N, C; long S; int mode; int act; float slope; int chunks;
+};
+
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) {
+    switch (act) {
+        case C2M_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+        case C2M_ACT_LRELU: return pre > 0.f ? 1.f : slope;
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
+    __shared__ float sm[4];
+    const long plane = blockIdx.x / p.chunks;
+    const int chunk = blockIdx.x % p.chunks;
+    const long beg = (long)chunk * NORM_CHUNK;
+    const long end = beg + NORM_CHUNK < p.S ? beg + NORM_CHUNK : p.S;
+    const int c = (int)(plane % p.C);
+    const int n = (int)(plane / p.C);
+    const int st = p.mode == 0 ? (int)plane : c;
+    const float mean = p.mean[st], invstd = p.invstd[st];
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (long s = beg + threadIdx.x; s < end; s += 256) {
+        const long i = plane * p.S + s;
+        const float xhat = (p.x[i] - mean) * invstd;
+        float scale = ga, shift = be;
+        long gbase = 0;
+        if (p.gb) {
+            gbase = ((long)n * 2 * p.C + c) * p.S + s;
+            scale = 1.0f + p.gb[gbase];
+            shift = p.gb[gbase + (long)p.C * p.S];
+        }
+        const float g = p.gy[i] * act_grad(xhat * scale + shift, p.act, p.slope);
+        if (p.gb) {
+            p.ggb[gbase] = g * xhat;
+            p.ggb[gbase + (long)p.C * p.S] = g;
+            s1 += g * scale; s2 += g * scale * xhat;
+        } else {
+            s1 += g; s2 += g * xhat;
+        }
+    }
+    s1 = block_sum_256(s1, sm);
+    s2 = block_sum_256(s2, sm);
+    if (threadIdx.x == 0) {
+        p.partial[(long)blockIdx.x * 2 + 0] = s1;
+        p.partial[(long)blockIdx.x * 2 + 1] = s2;
+    }
+}
+
+__global__ void norm_bwd_finalize_kernel(const BwdP p) {
+    const int nstat = p.mode == 0 ? p.N * p.C : p.C;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.mode == 1) {
+        if (i >= nstat) return;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < p.N; ++r)
+            for (int c = 0; c < p.chunks; ++c) {
+                const long q = (((long)r * p.C + i) * p.chunks + c) * 2;
+                s1 += p.partial[q]; s2 += p.partial[q + 1];
+            }
+        const double cnt = (double)p.N * (double)p.S;
+        const double ga = p.gamma ? (double)p.gamma[i] : 1.0;
+        p.coef[i * 2 + 0] = (float)(ga * s1 / cnt);
+        p.coef[i * 2 + 1] = (float)(ga * s2 / cnt);
+        if (p.dgamma) { p.dgamma[i] = (float)s2; p.dbeta[i] = (float)s1; }
+    } else {
+        // per-plane coefficients; per-channel dgamma/dbeta are finished by thread c over its N planes
+        if (i < nstat) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int c = 0; c < p.chunks; ++c) {
+                const long q = ((long)i * p.chunks + c) * 2;
+                s1 += p.partial[q]; s2 += p.partial[q + 1];
+            }
+            const double ga = p.gamma ? (double)p.gamma[i % p.C] : 1.0;
+            p.coef[i * 2 + 0] = (float)(ga * s1 / (double)p.S);
+            p.coef[i * 2 + 1] = (float)(ga * s2 / (double)p.S);
+        }
+        if (p.dgamma && i < p.C) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < p.N; ++r)
+                for (int c = 0; c < p.chunks; ++c) {
+                    const long q = (((long)r * p.C + i) * p.chunks + c) * 2;
+                    s1 += p.partial[q]; s2 += p.partial[q + 1];
+                }
+            p.dgamma[i] = (float)s2; p.dbeta[i] = (float)s1;
+        }
+    }
+}
+
+__global__ void norm_bwd_apply_kernel(const BwdP p) {
+    const long total = (long)p.N * p.C * p.S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long plane = i / p.S;
+        const long s = i - plane * p.S;
+        const int c = (int)(plane % p.C);
+        const int n = (int)(plane / p.C);
+        const int st = p.mode == 0 ? (int)plane : c;
+        const float invstd = p.invstd[st];
+        const float xhat = (p.x[i] - p.mean[st]) * invstd;
+        float scale = p.gamma ? p.gamma[c] : 1.f, shift = p.gamma ? p.beta[c] : 0.f;
+        if (p.gb) {
+            const long gbase = ((long)n * 2 * p.C + c) * p.S + s;
+            scale = 1.0f + p.gb[gbase];
+            shift = p.gb[gbase + (long)p.C * p.S];
+        }
+        const float g = p.gy[i] * act_grad(xhat * scale + shift, p.act, p.slope);
+        p.dx[i] = invstd * (g * scale - p.coef[st * 2 + 0] - xhat * p.coef[st * 2 + 1]);
+    }
+}
+
+// workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
+C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
+                         float* workspace, int N, int C, long S, int mode, int act, float slope, void* stream) {
+    const long total = (long)N * C * S;
+    if (total <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    BwdP p;
+    p.x = x; p.gy = gy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.gb = gb; p.ggb = ggb;
+    p.chunks = norm_chunks(S);
+    p.partial = workspace;
+    p.coef = workspace + (long)N * C * p.chunks * 2;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dx = dx;
+    p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
+    const int nthreads = mode == 0 ? N * C : C;
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- activation backward
+// For conv epilogue activations (no norm in between): gradient from the OUTPUT y.
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx,
+                               long total, int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float v = y[i], g = gy[i];
+        float d;
+        switch (act) {
+            case C2M_ACT_RELU: d = v > 0.f ? 1.f : 0.f; break;
+            case C2M_ACT_LRELU: d = v > 0.f ? 1.f : slope; break;
+            case C2M_ACT_SIGMOID: d = v * (1.f - v); break;
+            default: d = 1.f;
+        }
+        gx[i] = g * d;
+    }
+}
+
+C2M_API int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream) {
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, gy, gx, total,
+                       act, slope);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,308 @@
+// Optical-flow feature warping and resampling kernels (HBM-bound gathers), gfx950.
+//
+//   c2m_flow_warp_fwd / _bwd   utils/ops.py:183-202  resample(): get_grid (align_corners=True convention) + pixel
+//                              flow, sampled by grid_sample(bilinear, border, align_corners=False); optional fused
+//                              "* occlusion" (motion_autoencoder.py:125, model.py:208).
+//   c2m_upsample2x_fwd / _bwd  nn.Upsample(scale_factor=2, bilinear) (up_block.py:10, generator.py:77)
+//   c2m_resize_bilinear        F.interpolate(size, bilinear) both align modes (utils.py:349, motion_autoencoder.py:123)
+//   c2m_maxpool2x2_fwd / _bwd  VGG-19 pools (vgg.py via torchvision features 4,9,18,27)
+//
+// This file is compiled with -ffp-contract=off: the coordinate arithmetic follows the exact fp32 operation order
+// of ATen's CPU kernels (oracle/c2m_oracle_index.c documents and pins it), every fused multiply-add is explicit.
+// Layout NCHW; a wave covers 64 consecutive x of one row, so the 4 bilinear taps of a smooth flow are coalesced
+// row segments; coordinates/weights are computed once per pixel and reused across a chunk of channels.
+#include "common.h"
+
+__device__ __forceinline__ float lin_m1_1(int i, int steps) {
+    if (steps <= 1) return -1.0f;
+    const float step = 2.0f / (float)(steps - 1);
+    const int half = steps / 2;
+    return i < half ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(steps - 1 - i), 1.0f);
+}
+
+struct WarpCoord {
+    int x0, y0, x1, y1;
+    float nw, ne, sw, se;   // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    float w_, e_, n_, s_;
+    bool okx1, oky1;
+    float gmx, gmy;         // d(ix)/d(flow_x), d(iy)/d(flow_y) incl. the border-clip gate
+};
+
+__device__ __forceinline__ WarpCoord warp_coord(float fx, float fy, int x, int y, int H, int W) {
+    WarpCoord c;
+    const float cx = (float)(((double)W - 1.0) / 2.0), cy = (float)(((double)H - 1.0) / 2.0);
+    const float gx = lin_m1_1(x, W) + fx / cx;
+    const float gy = lin_m1_1(y, H) + fy / cy;
+    float ix = fmaf(gx + 1.0f, (float)W / 2.0f, -0.5f);
+    float iy = fmaf(gy + 1.0f, (float)H / 2.0f, -0.5f);
+    // clip_coordinates_set_grad (ATen GridSampler.h): gradient gate is 0 on/outside the border
+    c.gmx = (ix > 0.0f && ix < (float)(W - 1)) ? ((float)W / 2.0f) / cx : 0.0f;
+    c.gmy = (iy > 0.0f && iy < (float)(H - 1)) ? ((float)H / 2.0f) / cy : 0.0f;
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float xw = floorf(ix), yn = floorf(iy);
+    c.w_ = ix - xw; c.e_ = 1.0f - c.w_; c.n_ = iy - yn; c.s_ = 1.0f - c.n_;
+    c.nw = c.s_ * c.e_; c.ne = c.s_ * c.w_; c.sw = c.n_ * c.e_; c.se = c.n_ * c.w_;
+    c.x0 = (int)xw; c.y0 = (int)yn; c.x1 = c.x0 + 1; c.y1 = c.y0 + 1;
+    c.okx1 = c.x1 < W; c.oky1 = c.y1 < H;
+    return c;
+}
+
+// grid: x = pixel blocks over N*H*W, y = channel chunk
+__global__ void flow_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                     const float* __restrict__ occ, float* __restrict__ out, int N, int C, int H, int W,
+                                     int cchunk) {
+    const long HW = (long)H * W;
+    const long total = (long)N * HW;
+    const int c0 = blockIdx.y * cchunk;
+    const int c1 = min(c0 + cchunk, C);
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W); const long r = p / W;
+        const int y = (int)(r % H); const int n = (int)(r / H);
+        const long sp = (long)y * W + x;
+        const float fx = flow[((long)n * 2 + 0) * HW + sp], fy = flow[((long)n * 2 + 1) * HW + sp];
+        const WarpCoord k = warp_coord(fx, fy, x, y, H, W);
+        const float o = occ ? occ[(long)n * HW + sp] : 1.0f;
+        const long i00 = (long)k.y0 * W + k.x0, i01 = (long)k.y0 * W + k.x1, i10 = (long)k.y1 * W + k.x0,
+                   i11 = (long)k.y1 * W + k.x1;
+        for (int c = c0; c < c1; ++c) {
+            const float* __restrict__ pl = img + ((long)n * C + c) * HW;
+            const float vnw = pl[i00];
+            const float vne = k.okx1 ? pl[i01] : 0.0f;
+            const float vsw = k.oky1 ? pl[i10] : 0.0f;
+            const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
+            float v = vnw * k.nw;
+            v = fmaf(vne, k.ne, v);
+            v = fmaf(vsw, k.sw, v);
+            v = fmaf(vse, k.se, v);
+            if (occ) v = v * o;
+            out[((long)n * C + c) * HW + sp] = v;
+        }
+    }
+}
+
+// gimg (zero-initialised by the caller) accumulated with float atomics; gflow written (each pixel owns its flow);
+// when channels are chunked (gridDim.y > 1) gflow is accumulated with atomics instead and must be zeroed too.
+__global__ void flow_warp_bwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                     const float* __restrict__ occ, const float* __restrict__ gout,
+                                     float* __restrict__ gimg, float* __restrict__ gflow, int N, int C, int H, int W,
+                                     int cchunk) {
+    const long HW = (long)H * W;
+    const long total = (long)N * HW;
+    const int c0 = blockIdx.y * cchunk;
+    const int c1 = min(c0 + cchunk, C);
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W); const long r = p / W;
+        const int y = (int)(r % H); const int n = (int)(r / H);
+        const long sp = (long)y * W + x;
+        const float fx = flow[((long)n * 2 + 0) * HW + sp], fy = flow[((long)n * 2 + 1) * HW + sp];
+        const WarpCoord k = warp_coord(fx, fy, x, y, H, W);
+        const float o = occ ? occ[(long)n * HW + sp] : 1.0f;
+        const long i00 = (long)k.y0 * W + k.x0, i01 = (long)k.y0 * W + k.x1, i10 = (long)k.y1 * W + k.x0,
+                   i11 = (long)k.y1 * W + k.x1;
+        float gix = 0.0f, giy = 0.0f;
+        for (int c = c0; c < c1; ++c) {
+            const long pb = ((long)n * C + c) * HW;
+            const float g = gout[pb + sp] * o;
+            if (gimg) {
+                atomicAdd(gimg + pb + i00, g * k.nw);
+                if (k.okx1) atomicAdd(gimg + pb + i01, g * k.ne);
+                if (k.oky1) atomicAdd(gimg + pb + i10, g * k.sw);
+                if (k.okx1 && k.oky1) atomicAdd(gimg + pb + i11, g * k.se);
+            }
+            if (gflow) {
+                const float* __restrict__ pl = img + pb;
+                const float vnw = pl[i00];
+                const float vne = k.okx1 ? pl[i01] : 0.0f;
+                const float vsw = k.oky1 ? pl[i10] : 0.0f;
+                const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
+                gix += g * (k.s_ * (vne - vnw) + k.n_ * (vse - vsw));
+                giy += g * (k.e_ * (vsw - vnw) + k.w_ * (vse - vne));
+            }
+        }
+        if (gflow) {
+            float* gx = gflow + ((long)n * 2 + 0) * HW + sp;
+            float* gy = gflow + ((long)n * 2 + 1) * HW + sp;
+            if (gridDim.y == 1) { *gx = gix * k.gmx; *gy = giy * k.gmy; }
+            else { atomicAdd(gx, gix * k.gmx); atomicAdd(gy, giy * k.gmy); }
+        }
+    }
+}
+
+static void warp_grid(int N, int C, int H, int W, dim3& grid, int& cchunk) {
+    const long pix = (long)N * H * W;
+    int gx = c2m_grid(pix, 256);
+    // enough threads to fill the chip: split channels while pixel-threads alone are fewer than ~256k
+    int chunks = 1;
+    while (chunks < C && (long)gx * 256 * chunks < 262144) chunks *= 2;
+    if (chunks > C) chunks = C;
+    cchunk = (C + chunks - 1) / chunks;
+    grid = dim3(gx, (C + cchunk - 1) / cchunk);
+}
+
+C2M_API int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H,
+                              int W, void* stream) {
+    if ((long)N * C * H * W <= 0) return 0;
+    dim3 grid; int cchunk;
+    warp_grid(N, C, H, W, grid, cchunk);
+    hipLaunchKernelGGL(flow_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, flow, occ, out, N, C, H, W,
+                       cchunk);
+    return (int)hipGetLastError();
+}
+
+// Returns 1 in *gflow_needs_zero when the caller must zero gflow before the launch (channel-chunked accumulation).
+C2M_API int c2m_flow_warp_bwd_needs_zero(int N, int C, int H, int W) {
+    dim3 grid; int cchunk;
+    warp_grid(N, C, H, W, grid, cchunk);
+    return grid.y > 1 ? 1 : 0;
+}
+
+C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
+                              float* gflow, int N, int C, int H, int W, void* stream) {
+    if ((long)N * C * H * W <= 0) return 0;
+    dim3 grid; int cchunk;
+    warp_grid(N, C, H, W, grid, cchunk);
+    hipLaunchKernelGGL(flow_warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, flow, occ, gout, gimg,
+                       gflow, N, C, H, W, cchunk);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- bilinear resize
+struct Lerp { int i0, i1; float l0, l1; };
+
+// ATen upsample_bilinear2d source index: align_corners ? o*scale : max((o+0.5)*scale-0.5, 0)
+__device__ __forceinline__ Lerp lerp_src(int o, int in, float scale, bool align) {
+    float src = align ? (float)o * scale : fmaxf(((float)o + 0.5f) * scale - 0.5f, 0.0f);
+    Lerp l;
+    l.i0 = (int)src;                       // src >= 0
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.l1 = src - (float)l.i0;
+    l.l0 = 1.0f - l.l1;
+    return l;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi,
+                                       int Ho, int Wo, float sh, float sw, int align, float mul) {
+    const long total = NC * Ho * Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo); const long r = i / Wo;
+        const int oy = (int)(r % Ho); const long nc = r / Ho;
+        const Lerp ly = lerp_src(oy, Hi, sh, align), lx = lerp_src(ox, Wi, sw, align);
+        const float* __restrict__ p = in + nc * (long)Hi * Wi;
+        const float v = ly.l0 * (lx.l0 * p[(long)ly.i0 * Wi + lx.i0] + lx.l1 * p[(long)ly.i0 * Wi + lx.i1]) +
+                        ly.l1 * (lx.l0 * p[(long)ly.i1 * Wi + lx.i0] + lx.l1 * p[(long)ly.i1 * Wi + lx.i1]);
+        out[i] = v * mul;
+    }
+}
+
+static float area_scale(int in, int out, int align, double scale_factor) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
+    if (scale_factor > 0.0) return (float)(1.0 / scale_factor);
+    return (float)in / (float)out;
+}
+
+C2M_API int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
+                                double scale_factor, void* stream) {
+    const long total = NC * Ho * Wo;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       NC, Hi, Wi, Ho, Wo, area_scale(Hi, Ho, align, scale_factor),
+                       area_scale(Wi, Wo, align, scale_factor), align, 1.0f);
+    return (int)hipGetLastError();
+}
+
+// adjoint of the x2 (align_corners=False, scale 0.5) upsample, gather form (deterministic, no atomics)
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long NC, int Hi, int Wi) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const long total = NC * Hi * Wi;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wi); const long r = i / Wi;
+        const int y = (int)(r % Hi); const long nc = r / Hi;
+        const float* __restrict__ g = gout + nc * (long)Ho * Wo;
+        float wy[4], wx[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int oy = 2 * y - 1 + d, ox = 2 * x - 1 + d;
+            wy[d] = 0.0f; wx[d] = 0.0f;
+            if (oy >= 0 && oy < Ho) { const Lerp l = lerp_src(oy, Hi, 0.5f, false); wy[d] = (l.i0 == y ? l.l0 : 0.0f) + (l.i1 == y ? l.l1 : 0.0f); }
+            if (ox >= 0 && ox < Wo) { const Lerp l = lerp_src(ox, Wi, 0.5f, false); wx[d] = (l.i0 == x ? l.l0 : 0.0f) + (l.i1 == x ? l.l1 : 0.0f); }
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = 2 * y - 1 + a;
+            if (wy[a] == 0.0f) continue;
+            float row = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = 2 * x - 1 + b;
+                if (wx[b] != 0.0f) row += wx[b] * g[(long)oy * Wo + ox];
+            }
+            acc += wy[a] * row;
+        }
+        gin[i] = acc;
+    }
+}
+
+C2M_API int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+    return c2m_resize_bilinear(in, out, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, stream);
+}
+
+C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+    const long total = NC * Hi * Wi;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gout, gin,
+                       NC, Hi, Wi);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------- maxpool 2x2 / 2
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi) {
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const long total = NC * Ho * Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo); const long r = i / Wo;
+        const int oy = (int)(r % Ho); const long nc = r / Ho;
+        const float* __restrict__ p = in + nc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+        out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Wi], p[Wi + 1]));
+    }
+}
+
+// gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                    float* __restrict__ gin, long NC, int Hi, int Wi) {
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const long total = NC * Hi * Wi;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wi); const long r = i / Wi;
+        const int y = (int)(r % Hi); const long nc = r / Hi;
+        const int oy = y / 2, ox = x / 2;
+        float g = 0.0f;
+        if (oy < Ho && ox < Wo) {
+            const float* __restrict__ p = in + nc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+            const float v[4] = {p[0], p[1], p[Wi], p[Wi + 1]};
+            int arg = 0; float m = v[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
+            if (arg == (y & 1) * 2 + (x & 1)) g = gout[nc * (long)Ho * Wo + (long)oy * Wo + ox];
+        }
+        gin[i] = g;
+    }
+}
+
+C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+    const long total = NC * (Hi / 2) * (Wi / 2);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, NC,
+                       Hi, Wi);
+    return (int)hipGetLastError();
+}
+
+C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+    const long total = NC * Hi * Wi;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, gout, gin,
+                       NC, Hi, Wi);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,165 @@
+"""Loss stack (reference: src/losses/losses.py:23-255) on fused HIP reductions.
+
+L1 (masked / plain), SSIM and every VGG-feature L1 are single-pass two-stage deterministic reductions
+(c2m_amd/csrc/losses.hip); the 5 "warped" resample calls and the 10 VGG passes of the reference are batched over
+frames (same values: every term is a mean over equally sized frames)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..modules.layers.vgg import Vgg19
+from ..modules.layers.common import fold_time
+from ..utils.utils import isnan
+
+_TAPS = ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1")
+
+
+class PerceptualLoss(nn.Module):
+    def __init__(self, train_params):
+        super().__init__()
+        self.train_params = train_params
+        style = train_params["loss_weights"].get("style", 0) > 0
+        # without the style term only relu{1..5}_1 are consumed: stop there
+        self.vgg19 = Vgg19(stop_after="relu5_4" if style else "relu5_1")
+        self.criterion = nn.L1Loss()
+
+    @staticmethod
+    def compute_gram(x):
+        b, ch, h, w = x.size()
+        f = x.view(b, ch, w * h)
+        return f.bmm(f.transpose(1, 2)) / (h * w * ch)
+
+    def forward(self, gt, fake):
+        T = self.train_params["num_predicted_frames"]
+        w = self.train_params["loss_weights"]
+        out = {}
+        if w.get("style", 0) > 0:
+            raise NotImplementedError("style loss (weight 0 in every shipped config) is not on the C2M-AMD path")
+        if w.get("perceptual", 0) > 0:
+            B = gt.shape[0]
+            # frame-major fold: rows [t*B:(t+1)*B] are frame t -> per-frame means are recovered from one VGG pass
+            with torch.no_grad():
+                x_feats = self.vgg19(fold_time(gt))
+            y_feats = self.vgg19(fold_time(fake))
+            content = 0.0
+            for k in _TAPS:
+                # sum_t mean_frame|x - y| = T * mean_all|x - y| because every frame contributes equally many elements
+                content = content + ops.l1_mean(y_feats[k], x_feats[k]) * T
+            out["perceptual"] = content / T
+        return out
+
+
+class KLLoss(nn.Module):
+    def forward(self, mu, logvar):
+        return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / mu.numel()
+
+
+class SSIMLoss(nn.Module):
+    @staticmethod
+    def ssim(x, y):
+        return ops.ssim_loss(x, y)
+
+    def forward(self, x, y):
+        return self.ssim(fold_time(x), fold_time(y))
+
+
+class L1MaskedLoss(nn.Module):
+    def forward(self, source, target, mask=None):
+        if source.dim() < 4:                       # small vectors (theta columns): plain device ops
+            if mask is not None:
+                mask = mask.expand_as(source)
+                return torch.nn.functional.l1_loss(source * mask, target * mask)
+            return torch.nn.functional.l1_loss(source, target)
+        if mask is not None and mask.shape[1] != 1:
+            raise NotImplementedError("mask must broadcast over the channel dim")
+        return ops.l1_mean(source, target, mask)
+
+
+class SmoothLoss(nn.Module):
+    """Edge-aware flow smoothness (losses.py:73-112); weight 0 in every shipped config -> plain device ops."""
+
+    @staticmethod
+    def _pair(flow, img):
+        def gx(t): return t[:, :, :-1, :] - t[:, :, 1:, :]
+        def gy(t): return t[:, :, :, :-1] - t[:, :, :, 1:]
+        wx = torch.exp(-torch.mean(torch.abs(gx(img)), 1, True))
+        wy = torch.exp(-torch.mean(torch.abs(gy(img)), 1, True))
+        return torch.mean(torch.abs(gx(flow) * wx)) + torch.mean(torch.abs(gy(flow) * wy))
+
+    def forward(self, flow, image):
+        f, i = fold_time(flow), fold_time(image)
+        return sum(self._pair(f[:, c:c + 1], i) for c in range(2)) / 2
+
+
+class FlowConsistLoss(nn.Module):
+    """Forward/backward flow consistency (losses.py:115-140); only active with use_fw_of."""
+
+    def __init__(self, train_params):
+        super().__init__()
+        self.train_params = train_params
+
+    @staticmethod
+    def _consist(flow, flowback, mask_fw=None, mask_bw=None):
+        nxt = torch.abs(ops.flow_warp(flowback, flow) + flow)
+        prv = torch.abs(ops.flow_warp(flow, flowback) + flowback)
+        if mask_fw is not None:
+            nxt, prv = mask_fw * nxt, mask_bw * prv
+        return prv.mean() + nxt.mean()
+
+    def forward(self, flow, flowback, mask_fw=None, mask_bw=None):
+        args = [fold_time(flow), fold_time(flowback)]
+        if mask_bw is not None:
+            args += [fold_time(mask_fw), fold_time(mask_bw)]
+        return self._consist(*args) * self.train_params["num_predicted_frames"]
+
+
+class TrainingLosses(nn.Module):
+    def __init__(self, train_params, model_params):
+        super().__init__()
+        self.train_params = train_params
+        self.model_params = model_params
+        if self.train_params["loss_weights"]["perceptual"] > 0:
+            self.perceptual_loss = PerceptualLoss(train_params)
+        self.flow_consist = FlowConsistLoss(self.train_params)
+        self.smooth_loss = SmoothLoss()
+        self.kl_loss = KLLoss()
+        self.ssim_loss = SSIMLoss()
+        self.l1_masked_loss = L1MaskedLoss()
+
+    def forward(self, data, frames, bw_optical_flows, fw_optical_flows, bw_occlusion_masks, fw_occlusion_masks,
+                generated, tracking_gnn):
+        tp = self.train_params
+        t_in, T = tp["num_input_frames"], tp["num_predicted_frames"]
+        source = frames[:, :, t_in - 1]
+        targets = frames[:, :, t_in:]
+        L = {}
+        L["flow_reconstruction"] = self.l1_masked_loss(generated["dense_motion_bw"], bw_optical_flows, bw_occlusion_masks)
+        if fw_optical_flows is not None:
+            L["flow_reconstruction"] = L["flow_reconstruction"] + self.l1_masked_loss(
+                generated["dense_motion_fw"], fw_optical_flows, fw_occlusion_masks)
+            L["flowcon"] = self.flow_consist(generated["dense_motion_fw"], generated["dense_motion_bw"],
+                                             generated["occlusion_fw"], generated["occlusion_bw"])
+        b, c, h, w = source.shape
+        src_rep = source.unsqueeze(0).expand(T, b, c, h, w).reshape(T * b, c, h, w)
+        warped = ops.flow_warp(src_rep, fold_time(generated["dense_motion_bw"]))      # 5 resample calls -> 1 launch
+        L["warped"] = ops.l1_mean(warped, fold_time(targets))
+        if tp["loss_weights"]["flow_smooth"] > 0:
+            L["flow_smooth"] = self.smooth_loss(generated["dense_motion_bw"], targets)
+            if fw_optical_flows is not None:
+                L["flow_smooth"] = L["flow_smooth"] + self.smooth_loss(
+                    generated["dense_motion_fw"], source.unsqueeze(2).repeat(1, 1, targets.shape[2], 1, 1))
+        L["kl"] = self.kl_loss(generated["mu"], generated["logvar"])
+        L["ssim"] = self.ssim_loss(generated["generated"], targets)
+        L["reconstruction"] = self.l1_masked_loss(generated["generated"], targets)
+        if tp["loss_weights"]["perceptual"] > 0:
+            L.update(self.perceptual_loss(targets, generated["generated"]))
+        L["occlusion_bw"] = self.l1_masked_loss(bw_occlusion_masks, generated["occlusion_bw"])
+        if fw_optical_flows is not None:
+            L["occlusion_fw"] = self.l1_masked_loss(fw_occlusion_masks, generated["occlusion_fw"])
+        # 30 scalar-vector L1s of the reference (losses.py:244-250) as three column reductions
+        pred = torch.stack([generated[f"theta_{t}"] for t in range(T)], 1)        # [N,T,6]
+        per_col = (pred - tracking_gnn.targets_theta).abs().mean(dim=0).sum(dim=0)  # sum_t mean_n |.| per column
+        L["translation"] = isnan(per_col[2] + per_col[5])
+        L["scale"] = isnan(per_col[0] + per_col[4])
+        L["rotation"] = isnan(per_col[1] + per_col[3])
+        return L

@@ -1,0 +1,53 @@
+"""Shared glue for the block mirrors: torch.nn modules are kept ONLY as parameter containers (identical
+state_dict keys / default initialisation to the reference); all arithmetic goes through c2m_amd.ops (HIP)."""
+import torch
+
+from ... import ops
+
+
+def pad_triple(padding):
+    """ReflectionPad3d-style padding (int or [w,w,h,h,t,t]) -> (pt, ph, pw); asymmetric pads are not used."""
+    if isinstance(padding, int):
+        return (padding, padding, padding)
+    p = list(padding)
+    if len(p) == 6:
+        if p[0] != p[1] or p[2] != p[3] or p[4] != p[5]:
+            raise NotImplementedError("asymmetric 3-D padding")
+        return (p[4], p[2], p[0])
+    if len(p) == 3:
+        return tuple(p)
+    raise ValueError(f"padding {padding}")
+
+
+def conv_module(x, conv, act=None, padding=None, padding_mode=None):
+    """Run an nn.Conv2d / nn.Conv3d container through the implicit-GEMM kernel."""
+    pad = conv.padding if padding is None else padding
+    mode = conv.padding_mode if padding_mode is None else padding_mode
+    return ops.conv(x, conv.weight, conv.bias, stride=tuple(conv.stride), padding=tuple(pad) if not isinstance(pad, int) else pad,
+                    padding_mode=mode, act=act)
+
+
+def batch_norm_module(x, bn, act=None):
+    """nn.BatchNorm{1,2,3}d container, train mode: batch statistics + running-stat update, fused activation."""
+    if bn.training:
+        bn.num_batches_tracked += 1
+        return ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, bn.eps, bn.momentum)
+    # eval: running statistics (inference path) -- scale/shift folded into the same apply kernel
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    return ops.norm_apply_eval(x, bn.running_mean, invstd, bn.weight, bn.bias, act)
+
+
+def instance_norm_module(x, inorm, act=None):
+    return ops.instance_norm_act(x, inorm.weight, inorm.bias, act, inorm.eps)
+
+
+def fold_time(x):
+    """[B,C,T,H,W] -> [T*B,C,H,W], frame-major (the reference's cat(unbind(x, 2), 0))."""
+    b, c, t, h, w = x.shape
+    return x.permute(2, 0, 1, 3, 4).reshape(t * b, c, h, w)
+
+
+def unfold_time(x, t):
+    """[T*B,C,H,W] -> [B,C,T,H,W] (the reference's cat(x.unsqueeze(2).chunk(t, 0), 2))."""
+    tb, c, h, w = x.shape
+    return x.reshape(t, tb // t, c, h, w).permute(1, 2, 0, 3, 4)

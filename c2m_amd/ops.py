@@ -1,0 +1,510 @@
+"""Host side of the HIP kernels: torch.autograd Functions over the C ABI (include/c2m_hip.h).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every op below launches hand-written
+gfx950 kernels from libc2m_hip.so on torch's current HIP stream.  There is no CPU or eager fallback: a tensor that is
+not on a HIP device raises (the oracle in oracle/ is test infrastructure and is never imported from here).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
+LRELU_SLOPE = 0.2
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("c2m_amd ops need tensors on a HIP device (no CPU fallback by design)")
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"c2m_amd ops compute in fp32, got {t.dtype}")
+
+
+def _f(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# =============================================================================================== convolution
+_geom_cache = {}
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def _triple(v, nd):
+    if isinstance(v, int):
+        return (1,) * (3 - nd) + (v,) * nd if nd < 3 else (v, v, v)
+    v = tuple(int(a) for a in v)
+    return (1,) * (3 - len(v)) + v if len(v) < 3 else v
+
+
+def _pad3(v, nd):
+    if isinstance(v, int):
+        return (0,) * (3 - nd) + (v,) * nd
+    v = tuple(int(a) for a in v)
+    return (0,) * (3 - len(v)) + v
+
+
+def _ktab(entries, rows, device):
+    tab = np.full((rows, 4), 0, dtype=np.int32)
+    tab[:, 0] = -1
+    n = len(entries)
+    if n:
+        tab[:n] = np.asarray(entries, dtype=np.int32)
+    return torch.from_numpy(tab).to(device)
+
+
+def _tap_entries(C, taps, chan_stride, offs):
+    """k = (c, a_t, a_y, a_x) row-major -> (c*chan_stride, off_t[a_t], off_y[a_y], off_x[a_x])."""
+    kt, kh, kw = taps
+    c = np.repeat(np.arange(C, dtype=np.int64), kt * kh * kw) * chan_stride
+    at = np.tile(np.repeat(np.arange(kt), kh * kw), C)
+    ay = np.tile(np.repeat(np.arange(kh), kw), C * kt)
+    ax = np.tile(np.arange(kw), C * kt * kh)
+    ot, oy, ox = (np.asarray(o, dtype=np.int64) for o in offs)
+    return np.stack([c, ot[at], oy[ay], ox[ax]], 1)
+
+
+class _ConvPlan:
+    """Everything shape-dependent for one conv layer geometry (cached): gather tables + geom arrays."""
+
+    def __init__(self, xs, ws, stride, pad, reflect, device):
+        nd = len(xs) - 2
+        self.is3d = 1 if nd == 3 else 0
+        N, Cin = xs[0], xs[1]
+        Ti, Hi, Wi = (xs[2], xs[3], xs[4]) if nd == 3 else (1, xs[2], xs[3])
+        Cout = ws[0]
+        kt, kh, kw = (ws[2], ws[3], ws[4]) if nd == 3 else (1, ws[2], ws[3])
+        st, sh, sw = stride
+        pt, ph, pw = pad
+        To, Ho, Wo = (Ti + 2 * pt - kt) // st + 1, (Hi + 2 * ph - kh) // sh + 1, (Wi + 2 * pw - kw) // sw + 1
+        if min(To, Ho, Wo) <= 0:
+            raise ValueError("empty convolution output")
+        if reflect and (pt >= Ti and pt > 0 or ph >= Hi and ph > 0 or pw >= Wi and pw > 0):
+            raise ValueError("reflect padding must be smaller than the input extent")
+        self.dims = (N, Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw)
+        self.stride, self.pad, self.reflect = stride, pad, reflect
+        self.out_shape = (N, Cout, To, Ho, Wo) if nd == 3 else (N, Cout, Ho, Wo)
+        K = Cin * kt * kh * kw
+        self.K, self.Kpad = K, _ceil(K, 16)
+        in_sc = Ti * Hi * Wi
+        ent = _tap_entries(Cin, (kt, kh, kw), in_sc, (np.arange(kt) - pt, np.arange(kh) - ph, np.arange(kw) - pw))
+        self.fwd_tab = _ktab(ent, self.Kpad, device)
+        osp = To * Ho * Wo
+        self.fwd_geom = np.array([Cout, self.Kpad, self.Kpad, N * osp, To, Ho, Wo, Ti, Hi, Wi, st, sh, sw,
+                                  Cin * in_sc, Hi * Wi, Wi, Cout * osp, osp, Ho * Wo, Wo, 1, 0, int(reflect),
+                                  self.is3d, 0], dtype=np.int64)
+        # ---- wgrad
+        self.has_ones = True
+        J = K + 1
+        bn = 128 if Cout <= 32 else 64
+        self.J, self.Jpad = J, _ceil(J, bn)
+        went = np.concatenate([ent, np.array([[-2, 0, 0, 0]])], 0)
+        self.wg_tab = _ktab(went, self.Jpad, device)
+        self.wg_geom = self.fwd_geom.copy()
+        self.wg_geom[0:3] = (Cout, J, self.Jpad)
+        self.wg_geom[16:18] = (Cout * osp, osp)
+        self.wg_geom[24] = K
+        self.wg_splits = _lib.lib().c2m_conv_wgrad_splits(Cout, J, N * osp)
+        # ---- dgrad: one launch per stride-parity class
+        Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)
+        self.dgrad_target = (N, Cin, Tp, Hp, Wp)
+        self.dgrad_needs_zero = False
+        self.classes = []
+
+        def dim_classes(I, O, k, s, p):
+            Ip = I + 2 * p if reflect else I
+            out = []
+            for r in range(s):
+                A = len(range(r, k, s))
+                if reflect:
+                    qmin, qmax, off = 0, (Ip - 1 - r) // s, r
+                else:
+                    qmin = max(0, -((r - p) // s))      # ceil((p - r)/s)
+                    qmax = (I - 1 + p - r) // s
+                    off = s * qmin + r - p
+                Q = qmax - qmin + 1
+                if Q <= 0:
+                    continue
+                if A == 0:
+                    self.dgrad_needs_zero = True
+                    continue
+                out.append((r, A, qmin, Q, off))
+            return out
+
+        for (rt, At, qt, Qt, offt) in dim_classes(Ti, To, kt, st, pt):
+            for (ry, Ay, qy, Qy, offy) in dim_classes(Hi, Ho, kh, sh, ph):
+                for (rx, Ax, qx, Qx, offx) in dim_classes(Wi, Wo, kw, sw, pw):
+                    Kc = Cout * At * Ay * Ax
+                    Kcp = _ceil(Kc, 16)
+                    e = _tap_entries(Cout, (At, Ay, Ax), osp, (qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax)))
+                    geom = np.array([Cin, Kcp, Kcp, N * Qt * Qy * Qx, Qt, Qy, Qx, To, Ho, Wo, 1, 1, 1,
+                                     Cout * osp, Ho * Wo, Wo, Cin * Tp * Hp * Wp, Tp * Hp * Wp, st * Hp * Wp, sh * Wp, sw,
+                                     offt * Hp * Wp + offy * Wp + offx, 0, self.is3d, 0], dtype=np.int64)
+                    self.classes.append(dict(r=(rt, ry, rx), Kc=Kc, Kcp=Kcp, tab=_ktab(e, Kcp, device), geom=geom))
+
+
+def _plan(x, w, stride, pad, reflect):
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index)
+    pl = _geom_cache.get(key)
+    if pl is None:
+        pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device)
+    return pl
+
+
+def _gp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _padded_rows(mat, Kpad):
+    """[M,K] -> contiguous [M,Kpad] (zero tail) when K is not already a multiple of 16."""
+    mat = _f(mat)
+    if mat.shape[1] == Kpad:
+        return mat
+    out = mat.new_zeros(mat.shape[0], Kpad)
+    out[:, :mat.shape[1]] = mat
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, reflect, act):
+        _dev(x, w, b)
+        x, w = _f(x), _f(w)
+        pl = _plan(x, w, stride, pad, reflect)
+        L = _lib.lib()
+        Cout = pl.dims[2]
+        A = _padded_rows(w.reshape(Cout, pl.K), pl.Kpad)
+        y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
+        _lib.check(L.c2m_conv_igemm(_p(A), _p(x), _p(y), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom), ACT[act],
+                                    LRELU_SLOPE, _stream()), "conv_igemm fwd")
+        ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
+        ctx.save_for_backward(x, w, y if ACT[act] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        pl, L = ctx.pl, _lib.lib()
+        gy = _f(gy)
+        if ACT[ctx.act]:
+            g = torch.empty_like(gy)
+            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], LRELU_SLOPE, _stream()), "act_bwd")
+            gy = g
+        N, Cin, Cout = pl.dims[0:3]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            tgt = (torch.zeros if pl.dgrad_needs_zero else torch.empty)(pl.dgrad_target, device=x.device,
+                                                                        dtype=torch.float32)
+            st, sh, sw = pl.stride
+            w5 = w if pl.is3d else w.unsqueeze(2)
+            for c in pl.classes:
+                rt, ry, rx = c["r"]
+                wc = w5[:, :, rt::st, ry::sh, rx::sw].permute(1, 0, 2, 3, 4).reshape(Cin, c["Kc"])
+                A = _padded_rows(wc, c["Kcp"])
+                _lib.check(L.c2m_conv_igemm(_p(A), _p(gy), _p(tgt), None, _p(c["tab"]), _gp(c["geom"]), 0, 0.0,
+                                            _stream()), "conv_igemm dgrad")
+            if pl.reflect and any(pl.pad):
+                gx = torch.empty_like(x)
+                Ti, Hi, Wi = pl.dims[3:6]
+                _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2],
+                                              _stream()), "reflect_fold")
+            else:
+                gx = tgt.view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            _lib.check(L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab), _gp(pl.wg_geom),
+                                        _stream()), "conv_wgrad")
+            gb = gb_t if ctx.has_bias else None
+        return gx, gw, gb, None, None, None, None
+
+
+def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None):
+    """conv2d (4-D x) / conv3d (5-D x) with zero or reflect padding folded into the gather; bias + activation fused."""
+    nd = x.dim() - 2
+    stride3, pad3 = _triple(stride, nd), _pad3(padding, nd)
+    reflect = padding_mode == "reflect" and any(pad3)
+    if padding_mode not in ("zeros", "reflect"):
+        raise NotImplementedError(f"padding_mode {padding_mode}")
+    return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act)
+
+
+# =============================================================================================== norm + act
+class _NormActFn(torch.autograd.Function):
+    """y = act(norm(x) * scale + shift); mode 0 instance / 1 batch statistics; gb = SPADE [N,2C,...] map or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum):
+        _dev(x, gamma, beta, gb)
+        x = _f(x)
+        gb = _f(gb) if gb is not None else None
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        L = _lib.lib()
+        nstat = N * C if mode == 0 else C
+        mean = torch.empty(nstat, device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
+        _lib.check(L.c2m_norm_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), N, C, S, mode,
+                                    eps, momentum, _stream()), "norm_stats")
+        y = torch.empty_like(x)
+        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(y), N, C, S, mode,
+                                    ACT[act], LRELU_SLOPE, _stream()), "norm_apply")
+        ctx.cfg = (N, C, S, mode, act)
+        ctx.save_for_backward(x, gamma, beta, gb, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, gb, mean, invstd = ctx.saved_tensors
+        N, C, S, mode, act = ctx.cfg
+        L = _lib.lib()
+        gy = _f(gy)
+        dx = torch.empty_like(x)
+        ggb = torch.empty_like(gb) if gb is not None else None
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        dbeta = torch.empty_like(beta) if gamma is not None else None
+        ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
+        _lib.check(L.c2m_norm_bwd(_p(x), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(ggb), _p(dgamma),
+                                  _p(dbeta), _p(dx), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _stream()), "norm_bwd")
+        return dx, dgamma, dbeta, ggb, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1):
+    return _NormActFn.apply(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum)
+
+
+def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5):
+    return _NormActFn.apply(x, gamma, beta, None, None, None, 0, act, eps, 0.1)
+
+
+def spade_norm_act(x, gamma_beta, act=None, eps=1e-5):
+    """InstanceNorm(affine=False)(x) * (1 + gamma) + beta with [gamma, beta] = gamma_beta.chunk(2, 1), then act."""
+    return _NormActFn.apply(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1)
+
+
+# =============================================================================================== warping / resampling
+class _FlowWarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, flow, occ):
+        _dev(img, flow, occ)
+        img, flow = _f(img), _f(flow)
+        occ = _f(occ) if occ is not None else None
+        N, C, H, W = img.shape
+        assert flow.shape == (N, 2, H, W), f"flow {tuple(flow.shape)} vs image {tuple(img.shape)}"
+        assert occ is None or occ.shape == (N, 1, H, W)
+        out = torch.empty_like(img)
+        _lib.check(_lib.lib().c2m_flow_warp_fwd(_p(img), _p(flow), _p(occ), _p(out), N, C, H, W, _stream()), "flow_warp")
+        ctx.save_for_backward(img, flow, occ)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, flow, occ = ctx.saved_tensors
+        N, C, H, W = img.shape
+        L = _lib.lib()
+        gimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        gflow = None
+        if ctx.needs_input_grad[1]:
+            gflow = (torch.zeros_like if L.c2m_flow_warp_bwd_needs_zero(N, C, H, W) else torch.empty_like)(flow)
+        if gimg is not None or gflow is not None:
+            _lib.check(L.c2m_flow_warp_bwd(_p(img), _p(flow), _p(occ), _p(_f(gout)), _p(gimg), _p(gflow), N, C, H, W,
+                                           _stream()), "flow_warp_bwd")
+        return gimg, gflow, None
+
+
+def flow_warp(img, flow, occ=None):
+    """utils.resample(img, flow) [* occ]: backward warp with pixel-unit flow (reference coordinate quirk included)."""
+    return _FlowWarpFn.apply(img, flow, occ)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _f(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _stream()), "upsample2x")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_upsample2x_bwd(_p(_f(gy)), _p(gx), N * C, H, W, _stream()), "upsample2x_bwd")
+        return gx
+
+
+def upsample2x(x):
+    return _Upsample2xFn.apply(x)
+
+
+def resize_bilinear(x, size, align_corners=False):
+    """F.interpolate(x, size, mode='bilinear') for no-grad tensors (sparse flow / occlusion pyramids)."""
+    _dev(x)
+    if x.requires_grad:
+        raise RuntimeError("resize_bilinear has no backward; use upsample2x for the differentiable x2 case")
+    x = _f(x)
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().c2m_resize_bilinear(_p(x), _p(y), N * C, H, W, Ho, Wo, 1 if align_corners else 0, 0.0,
+                                              _stream()), "resize_bilinear")
+    return y
+
+
+class _MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _f(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_maxpool2x2_fwd(_p(x), _p(y), N * C, H, W, _stream()), "maxpool")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().c2m_maxpool2x2_bwd(_p(x), _p(_f(gy)), _p(gx), N * C, H, W, _stream()), "maxpool_bwd")
+        return gx
+
+
+def maxpool2x2(x):
+    return _MaxPool2Fn.apply(x)
+
+
+# =============================================================================================== index / mask path
+def sparse_raster(instance, obj_id, obj_batch, thetas):
+    """instance [B,H,W] float ids, obj_id/obj_batch [K], thetas [K,T,6] -> (bw [B,2,T,H,W], fw, bin [B,1,T,H,W])."""
+    _dev(instance, thetas)
+    instance, thetas = _f(instance), _f(thetas.detach())
+    B, H, W = instance.shape
+    K, T = thetas.shape[0], thetas.shape[1]
+    oid = obj_id.to(device=instance.device, dtype=torch.int32).contiguous()
+    ob = obj_batch.to(device=instance.device, dtype=torch.int32).contiguous()
+    bw = torch.empty(B, 2, T, H, W, device=instance.device, dtype=torch.float32)
+    fw = torch.empty_like(bw)
+    binm = torch.empty(B, 1, T, H, W, device=instance.device, dtype=torch.float32)
+    _lib.check(_lib.lib().c2m_sparse_raster(_p(instance), _p(oid), _p(ob), _p(thetas), _p(bw), _p(fw), _p(binm), B, K, T,
+                                            H, W, _stream()), "sparse_raster")
+    return bw, fw, binm
+
+
+def occlusion_splat(flow, want_map=True, want_clip=False):
+    """get_occlusion_map for [B,2,H,W] or, frame-batched, [B,2,T,H,W] flows -> ([B,1,(T,)H,W] map, clip_mask) ."""
+    _dev(flow)
+    flow = _f(flow.detach())
+    five = flow.dim() == 5
+    if five:
+        B, _, T, H, W = flow.shape
+        sb, sc, st = 2 * T * H * W, T * H * W, H * W
+        oshape = (B, 1, T, H, W)
+    else:
+        B, _, H, W = flow.shape
+        T, sb, sc, st = 1, 2 * H * W, H * W, 0
+        oshape = (B, 1, H, W)
+    L = _lib.lib()
+    ws = torch.empty(L.c2m_occlusion_splat_workspace_bytes(B * T, H, W), device=flow.device, dtype=torch.uint8)
+    occ = torch.empty(oshape, device=flow.device, dtype=torch.float32) if want_map else None
+    clip = torch.empty(oshape, device=flow.device, dtype=torch.float32) if want_clip else None
+    _lib.check(L.c2m_occlusion_splat(_p(flow), sb, sc, st, B, T, H, W, _p(occ), _p(clip), _p(ws), _stream()),
+               "occlusion_splat")
+    return occ, clip
+
+
+# =============================================================================================== losses
+class _L1MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        _dev(a, b, mask)
+        a, b = _f(a), _f(b)
+        assert a.shape == b.shape
+        C, inner = 1, 1
+        if mask is not None:
+            mask = _f(mask)
+            assert mask.shape[0] == a.shape[0] and mask.shape[1] == 1 and mask.shape[2:] == a.shape[2:]
+            C, inner = a.shape[1], a[0, 0].numel()
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=a.device, dtype=torch.float64)
+        _lib.check(_lib.lib().c2m_l1_mean_fwd(_p(a), _p(b), _p(mask), _p(out), a.numel(), C, inner, _p(ws), _stream()),
+                   "l1_mean")
+        ctx.cfg = (C, inner)
+        ctx.save_for_backward(a, b, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, mask = ctx.saved_tensors
+        C, inner = ctx.cfg
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        g = _f(g.reshape(1).float())
+        _lib.check(_lib.lib().c2m_l1_mean_bwd(_p(a), _p(b), _p(mask), _p(g), _p(ga), _p(gb), a.numel(), C, inner,
+                                              _stream()), "l1_mean_bwd")
+        return ga, gb, None
+
+
+def l1_mean(a, b, mask=None):
+    """F.l1_loss(a*mask, b*mask) with mask [B,1,...] broadcast over channels (L1MaskedLoss), or plain L1 mean."""
+    return _L1MeanFn.apply(a, b, mask)
+
+
+class _SsimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        _dev(x, y)
+        x, y = _f(x), _f(y)
+        N, C, H, W = x.shape
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=x.device, dtype=torch.float64)
+        _lib.check(_lib.lib().c2m_ssim_fwd(_p(x), _p(y), _p(out), N * C, H, W, _p(ws), _stream()), "ssim")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        coef = torch.empty(N * C * (H - 2) * (W - 2) * 3, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_ssim_bwd(_p(x), _p(y), _p(_f(g.reshape(1).float())), _p(gx), _p(coef), N * C, H, W,
+                                           _stream()), "ssim_bwd")
+        return gx, None
+
+
+def ssim_loss(x, y):
+    """SSIMLoss.ssim on [N,C,H,W] (x = generated, differentiable; y = target)."""
+    return _SsimFn.apply(x, y)
+
+
+def norm_apply_eval(x, mean, invstd, gamma, beta, act=None):
+    """Inference-mode BatchNorm (+act): per-channel affine with given statistics. No autograd."""
+    _dev(x, mean, invstd, gamma, beta)
+    x = _f(x)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().c2m_norm_apply(_p(x), _p(_f(mean)), _p(_f(invstd)), _p(gamma), _p(beta), None, _p(y), N, C, S, 1,
+                                         ACT[act], LRELU_SLOPE, _stream()), "norm_apply(eval)")
+    return y

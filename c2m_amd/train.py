@@ -1,0 +1,69 @@
+"""Training-step harness: our counterpart of the reference's Trainer.update_model (src/trainer/trainer.py:138-168)
+and of the process setup in src/train.py:141-159.  Same loss weighting, same three backward calls in the same order
+(D_image, D_video, generator total -- the generator backward also deposits gradients in D parameters, reproduced),
+same four Adam steps; plus the real mean-of-ranks gradient all-reduce the reference lacks (c2m_amd/ddp.py)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .ddp import GradientReducer
+
+
+def init_distributed():
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); backend nccl == RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    return int(os.environ.get("RANK", "0")), local_rank, world
+
+
+class TrainStep:
+    def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0):
+        self.c2m = c2m
+        self.tp = c2m.train_params
+        self.loss_weights = loss_weights or self.tp["loss_weights"]
+        self.run_optimizers = run_optimizers
+        self.optimizers = [c2m.optimizer, c2m.optimizer_gnn]
+        if self.tp["use_image_discriminator"]:
+            self.optimizers.append(c2m.d_optimizer_image)
+        if self.tp["use_video_discriminator"]:
+            self.optimizers.append(c2m.d_optimizer_video)
+        distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
+        self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb) if distributed else None
+
+    def zero_grad(self):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            for o in self.optimizers:
+                o.zero_grad(set_to_none=True)
+
+    def __call__(self, data):
+        """One update; returns (generated dict, generator loss dict incl. total_gen, D loss dict)."""
+        self.zero_grad()
+        generated, loss_g, loss_d_img, loss_d_vid = self.c2m(data)
+        total = None
+        for k, v in loss_g.items():
+            term = v * self.loss_weights[k]
+            total = term if total is None else total + term
+        loss_g["total_gen"] = total
+        losses_d = {}
+        if self.tp["use_image_discriminator"]:
+            losses_d["total_image_dis"] = (loss_d_img.get("d_real", 0) + loss_d_img.get("d_fake", 0)) * 0.5
+            losses_d["total_image_dis"].backward()
+        if self.tp["use_video_discriminator"]:
+            losses_d["total_video_dis"] = (loss_d_vid.get("d_real", 0) + loss_d_vid.get("d_fake", 0)) * 0.5
+            losses_d["total_video_dis"].backward()
+        if self.reducer is not None:
+            self.reducer.arm()
+        total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.run_optimizers:
+            for o in self.optimizers:
+                o.step()
+        return generated, loss_g, losses_d

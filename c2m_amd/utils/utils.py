@@ -1,0 +1,73 @@
+"""resize_flow / resize_video / isnan / seeding helpers (reference: src/utils/utils.py:346-412)."""
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .. import ops as _ops
+
+
+def _fold(v):
+    b, c, t, h, w = v.shape
+    return v.permute(2, 0, 1, 3, 4).reshape(t * b, c, h, w)
+
+
+def _unfold(x, t):
+    tb, c, h, w = x.shape
+    return x.reshape(t, tb // t, c, h, w).permute(1, 2, 0, 3, 4)
+
+
+def resize_flow(flow, new_shape):
+    """bilinear(align_corners=True) resize of a pixel-unit flow, magnitudes rescaled (utils.py:346-354)."""
+    _, _, h, w = flow.shape
+    new_h, new_w = int(new_shape[0]), int(new_shape[1])
+    out = _ops.resize_bilinear(flow.detach(), (new_h, new_w), align_corners=True)
+    out[:, 0] /= w / float(new_w)
+    out[:, 1] /= h / float(new_h)
+    return out
+
+
+def resize_video(video, scale_factor, mode="nearest", is_flow=False):
+    """utils.py:357-372.  At scale_factor 1 (the only value the configs use) every mode is the identity, so the
+    reference's fold -> interpolate -> unfold round trip is skipped; other sizes go through the bilinear kernel."""
+    if video is None:
+        return None
+    if not isinstance(scale_factor, (list, tuple)) and scale_factor == 1:
+        return video
+    t = video.shape[2]
+    flat = _fold(video)
+    if is_flow:
+        h, w = video.shape[-2:]
+        return _unfold(resize_flow(flat, [int(h * scale_factor), int(w * scale_factor)]), t)
+    size = list(scale_factor) if isinstance(scale_factor, (list, tuple)) else \
+        [int(video.shape[-2] * scale_factor), int(video.shape[-1] * scale_factor)]
+    if mode == "bilinear" and not flat.requires_grad:
+        return _unfold(_ops.resize_bilinear(flat, size, align_corners=False), t)
+    return _unfold(F.interpolate(flat, size=size, mode=mode), t)
+
+
+def isnan(x, input_tensor=None):
+    """Raises ValueError on NaN like the reference (utils.py:375-379) -- one host sync per call."""
+    if torch.any(torch.isnan(x)):
+        raise ValueError(f"Value is nan {x}, input tensor is {input_tensor}")
+    return x
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_master():
+    return get_rank() == 0
+
+
+def set_random_seed(seed, by_rank=False):
+    if by_rank:
+        seed += get_rank()
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)

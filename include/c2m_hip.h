@@ -1,0 +1,106 @@
+/* c2m_hip.h -- C ABI of libc2m_hip.so, the MI355X (gfx950) kernel library behind c2m_amd.
+ *
+ * The reference (PierfrancescoArdino/C2M) has no FFI on this path: its hot path is stock ATen operators called from
+ * Python.  Each entry point below therefore names the reference *call site* (file:line under
+ * /root/reference/src) whose ATen op chain it replaces; the Python-side binding is the ctypes stub in
+ * c2m_amd/_lib.py (shown in INTEGRATION.md).
+ *
+ * Conventions (every function):
+ *   - plain pointers to DEVICE memory, fp32 unless noted, contiguous NCHW / NCTHW; sizes as int / long
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and never synchronise or allocate;
+ *     scratch is caller-provided (`workspace`), sized by the matching *_workspace_* query
+ *   - return value: hipError_t as int (0 = success); shape errors return hipErrorInvalidValue
+ *   - thread-safe and re-entrant (no global mutable state); callable from the autograd thread
+ */
+#ifndef C2M_HIP_H
+#define C2M_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 3 };
+
+/* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 (conv_igemm.hip) -------------------------------------
+ * Replaces nn.Conv2d / nn.Conv3d (+ ReflectionPad2d/3d, bias, LeakyReLU/ReLU/Sigmoid) at:
+ *   modules/layers/down_block.py:14-23,35-47   same_block.py:14-23,36-46,55-67   up_block.py:9-13
+ *   residual_block.py:13-31,42-71   spade_block.py:47-49   vgg.py:92-137   generator/generator.py:76-78
+ *   and their autograd backward (aten::convolution_backward).
+ *
+ * D[m][pix] = act( sum_k A[m][k] * G(k,pix) + bias[m] ),  G = input gathered through `ktab`.
+ * geom[] (int64, 25 entries):
+ *   0 M   1 K (multiple of 16)   2 lda   3 Npix = N*To*Ho*Wo   4 To 5 Ho 6 Wo   7 Ti 8 Hi 9 Wi
+ *   10 st 11 sh 12 sw (input coord = o*stride + tap offset from ktab)
+ *   13 in_sn 14 in_st 15 in_sh (input strides in elements; w stride 1; channel offset is in ktab)
+ *   16 out_sn 17 out_sc 18 out_st 19 out_sh 20 out_sw 21 out_off   22 reflect (0 zeros / 1 reflect) 23 is3d
+ *   24 (wgrad only) Jw
+ * ktab: K x int4 {channel_offset, t_off, y_off, x_off}; channel_offset -1 = zero row, -2 = ones row.        */
+int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
+                   const int64_t* geom, int act, float slope, void* stream);
+
+/* dW[m][j] = sum_pix dY[m][pix] * G(j,pix) with deterministic split-K slabs; a trailing ones-row yields db.
+ * geom as above with 0 M, 1 J, 2 Jpad (jtab length), 16 dy_sn, 17 dy_sc, 24 Jw (= J or J-1).
+ * slab: c2m_conv_wgrad_splits(M, J, Npix) * M * J floats.                                                     */
+int c2m_conv_wgrad_splits(int M, int J, int Npix);
+int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
+                   const int64_t* geom, void* stream);
+
+/* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward). */
+int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
+                     void* stream);
+
+/* ---- normalisation + activation (norm.hip) -----------------------------------------------------------------
+ * BatchNorm2d/3d(train) / InstanceNorm2d / SPADE + LeakyReLU/ReLU:
+ *   down_block.py:19-22,44-47  same_block.py:19-22,41-44,64-67  up_block.py:11-12  residual_block.py:20-28,56-70
+ *   spade_block.py:68-77.   mode 0 = per (n,c) plane, 1 = per channel over N*S.                              */
+long c2m_norm_workspace_floats(int N, int C, long S);
+int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                   float* workspace, int N, int C, long S, int mode, float eps, float momentum, void* stream);
+int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const float* gb, float* y, int N, int C, long S, int mode, int act, float slope, void* stream);
+int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
+                 float* workspace, int N, int C, long S, int mode, int act, float slope, void* stream);
+int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream);
+
+/* ---- optical-flow warping / resampling (warp.hip) -----------------------------------------------------------
+ * utils/ops.py:183-202 resample()/get_grid()/grid_sample() and its backward; callers generator.py:86,
+ * motion_autoencoder.py:125 (fused "* occlusion"), losses.py:219, model.py:204,208.                          */
+int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H, int W,
+                      void* stream);
+int c2m_flow_warp_bwd_needs_zero(int N, int C, int H, int W);
+int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
+                      float* gflow, int N, int C, int H, int W, void* stream);
+/* F.interpolate(bilinear) (utils/utils.py:349 align_corners=True; motion_autoencoder.py:123, up_block.py:10).  */
+int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
+                        double scale_factor, void* stream);
+int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
+int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
+/* VGG-19 max pools (layers/vgg.py, torchvision features 4/9/18/27).                                           */
+int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
+int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
+
+/* ---- sparse-motion raster + occlusion splat (motion_raster.hip): bit-exact index/mask path ------------------
+ * motion_estimator/dense_motion.py:94-168 generate_sparse_motion/warp/clip_mask;
+ * utils/ops.py:205-275 get_occlusion_map/get_corresponding_map.                                              */
+int c2m_sparse_raster(const float* instance, const int* obj_id, const int* obj_batch, const float* thetas, float* bw,
+                      float* fw, float* bin, int B, int K, int T, int H, int W, void* stream);
+long c2m_occlusion_splat_workspace_bytes(long nimg, int H, int W);
+int c2m_occlusion_splat(const float* flow, long sb, long sc, long st, int B, int T, int H, int W, float* occ,
+                        float* clip, void* workspace, void* stream);
+
+/* ---- loss reductions (losses.hip) ---------------------------------------------------------------------------
+ * losses/losses.py:180-189 L1MaskedLoss (also :60-65 VGG L1, model.py:118-121 feature matching); :152-177 SSIM. */
+int c2m_l1_mean_fwd(const float* a, const float* b, const float* mask, float* out, long total, int C, long inner,
+                    void* workspace /* 8 KiB */, void* stream);
+int c2m_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gscale, float* ga, float* gb,
+                    long total, int C, long inner, void* stream);
+int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int W, void* workspace /* 8 KiB */,
+                 void* stream);
+int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

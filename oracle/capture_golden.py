@@ -243,6 +243,12 @@ def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed)
     model = GeneratorFullModel(train_params=ref_cfg["train_params"], model_params=ref_cfg["model_params"],
                                dataset="cityscapes")
     spec = state_spec(model.state_dict())
+    # constructor parity: fingerprints of the reference's own default initialisation under a fixed torch seed
+    torch.manual_seed(1234 + seed)
+    fresh = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
+                               model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
+    init_sums = {"sum.init." + k: summarize(v.float()) for k, v in fresh.state_dict().items()}
+    del fresh
     model.load_state_dict(synth_state(spec, seed))
     model.train()
     batch = make_batch(batch_size, 128, 256, t_in, seed=seed)
@@ -272,6 +278,7 @@ def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed)
         ((ldv["d_real"] + ldv["d_fake"]) * 0.5).backward()
     total.backward()
     arrays = {"rng.latent_traj": latent, "rng.eps": eps, "rng.click_index": torch.tensor(clicks)}
+    arrays.update(init_sums)
     for k, v in lg.items():
         arrays["loss." + k] = v.detach() if torch.is_tensor(v) else torch.tensor(float(v))
     for k, v in ldi.items():

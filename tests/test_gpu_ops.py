@@ -1,0 +1,322 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every HIP op, through the C ABI, against the oracle /
+golden vectors.  Index/mask paths bit-exact; fp32 elementwise rtol 1e-5; conv / norm reductions 1e-4 (stated per test)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from c2m_amd import ops
+from oracle import c2m_oracle as O
+from oracle import build as oracle_build
+from golden_io import Case, names
+from gpu_util import close, rel_close, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(t):
+    return t.to(DEV)
+
+
+# ----------------------------------------------------------------------------------------------- convolution
+CONV_CASES = [
+    # (x shape, Cout, kernel, stride, pad, mode)
+    ((2, 6, 12, 16), 8, (4, 4), 2, 1, "reflect"),
+    ((2, 3, 10, 12), 4, (7, 7), 1, 3, "reflect"),
+    ((1, 32, 9, 11), 3, (7, 7), 1, 3, "zeros"),
+    ((2, 5, 9, 11), 7, (3, 3), 1, 1, "reflect"),
+    ((2, 16, 16, 32), 32, (3, 3), 1, 1, "zeros"),
+    ((3, 48, 8, 16), 80, (3, 3), 1, 1, "reflect"),
+    ((2, 64, 8, 8), 130, (3, 3), 1, 1, "reflect"),
+    ((2, 8, 6, 8), 4, (1, 1), 1, 0, "zeros"),
+    ((2, 21, 16, 32), 64, (4, 4), 2, 1, "reflect"),
+    ((1, 32, 16, 32), 1, (3, 3), 1, 1, "reflect"),
+    ((5, 40, 4, 8), 40, (3, 3), 1, 1, "reflect"),
+    ((2, 5, 7, 9), 6, (3, 3), 2, 1, "zeros"),          # odd extents, stride 2 with k < 2*s classes
+    ((1, 5, 5, 12, 16), 6, (4, 4, 4), (2, 2, 2), (1, 1, 1), "reflect"),
+    ((2, 2, 5, 8, 12), 4, (3, 4, 4), (1, 2, 2), (1, 1, 1), "reflect"),
+    ((2, 4, 1, 4, 8), 6, (1, 4, 4), (1, 2, 2), (0, 1, 1), "reflect"),
+    ((2, 4, 1, 2, 4), 4, (1, 3, 3), (1, 1, 1), (0, 1, 1), "reflect"),
+    ((2, 6, 5, 6, 8), 4, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
+    ((1, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
+]
+
+
+def _ref_conv(x, w, b, stride, pad, mode, act):
+    nd = x.dim() - 2
+    pads = (pad,) * nd if isinstance(pad, int) else tuple(pad)
+    if mode == "reflect" and any(pads):
+        tup = []
+        for p in reversed(pads):
+            tup += [p, p]
+        x = F.pad(x, tuple(tup), mode="reflect")
+        pads = (0,) * nd
+    y = (F.conv2d if nd == 2 else F.conv3d)(x, w, b, stride=stride, padding=pads)
+    if act == "lrelu":
+        y = F.leaky_relu(y, 0.2)
+    elif act == "relu":
+        y = F.relu(y)
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_k{c[2]}_s{c[3]}_{c[5]}")
+@pytest.mark.parametrize("act", [None, "lrelu"])
+def test_conv_fwd_bwd(case, act):
+    xs, cout, k, stride, pad, mode = case
+    seed = abs(hash(str(case))) % 10000
+    x = rnd(seed, *xs)
+    w = rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * int(np.prod(k))) ** 0.5))
+    b = rnd(seed + 2, cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = _ref_conv(xr, wr, br, stride, pad, mode, act)
+    go = rnd(seed + 3, *yr.shape)
+    (yr * go).sum().backward()
+    xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode, act=act)
+    (y * g(go)).sum().backward()
+    torch.cuda.synchronize()
+    rel_close(y, yr, 2e-5, "conv fwd")                 # fp32 MFMA = fmaf chain; only the summation order differs
+    rel_close(xg.grad, xr.grad, 5e-5, "conv dgrad")
+    rel_close(wg.grad, wr.grad, 1e-4, "conv wgrad")
+    rel_close(bg.grad, br.grad, 1e-4, "conv bias grad")
+
+
+def test_conv_big_wgrad_splitk():
+    """Many pixels, few channels: exercises the split-K slabs + fixed-order reduction."""
+    x, w = rnd(1, 4, 8, 64, 128), rnd(2, 16, 8, 3, 3, scale=0.1)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    go = rnd(3, *yr.shape)
+    (yr * go).sum().backward()
+    xg, wg = g(x).requires_grad_(True), g(w).requires_grad_(True)
+    y = ops.conv(xg, wg, None, stride=1, padding=1, padding_mode="reflect")
+    (y * g(go)).sum().backward()
+    rel_close(y, yr, 2e-5)
+    rel_close(wg.grad, wr.grad, 2e-4, "split-K wgrad")
+    rel_close(xg.grad, xr.grad, 5e-5)
+    # determinism: same launch twice -> bit-identical weight gradient (no float atomics)
+    xg2, wg2 = g(x).requires_grad_(True), g(w).requires_grad_(True)
+    (ops.conv(xg2, wg2, None, stride=1, padding=1, padding_mode="reflect") * g(go)).sum().backward()
+    assert torch.equal(wg.grad, wg2.grad) and torch.equal(xg.grad, xg2.grad)
+
+
+# ----------------------------------------------------------------------------------------------- norm + act
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 4, 5, 6, 8), (4, 16, 2, 4), (2, 3, 100, 90), (6, 8)])
+@pytest.mark.parametrize("act", [None, "lrelu", "relu"])
+def test_batch_norm_act(shape, act):
+    x = rnd(1, *shape) * 2 + 3.0          # non-zero mean: the statistics must be cancellation-safe
+    C = shape[1]
+    gam, bet = 1 + 0.1 * rnd(2, C), 0.1 * rnd(3, C)
+    rm, rv = 0.1 * rnd(4, C), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(5))
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    yr = F.leaky_relu(yr, 0.2) if act == "lrelu" else (F.relu(yr) if act == "relu" else yr)
+    go = rnd(6, *shape)
+    (yr * go).sum().backward()
+    xg, gg, bg = (g(t).requires_grad_(True) for t in (x, gam, bet))
+    rmg, rvg = g(rm), g(rv)
+    y = ops.batch_norm_act(xg, gg, bg, rmg, rvg, act)
+    (y * g(go)).sum().backward()
+    close(y, yr, 1e-4, 1e-5, "bn fwd")
+    close(rmg, rmr, 1e-5, 1e-6, "running_mean")
+    close(rvg, rvr, 1e-4, 1e-6, "running_var")
+    close(xg.grad, xr.grad, 1e-3, 1e-5, "bn dx")
+    close(gg.grad, gr.grad, 1e-4, 1e-4, "bn dgamma")
+    close(bg.grad, br.grad, 1e-4, 1e-4, "bn dbeta")
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 9, 11), (3, 8, 2, 4), (1, 4, 130, 70)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_instance_norm_act(shape, affine):
+    x = rnd(1, *shape) + 1.5
+    C = shape[1]
+    gam, bet = (1 + 0.1 * rnd(2, C), 0.1 * rnd(3, C)) if affine else (None, None)
+    xr = x.clone().requires_grad_(True)
+    gr, br = (gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)) if affine else (None, None)
+    yr = F.leaky_relu(F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5), 0.2)
+    go = rnd(4, *shape)
+    (yr * go).sum().backward()
+    xg = g(x).requires_grad_(True)
+    gg, bg = (g(gam).requires_grad_(True), g(bet).requires_grad_(True)) if affine else (None, None)
+    y = ops.instance_norm_act(xg, gg, bg, "lrelu")
+    (y * g(go)).sum().backward()
+    close(y, yr, 1e-4, 1e-5, "in fwd")
+    close(xg.grad, xr.grad, 1e-3, 1e-5, "in dx")
+    if affine:
+        close(gg.grad, gr.grad, 1e-4, 1e-4)
+        close(bg.grad, br.grad, 1e-4, 1e-4)
+
+
+def test_spade_norm_act():
+    x, gb = rnd(1, 2, 5, 6, 8) + 0.5, 0.3 * rnd(2, 2, 10, 6, 8)
+    xr, gbr = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+    ga, be = gbr.chunk(2, 1)
+    yr = F.leaky_relu(F.instance_norm(xr, None, None, None, None, True, 0.1, 1e-5) * (1 + ga) + be, 0.2)
+    go = rnd(3, *yr.shape)
+    (yr * go).sum().backward()
+    xg, gbg = g(x).requires_grad_(True), g(gb).requires_grad_(True)
+    y = ops.spade_norm_act(xg, gbg, "lrelu")
+    (y * g(go)).sum().backward()
+    close(y, yr, 1e-4, 1e-5, "spade fwd")
+    close(xg.grad, xr.grad, 1e-3, 1e-5, "spade dx")
+    close(gbg.grad, gbr.grad, 1e-4, 1e-5, "spade d(gamma,beta)")
+
+
+# ----------------------------------------------------------------------------------------------- warping / resampling
+@pytest.mark.parametrize("name", names("op_resample"))
+def test_flow_warp_golden(name):
+    c = Case(name)
+    i = c.group("in")
+    img, flow = g(i["image"]).requires_grad_(True), g(i["flow"]).requires_grad_(True)
+    y = ops.flow_warp(img, flow)
+    assert torch.equal(y.detach().cpu(), c.group("out")["y"]), "flow_warp forward must be bit-exact vs the reference"
+    if "gout" in i:
+        (y * g(i["gout"])).sum().backward()
+        gin = c.group("gin")
+        close(img.grad, gin["image"], 1e-5, 1e-6, "d image (atomic order)")
+        close(flow.grad, gin["flow"], 1e-4, 1e-5, "d flow")
+
+
+@pytest.mark.parametrize("shape", [(40, 16, 4, 8), (5, 64, 32, 64), (2, 3, 128, 256), (3, 7, 9, 13)])
+@pytest.mark.parametrize("with_occ", [False, True])
+def test_flow_warp_vs_oracle(shape, with_occ):
+    N, C, H, W = shape
+    img, flow = rnd(1, *shape), rnd(2, N, 2, H, W, scale=2.5)
+    occ = (torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(3))) if with_occ else None
+    ir, fr = img.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    yr = O.resample(ir, fr)
+    if with_occ:
+        yr = yr * occ
+    go = rnd(4, *shape)
+    (yr * go).sum().backward()
+    ig, fg = g(img).requires_grad_(True), g(flow).requires_grad_(True)
+    y = ops.flow_warp(ig, fg, g(occ) if with_occ else None)
+    (y * g(go)).sum().backward()
+    assert torch.equal(y.detach().cpu(), yr.detach()), "forward bit-exact"
+    close(ig.grad, ir.grad, 1e-5, 1e-5, "d image")
+    close(fg.grad, fr.grad, 1e-4, 1e-4, "d flow")
+
+
+def test_flow_warp_full_size_c_oracle_bitexact():
+    """BASELINE-size image warp against the C restatement (oracle/c2m_oracle_index.c), bit for bit."""
+    lib = oracle_build.load()
+    N, C, H, W = 5, 3, 128, 256
+    img, flow = rnd(1, N, C, H, W).numpy(), rnd(2, N, 2, H, W, scale=3.0).numpy()
+    ref = np.zeros_like(img)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.oc_resample(p(img), p(flow), None, p(ref), N, C, H, W, oracle_build.FMA_MODE)
+    y = ops.flow_warp(g(torch.from_numpy(img)), g(torch.from_numpy(flow))).cpu().numpy()
+    assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (5, 8, 16, 32), (1, 2, 7, 5)])
+def test_upsample2x(shape):
+    x = rnd(1, *shape)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bilinear")
+    go = rnd(2, *yr.shape)
+    (yr * go).sum().backward()
+    xg = g(x).requires_grad_(True)
+    y = ops.upsample2x(xg)
+    (y * g(go)).sum().backward()
+    close(y, yr, 1e-6, 1e-6, "upsample fwd")
+    close(xg.grad, xr.grad, 1e-5, 1e-6, "upsample bwd")
+
+
+@pytest.mark.parametrize("name", names("op_resize_flow"))
+def test_resize_flow_golden(name):
+    from c2m_amd.utils import resize_flow
+    c = Case(name)
+    close(resize_flow(g(c.group("in")["flow"]), c.meta["size"]), c.group("out")["y"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("size", [(8, 16), (4, 8), (16, 32), (5, 9)])
+def test_resize_bilinear_align_false(size):
+    x = rnd(1, 3, 2, 32, 64)
+    close(ops.resize_bilinear(g(x), size), F.interpolate(x, size=size, mode="bilinear"), 1e-5, 1e-6)
+
+
+def test_maxpool():
+    x = rnd(1, 3, 5, 8, 12)
+    x[0, 0, 0, 0:2] = 1.0   # a tie: gradient must go to the first maximum
+    x[0, 0, 1, 0:2] = 1.0
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    go = rnd(2, *yr.shape)
+    (yr * go).sum().backward()
+    xg = g(x).requires_grad_(True)
+    y = ops.maxpool2x2(xg)
+    (y * g(go)).sum().backward()
+    assert torch.equal(y.detach().cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+# ----------------------------------------------------------------------------------------------- index / mask path
+@pytest.mark.parametrize("name", names("op_raster"))
+def test_sparse_raster_and_occlusion_golden_bitexact(name):
+    c = Case(name)
+    i = c.group("in")
+    th = i["targets_theta"] if c.meta["use_gt"] else i["targets_theta"] * 1.01
+    bw, fw, binm = ops.sparse_raster(g(i["instance"][:, 0]), i["ids"][:, -1], i["batch"], g(th))
+    o = c.group("out")
+    assert torch.equal(binm.cpu(), c.mask("sparse_motion_bin")), "sparse_motion_bin"
+    assert torch.equal(bw.cpu(), o["sparse_motion_bw"]), "sparse_motion_bw"
+    assert torch.equal(fw.cpu(), o["sparse_motion_fw"]), "sparse_motion_fw"
+    occ_bw = ops.occlusion_splat(fw, want_map=False, want_clip=True)[1]
+    occ_fw = ops.occlusion_splat(bw, want_map=False, want_clip=True)[1]
+    assert int((occ_bw.cpu() != c.mask("sparse_occ_bw")).sum()) == 0
+    assert int((occ_fw.cpu() != c.mask("sparse_occ_fw")).sum()) == 0
+
+
+@pytest.mark.parametrize("name", names("op_occlusion"))
+def test_occlusion_splat_golden_bitexact(name):
+    c = Case(name)
+    occ, clip = ops.occlusion_splat(g(c.group("in")["flow"]), want_map=True, want_clip=True)
+    o = c.group("out")
+    assert torch.equal(occ.cpu(), o["y"]), f"{int((occ.cpu() != o['y']).sum())} pixels differ (exact summation order)"
+    assert torch.equal(clip.cpu(), o["clip"])
+
+
+def test_occlusion_splat_full_size_vs_c_oracle_and_converging_flow():
+    lib = oracle_build.load()
+    B, H, W = 3, 128, 256
+    flow = rnd(7, B, 2, H, W, scale=2.0)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flow[2, 0] = (100.0 - xs) * 0.9     # strongly converging field: long per-target lists (slow path)
+    flow[2, 1] = (60.0 - ys) * 0.9
+    ref = np.zeros((B, 1, H, W), np.float32)
+    f = flow.numpy()
+    lib.oc_occlusion_splat(f.ctypes.data_as(ctypes.c_void_p), ref.ctypes.data_as(ctypes.c_void_p), B, H, W)
+    occ, _ = ops.occlusion_splat(g(flow))
+    assert np.array_equal(occ.cpu().numpy(), ref)
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def test_losses_golden():
+    c = Case("op_losses")
+    i, o, gin = c.group("in"), c.group("out"), c.group("gin")
+    a = g(i["a"]).requires_grad_(True)
+    b, m = g(i["b"]), g(i["mask"])
+    ssim = ops.ssim_loss(O.fold_time(a), O.fold_time(b))
+    l1 = ops.l1_mean(a, b)
+    l1m = ops.l1_mean(a, b, m)
+    (ssim * 1.5 + l1 * 0.7 + l1m * 2.0).backward()
+    close(ssim, o["ssim"], 1e-5, 1e-6, "ssim")
+    close(l1, o["l1"], 1e-5, 1e-6, "l1")
+    close(l1m, o["l1_masked"], 1e-5, 1e-6, "masked l1")
+    close(a.grad, gin["a"], 1e-3, 1e-7, "d a")
+
+
+def test_l1_mean_grad_to_second_argument():
+    a, b = rnd(1, 2, 1, 5, 8, 8), rnd(2, 2, 1, 5, 8, 8)
+    br = b.clone().requires_grad_(True)
+    F.l1_loss(a, br).backward()
+    bg = g(b).requires_grad_(True)
+    ops.l1_mean(g(a), bg).backward()
+    close(bg.grad, br.grad, 1e-6, 1e-9)
