@@ -40,6 +40,44 @@ def _f(t):
 _geom_cache = {}
 
 
+class ConvProfiler:
+    """Optional HIP-event timing of every implicit-GEMM launch (bench.py roofline): events are recorded on the stream
+    the kernels are launched on (torch's current stream).  Off by default; zero overhead when off."""
+    active = None
+
+    def __init__(self):
+        self.records = []          # (kind, flops, start_event, end_event)
+
+    def __enter__(self):
+        ConvProfiler.active = self
+        return self
+
+    def __exit__(self, *exc):
+        ConvProfiler.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, e0, e1 in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+def _timed(kind, flops, fn):
+    prof = ConvProfiler.active
+    if prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    prof.records.append((kind, flops, e0, e1))
+    return rc
+
+
 def _ceil(a, b):
     return (a + b - 1) // b * b
 
@@ -189,8 +227,9 @@ class _ConvFn(torch.autograd.Function):
         Cout = pl.dims[2]
         A = _padded_rows(w.reshape(Cout, pl.K), pl.Kpad)
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
-        _lib.check(L.c2m_conv_igemm(_p(A), _p(x), _p(y), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom), ACT[act],
-                                    LRELU_SLOPE, _stream()), "conv_igemm fwd")
+        _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(y), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
+                                                   ACT[act], LRELU_SLOPE, _stream())), "conv_igemm fwd")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
         return y
@@ -215,8 +254,9 @@ class _ConvFn(torch.autograd.Function):
                 rt, ry, rx = c["r"]
                 wc = w5[:, :, rt::st, ry::sh, rx::sw].permute(1, 0, 2, 3, 4).reshape(Cin, c["Kc"])
                 A = _padded_rows(wc, c["Kcp"])
-                _lib.check(L.c2m_conv_igemm(_p(A), _p(gy), _p(tgt), None, _p(c["tab"]), _gp(c["geom"]), 0, 0.0,
-                                            _stream()), "conv_igemm dgrad")
+                _lib.check(_timed("igemm", 2.0 * Cin * c["Kc"] * int(c["geom"][3]),
+                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(tgt), None, _p(c["tab"]), _gp(c["geom"]), 0,
+                                                           0.0, _stream())), "conv_igemm dgrad")
             if pl.reflect and any(pl.pad):
                 gx = torch.empty_like(x)
                 Ti, Hi, Wi = pl.dims[3:6]
@@ -228,8 +268,9 @@ class _ConvFn(torch.autograd.Function):
             slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
-            _lib.check(L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab), _gp(pl.wg_geom),
-                                        _stream()), "conv_wgrad")
+            _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+                              lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
+                                                       _gp(pl.wg_geom), _stream())), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
         return gx, gw, gb, None, None, None, None
 
