@@ -12,6 +12,10 @@
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+// hipGetLastError() is sticky across unrelated runtime calls of the process (e.g. a probe that returned
+// hipErrorNoDevice during framework start-up): clear it on entry so that our launch check reports OUR launch only.
+#define C2M_ENTER() (void)hipGetLastError()
+
 static inline int c2m_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // memory-bound kernels: cap the grid and grid-stride (cdna guide, Guideline 11)

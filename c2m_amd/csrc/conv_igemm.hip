@@ -210,6 +210,7 @@ static int launch_igemm(const ConvP& p, int reflect, int is3d, hipStream_t s) {
 // geom[] layout (int64): see include/c2m_hip.h  (C2M_CG_*)
 C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
                            const int64_t* g, int act, float slope, void* stream) {
+    C2M_ENTER();
     ConvP p;
     p.A = A; p.X = X; p.Y = Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
     p.M = (int)g[0]; p.K = (int)g[1]; p.lda = (int)g[2];
@@ -374,6 +375,7 @@ C2M_API int c2m_conv_wgrad_splits(int M, int J, int Npix) {
 
 C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
                            const int64_t* g, void* stream) {
+    C2M_ENTER();
     WgradP p;
     p.dY = dY; p.X = X; p.slab = slab; p.jtab = reinterpret_cast<const int4*>(jtab);
     p.M = (int)g[0]; p.J = (int)g[1]; p.Jpad = (int)g[2];
@@ -437,6 +439,7 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __rest
 
 C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
                              void* stream) {
+    C2M_ENTER();
     FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
     if (f.total <= 0) return 0;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream, dXpad, dX,

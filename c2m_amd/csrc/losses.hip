@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
 // workspace: RED_BLOCKS doubles
 C2M_API int c2m_l1_mean_fwd(const float* a, const float* b, const float* mask, float* out, long total, int C, long inner,
                             void* workspace, void* stream) {
+    C2M_ENTER();
     if (total <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     int blocks = c2m_grid(total, 256); if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
@@ -70,6 +71,7 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
 
 C2M_API int c2m_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gscale, float* ga, float* gb,
                             long total, int C, long inner, void* stream) {
+    C2M_ENTER();
     if (total <= 0) return 0;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, mask, gscale,
                        ga, gb, total, C, inner);
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
 
 C2M_API int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int W, void* workspace,
                          void* stream) {
+    C2M_ENTER();
     const long total = NC * (long)(H - 2) * (W - 2);
     if (total <= 0 || H < 3 || W < 3) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
@@ -179,6 +182,7 @@ __global__ void ssim_gather_kernel(const float* __restrict__ x, const float* __r
 // coef workspace: NC*(H-2)*(W-2)*3 floats
 C2M_API int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H,
                          int W, void* stream) {
+    C2M_ENTER();
     const long nwin = NC * (long)(H - 2) * (W - 2);
     if (nwin <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;

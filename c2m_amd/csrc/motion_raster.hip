@@ -80,6 +80,7 @@ __global__ void sparse_raster_kernel(const float* __restrict__ instance, const i
 
 C2M_API int c2m_sparse_raster(const float* instance, const int* obj_id, const int* obj_batch, const float* thetas,
                               float* bw, float* fw, float* bin, int B, int K, int T, int H, int W, void* stream) {
+    C2M_ENTER();
     const long total = (long)B * T * H * W;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(sparse_raster_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, instance,
@@ -223,6 +224,7 @@ C2M_API long c2m_occlusion_splat_workspace_bytes(long nimg, int H, int W) {
 
 C2M_API int c2m_occlusion_splat(const float* flow, long sb, long sc, long st, int B, int T, int H, int W, float* occ,
                                 float* clip, void* workspace, void* stream) {
+    C2M_ENTER();
     const long nimg = (long)B * T, HW = (long)H * W;
     if (nimg * HW <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -81,6 +81,7 @@ C2M_API long c2m_norm_workspace_floats(int N, int C, long S) { return (long)N * 
 
 C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
                            float* workspace, int N, int C, long S, int mode, float eps, float momentum, void* stream) {
+    C2M_ENTER();
     if ((long)N * C * S <= 0) return 0;
     NormShape sh{N, C, S, mode, norm_chunks(S)};
     hipStream_t s = (hipStream_t)stream;
@@ -126,6 +127,7 @@ __global__ void norm_apply_kernel(const ApplyP p) {
 C2M_API int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, const float* gb, float* y, int N, int C, long S, int mode, int act,
                            float slope, void* stream) {
+    C2M_ENTER();
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
     ApplyP p{x, mean, invstd, gamma, beta, gb, y, N, C, S, mode, act, slope};
@@ -257,6 +259,7 @@ __global__ void norm_bwd_apply_kernel(const BwdP p) {
 C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
                          float* workspace, int N, int C, long S, int mode, int act, float slope, void* stream) {
+    C2M_ENTER();
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -292,6 +295,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
 }
 
 C2M_API int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream) {
+    C2M_ENTER();
     if (total <= 0) return 0;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, gy, gx, total,
                        act, slope);

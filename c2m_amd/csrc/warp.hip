@@ -142,6 +142,7 @@ static void warp_grid(int N, int C, int H, int W, dim3& grid, int& cchunk) {
 
 C2M_API int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H,
                               int W, void* stream) {
+    C2M_ENTER();
     if ((long)N * C * H * W <= 0) return 0;
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
@@ -159,6 +160,7 @@ C2M_API int c2m_flow_warp_bwd_needs_zero(int N, int C, int H, int W) {
 
 C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
                               float* gflow, int N, int C, int H, int W, void* stream) {
+    C2M_ENTER();
     if ((long)N * C * H * W <= 0) return 0;
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
@@ -204,6 +206,7 @@ static float area_scale(int in, int out, int align, double scale_factor) {
 
 C2M_API int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
                                 double scale_factor, void* stream) {
+    C2M_ENTER();
     const long total = NC * Ho * Wo;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
@@ -246,10 +249,12 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __r
 }
 
 C2M_API int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+    C2M_ENTER();
     return c2m_resize_bilinear(in, out, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, stream);
 }
 
 C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+    C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gout, gin,
@@ -292,6 +297,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* _
 }
 
 C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+    C2M_ENTER();
     const long total = NC * (Hi / 2) * (Wi / 2);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, NC,
@@ -300,6 +306,7 @@ C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int
 }
 
 C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+    C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, gout, gin,
