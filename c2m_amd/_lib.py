@@ -54,6 +54,10 @@ def lib():
             raise RuntimeError(
                 f"c2m_amd: HIP kernel library not found at {LIB_PATH}. Build it with "
                 "`python -m c2m_amd.build` (needs hipcc); there is no CPU/PyTorch fallback for these ops.")
+        # torch bundles its own HIP runtime (same SONAME as the system one).  It must be in the process BEFORE our
+        # library is mapped so that both resolve to ONE runtime; the other order registers our kernels with a second
+        # runtime that never sees torch's device context (every launch then fails with hipErrorNoDevice).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
