@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
     args = ap.parse_args()
 
     rank, local_rank, world = init_distributed()
@@ -150,6 +151,11 @@ def main():
                           "launches_per_step": wg["launches"] // args.steps,
                           "share_of_step_time": round(wg["ms"] / (1000.0 * elapsed), 3)},
             }
+        if prof is not None and args.conv_table:
+            with open(args.conv_table, "w") as f:
+                f.write("kind pass M K Npix taps stride reflect | launches/step ms/step TFLOP/s\n")
+                for tag, n, ms, tf in prof.table():
+                    f.write(f"{tag} | {n / args.steps:.1f} {ms / args.steps:.3f} {tf:.1f}\n")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)

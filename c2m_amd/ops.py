@@ -46,7 +46,7 @@ class ConvProfiler:
     active = None
 
     def __init__(self):
-        self.records = []          # (kind, flops, start_event, end_event)
+        self.records = []          # (kind, flops, start_event, end_event, tag)
 
     def __enter__(self):
         ConvProfiler.active = self
@@ -58,15 +58,27 @@ class ConvProfiler:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1 in self.records:
+        for kind, flops, e0, e1, _ in self.records:
             d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += e0.elapsed_time(e1)
         return out
 
+    def table(self):
+        """Per launch-shape totals: [(tag, launches, ms, TFLOP/s)] sorted by time."""
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, e0, e1, tag in self.records:
+            d = agg.setdefault((kind,) + tuple(tag), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += flops
+        rows = [(k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r[2])
 
-def _timed(kind, flops, fn):
+
+def _timed(kind, flops, fn, tag=()):
     prof = ConvProfiler.active
     if prof is None:
         return fn()
@@ -74,7 +86,7 @@ def _timed(kind, flops, fn):
     e0.record()
     rc = fn()
     e1.record()
-    prof.records.append((kind, flops, e0, e1))
+    prof.records.append((kind, flops, e0, e1, tag))
     return rc
 
 
@@ -229,7 +241,8 @@ class _ConvFn(torch.autograd.Function):
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
         _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                           lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(y), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
-                                                   ACT[act], LRELU_SLOPE, _stream())), "conv_igemm fwd")
+                                                   ACT[act], LRELU_SLOPE, _stream()),
+                          ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect)), "conv_igemm fwd")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
         return y
@@ -256,7 +269,9 @@ class _ConvFn(torch.autograd.Function):
                 A = _padded_rows(wc, c["Kcp"])
                 _lib.check(_timed("igemm", 2.0 * Cin * c["Kc"] * int(c["geom"][3]),
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(tgt), None, _p(c["tab"]), _gp(c["geom"]), 0,
-                                                           0.0, _stream())), "conv_igemm dgrad")
+                                                           0.0, _stream()),
+                                  ("dgrad", Cin, c["Kc"], int(c["geom"][3]), pl.dims[9:12], pl.stride, pl.reflect)),
+                           "conv_igemm dgrad")
             if pl.reflect and any(pl.pad):
                 gx = torch.empty_like(x)
                 Ti, Hi, Wi = pl.dims[3:6]
@@ -270,7 +285,8 @@ class _ConvFn(torch.autograd.Function):
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
-                                                       _gp(pl.wg_geom), _stream())), "conv_wgrad")
+                                                       _gp(pl.wg_geom), _stream()),
+                              ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect)), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
         return gx, gw, gb, None, None, None, None
 
