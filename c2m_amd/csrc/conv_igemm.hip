@@ -5,19 +5,21 @@
 //   residual_block.py:13-31,42-71  spade_block.py:47-49  vgg.py (torchvision features)  generator.py:76-78
 //
 // One kernel serves forward and data-gradient:  D[m][pix] = sum_k A[m][k] * G(k, pix)
-//   * A  : row-major [M][lda] weights (native [Cout][Cin*taps] for forward, a packed transpose for dgrad)
-//   * G  : gathered input: k -> (channel, tap) through a small host-built table (KEntry), pix -> (n, ot, oy, ox);
-//          input coord = o*stride + tap_offset, zero or reflect boundary handled in the gather (no padded copy).
+//   * K is ordered (channel chunk, tap group, tap, channel-in-chunk): one K-step (16 deep) = NS taps x CK channels
+//     (NS*CK = 16).  The spatial part of the gather (o*stride + tap offset, zero / reflect boundary) is therefore
+//     computed once per tap per K-step and the CK channel loads only add a channel stride: ~2 VALU per element.
+//   * A  : row-major [M][K] weights packed by the host into that K order (zero rows for channel / tap padding).
 //   * D  : written with arbitrary output strides (NCHW / NCTHW, or the strided parity classes of a dgrad).
-// Orientation is chosen so that the MFMA column index (lane&31) is the pixel: every accumulator register is
-// stored as 2 x 128 contiguous bytes per wave -> coalesced NCHW stores; bias/activation fused in the epilogue.
+//   * split-K over gridDim.z for layers with few output pixels (deep encoder layers: 2x4 maps, K up to 16384):
+//     partial slabs + a fixed-order reduction that also applies bias / activation (no float atomics).
+// Orientation: the MFMA column index (lane&31) is the pixel, so every accumulator register is stored as 2 x 128
+// contiguous bytes per wave -> coalesced NCHW stores.
 //
-// wgrad:  dW[co][j] = sum_pix dY[co][pix] * G(j, pix)  with split-K over pixels into deterministic slabs
-// (no float atomics), an optional all-ones row giving the bias gradient, then a fixed-order slab reduction.
+// wgrad:  dW[co][j] = sum_pix dY[co][pix] * G(j, pix), rows j in (tap, channel) order so that 16 consecutive rows
+// share a tap; split-K over pixels into deterministic slabs, an all-ones row gives the bias gradient; the slab
+// reduction permutes back to the [Cout][Cin][taps] weight layout.
 //
 // Tiling: 256 threads = 4 waves, BK = 16, register-prefetched + double-buffered LDS, one barrier per K-step.
-// The f32 MFMA takes 64 cycles per 32x32x2 issue, so LDS traffic (4 ds_read_b32 per 4 MFMAs) and the gather
-// address arithmetic (mostly scalar: the k-row is wave-uniform) sit in its shadow.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,67 +27,64 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvP {
     const float* A;
     const float* X;
-    float* Y;
-    const float* bias;   // per-row (may be null)
-    const int4* ktab;    // [K] : {channel offset (<0: -1 zero row, -2 ones row), t, y, x tap offsets}
-    int M, K, lda;       // K is a multiple of 16 (table padded with zero rows)
+    float* Y;            // output, or the slab base when splits > 1
+    const float* bias;   // per-row (may be null); ignored when splits > 1
+    const int4* ktab;    // per K-step: header {chan_off, nvalid_chan, 0, 0} + NS x {dt, dy, dx, valid}
+    int M, nk, lda;      // nk K-steps of 16
     int Npix, To, Ho, Wo;
     int Ti, Hi, Wi;
     int st, sh, sw;
+    int in_sc;           // channel stride of the gathered tensor (elements)
     long in_sn, in_st, in_sh;
     long out_sn, out_sc, out_st, out_sh, out_sw, out_off;
+    long slab_stride;    // elements between split slabs
+    int ksteps_per_split;
+    int reflect, is3d;
     int act;
     float slope;
 };
 
-struct GatherDims { int Ti, Hi, Wi; long in_st, in_sh; };
-
-template <bool REFLECT, bool IS3D>
-__device__ __forceinline__ float gather_one(const float* __restrict__ Xn, const int4 e, int ots, int oys, int oxs,
-                                            const GatherDims& p) {
-    if (e.x < 0) return e.x == -2 ? 1.f : 0.f;  // wave-uniform branch (k-row is uniform)
-    int it = 0, iy = oys + e.z, ix = oxs + e.w;
-    if (IS3D) it = ots + e.y;
-    bool ok = true;
-    if (REFLECT) {
-        if (IS3D) { it = it < 0 ? -it : it; it = it >= p.Ti ? 2 * p.Ti - 2 - it : it; }
-        iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
-        ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+// spatial offset of one tap for this thread's pixel, or -1 when it falls in zero padding
+__device__ __forceinline__ int spatial_off(const int4 tp, int ots, int oys, int oxs, int Ti, int Hi, int Wi, int in_st,
+                                           int in_sh, int reflect, int is3d) {
+    int it = is3d ? ots + tp.x : 0, iy = oys + tp.y, ix = oxs + tp.z;
+    bool ok = tp.w != 0;
+    if (reflect) {
+        if (is3d) { it = it < 0 ? -it : it; it = it >= Ti ? 2 * Ti - 2 - it : it; }
+        iy = iy < 0 ? -iy : iy; iy = iy >= Hi ? 2 * Hi - 2 - iy : iy;
+        ix = ix < 0 ? -ix : ix; ix = ix >= Wi ? 2 * Wi - 2 - ix : ix;
     } else {
-        ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        if (IS3D) ok = ok && (unsigned)it < (unsigned)p.Ti;
+        ok = ok && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        if (is3d) ok = ok && (unsigned)it < (unsigned)Ti;
     }
-    float v = 0.f;
-    if (ok) {
-        long off = (long)e.x + (long)iy * p.in_sh + ix;
-        if (IS3D) off += (long)it * p.in_st;
-        v = Xn[off];
-    }
-    return v;
+    return ok ? it * in_st + iy * in_sh + ix : -1;
 }
 
-__device__ __forceinline__ void decompose_pix(int pix, const ConvP& p, int& n, int& ot, int& oy, int& ox) {
+template <class P>
+__device__ __forceinline__ void decompose_pix(int pix, const P& p, int& n, int& ot, int& oy, int& ox) {
     ox = pix % p.Wo; int r = pix / p.Wo;
     oy = r % p.Ho;   r = r / p.Ho;
     ot = r % p.To;   n = r / p.To;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool REFLECT, bool IS3D>
+template <int BM, int BN, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
-    constexpr int BK = 16;
+    constexpr int BK = 16, CK = BK / NS;
     constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
     constexpr int LDA_S = BM + 4, LDB_S = BN;
     constexpr int BROWS = 256 / BN;           // k rows gathered per pass
     constexpr int BPASS = BK / BROWS;         // gathers per thread per K-step
     constexpr int A_F4 = BM * BK / 4;         // float4 loads per K-step (whole block)
     constexpr int APASS = (A_F4 + 255) / 256;
-    static_assert(WGM * WGN == 4 && BN >= 64 && BROWS >= 1 && BK % BROWS == 0, "tile");
+    static_assert(WGM * WGN == 4 && BN >= 64 && CK % BROWS == 0, "tile");
     __shared__ float sA[2][BK][LDA_S];
     __shared__ float sB[2][BK][LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kt_beg = blockIdx.z * p.ksteps_per_split;
+    int kt_end = kt_beg + p.ksteps_per_split; kt_end = kt_end < p.nk ? kt_end : p.nk;
 
     // ---- gather side: this thread owns one pixel column of the tile
     const int bp = tid % BN;
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
     const float* __restrict__ Xn = p.X + (long)pn * p.in_sn;
     const int ots = pt * p.st, oys = py * p.sh, oxs = px * p.sw;
-    const GatherDims gd{p.Ti, p.Hi, p.Wi, p.in_st, p.in_sh};
+    const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
 
     // ---- weight side: float4 along k
     const int akq = (tid & 3) * 4;
@@ -113,21 +112,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     float4 ra[APASS];
     float rb[BPASS];
-    const int nk = p.K / BK;
 
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int kt) {
 #pragma unroll
         for (int s = 0; s < APASS; ++s) {
             int r = arow + s * 64;
             if (A_F4 >= 256 || r < BM) {
                 int row = m0 + r; row = row < p.M ? row : p.M - 1;
-                ra[s] = *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + k0 + akq);
+                ra[s] = *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + kt * BK + akq);
             }
         }
+        const int4* __restrict__ kd = p.ktab + (long)kt * (1 + NS);
+        const int4 hdr = kd[0];
+        int sp[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            sp[q] = spatial_off(kd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
 #pragma unroll
         for (int s = 0; s < BPASS; ++s) {
-            const int4 e = p.ktab[k0 + brow0 + s * BROWS];
-            rb[s] = gather_one<REFLECT, IS3D>(Xn, e, ots, oys, oxs, gd);
+            const int slot = (s * BROWS) / CK;                       // compile-time
+            const int cc = (s * BROWS) % CK + brow0;                  // wave-uniform
+            const int so = sp[slot];
+            float v = 0.f;
+            if (so >= 0 && cc < hdr.y) v = Xn[hdr.x + cc * p.in_sc + so];
+            rb[s] = v;
         }
     };
     auto store_tile = [&](int buf) {
@@ -143,13 +151,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         for (int s = 0; s < BPASS; ++s) sB[buf][brow0 + s * BROWS][bp] = rb[s];
     };
 
-    load_tile(0);
-    store_tile(0);
+    if (kt_beg < kt_end) {
+        load_tile(kt_beg);
+        store_tile(0);
+    }
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load_tile((kt + 1) * BK);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = kk * 2 + (lane >> 5);
@@ -170,13 +180,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 
     // ---- epilogue: acc[i][j][r] -> row m = ..(r&3)+8*(r>>2)+4*(lane>>5), col pix = ..(lane&31)
+    const bool direct = gridDim.z == 1;
+    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int pix = n0 + wn * TN + j * 32 + (lane & 31);
         if (pix >= p.Npix) continue;
         int n, ot, oy, ox;
         decompose_pix(pix, p, n, ot, oy, ox);
-        float* __restrict__ yb = p.Y + p.out_off + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
+        float* __restrict__ yb = Yb + p.out_off + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
                                  (long)ox * p.out_sw;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -185,8 +197,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < p.M) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[row];
-                    v = c2m_act(v, p.act, p.slope);
+                    if (direct) {
+                        if (p.bias) v += p.bias[row];
+                        v = c2m_act(v, p.act, p.slope);
+                    }
                     yb[(long)row * p.out_sc] = v;
                 }
             }
@@ -194,42 +208,85 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 }
 
+// out[i] = act( sum_z slab[z][i] + bias[(i / chan_stride) % M] ), fixed order
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                     const float* __restrict__ bias, long total, int S, long chan_stride, int M, int act,
+                                     float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int z = 0; z < S; ++z) acc += slab[(long)z * total + i];
+        if (bias) acc += bias[(int)((i / chan_stride) % M)];
+        out[i] = c2m_act(acc, act, slope);
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN>
-static int launch_igemm(const ConvP& p, int reflect, int is3d, hipStream_t s) {
-    dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM));
-    if (reflect) {
-        if (is3d) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (is3d) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), 0, s, p);
+static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s) {
+    dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits);
+    switch (ns) {
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 2>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 4>), grid, dim3(256), 0, s, p); break;
+        default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();
 }
 
-// geom[] layout (int64): see include/c2m_hip.h  (C2M_CG_*)
+static void igemm_tile(int M, int& BM, int& BN) {
+    if (M <= 32) { BM = 32; BN = 256; }
+    else if (M <= 64) { BM = 64; BN = 128; }
+    else { BM = 128; BN = 128; }
+}
+
+// Number of K splits the launch will use (the caller sizes the slab = splits * slab_stride floats when > 1).
+C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
+    int BM, BN;
+    igemm_tile(M, BM, BN);
+    const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(Npix, BN);
+    if (tiles >= 384 || nk < 8) return 1;
+    long S = (768 + tiles - 1) / tiles;
+    if (S > nk / 4) S = nk / 4;
+    if (S > 128) S = 128;
+    if (S < 2) return 1;
+    const int per = c2m_cdiv(nk, (int)S);
+    return c2m_cdiv(nk, per);                 // every split owns >= 1 K-step
+}
+
+// geom[] layout (int64): see include/c2m_hip.h
 C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
                            const int64_t* g, int act, float slope, void* stream) {
     C2M_ENTER();
     ConvP p;
     p.A = A; p.X = X; p.Y = Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
-    p.M = (int)g[0]; p.K = (int)g[1]; p.lda = (int)g[2];
+    p.M = (int)g[0]; p.nk = (int)g[1]; p.lda = (int)g[2];
     p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
     p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
     p.st = (int)g[10]; p.sh = (int)g[11]; p.sw = (int)g[12];
     p.in_sn = g[13]; p.in_st = g[14]; p.in_sh = g[15];
     p.out_sn = g[16]; p.out_sc = g[17]; p.out_st = g[18]; p.out_sh = g[19]; p.out_sw = g[20]; p.out_off = g[21];
-    const int reflect = (int)g[22], is3d = (int)g[23];
+    p.reflect = (int)g[22]; p.is3d = (int)g[23];
+    const int ns = (int)g[24];
+    p.in_sc = (int)g[25];
+    const int splits = (int)g[26];           // 1, or the value returned by c2m_conv_igemm_splits
+    p.slab_stride = g[27];
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.Npix <= 0) return 0;
-    if (p.K <= 0 || (p.K & 15) || (p.lda & 3) || (((uintptr_t)A) & 15)) return (int)hipErrorInvalidValue;
-    if (reflect && ((is3d && p.Ti < 2) || p.Hi < 2 || p.Wi < 2)) {
-        // reflect with an extent of 1 is only legal when no tap leaves the tensor; host guarantees that
-    }
+    if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
+    p.ksteps_per_split = c2m_cdiv(p.nk, splits);
+    if (c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // a split would be empty
     hipStream_t s = (hipStream_t)stream;
-    if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, reflect, is3d, s);
-    else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, reflect, is3d, s);
-    else                return launch_igemm<128, 128, 2, 2>(p, reflect, is3d, s);
+    if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s);
+    else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s);
+    else                return launch_igemm<128, 128, 2, 2>(p, ns, splits, s);
+}
+
+C2M_API int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits,
+                              long chan_stride, int M, int act, float slope, void* stream) {
+    C2M_ENTER();
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, out,
+                       bias, total, splits, chan_stride, M, act, slope);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -237,20 +294,26 @@ struct WgradP {
     const float* dY;     // [N][M][pix_per_image] contiguous
     const float* X;
     float* slab;         // [S][M][J]
-    const int4* jtab;    // [Jpad]
-    int M, J, Jpad;      // J = Cin*taps (+1 when the ones row is appended)
+    const int4* jtab;    // per 16-row group (= NS taps x CK channels, same format as the igemm K-step table):
+                         // {chan_off, nvalid_chan (-2: ones row, 0: zero rows), 0, 0} + NS x {dt,dy,dx,valid}
+    int M, J;            // J = padded (tap, channel) rows incl. the ones-row group
     int Npix, To, Ho, Wo, Ti, Hi, Wi, st, sh, sw;
+    int in_sc;
     long in_sn, in_st, in_sh;
     long dy_sn, dy_sc;   // dY strides (pix stride 1)
     int pix_per_split;   // multiple of 64
+    int reflect, is3d;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool REFLECT, bool IS3D>
+template <int BM, int BN, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
+    constexpr int CK = 16 / NS;
     constexpr int BK = 64;                 // pixels per K-step (one wave-width: coalesced along pix)
     constexpr int LDS_S = BK + 1;          // odd stride: conflict-free fragment reads
     constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
     constexpr int AROWS = BM / 4, BROWSW = BN / 4;   // rows per wave
+    constexpr int BGROUPS = BROWSW / 16;              // 16-row (one tap) groups per wave
+    static_assert(BROWSW % 16 == 0, "wgrad rows per wave must be whole tap groups");
     __shared__ float sA[BM][LDS_S];
     __shared__ float sB[BN][LDS_S];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -260,6 +323,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     const int split = blockIdx.z;
     const int pbeg = split * p.pix_per_split;
     int pend = pbeg + p.pix_per_split; pend = pend < p.Npix ? pend : p.Npix;
+    const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -270,35 +334,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[AROWS], rb[BROWSW];
-    const GatherDims g{p.Ti, p.Hi, p.Wi, p.in_st, p.in_sh};
-
     for (int pk = pbeg; pk < pend; pk += BK) {
         const int pix = pk + lane;
         const bool live = pix < pend;
-        int n = 0, ot = 0, oy = 0, ox = 0;
-        {
-            const int q = live ? pix : pend - 1;
-            ox = q % p.Wo; int r = q / p.Wo;
-            oy = r % p.Ho; r = r / p.Ho;
-            ot = r % p.To; n = r / p.To;
-        }
+        int n, ot, oy, ox;
+        decompose_pix(live ? pix : pend - 1, p, n, ot, oy, ox);
         const int sp = (ot * p.Ho + oy) * p.Wo + ox;
         const float* __restrict__ dyn = p.dY + (long)n * p.dy_sn + sp;
         const float* __restrict__ Xn = p.X + (long)n * p.in_sn;
         const int ots = ot * p.st, oys = oy * p.sh, oxs = ox * p.sw;
 #pragma unroll
         for (int s = 0; s < AROWS; ++s) {
-            int row = m0 + wave * AROWS + s;
+            const int row = m0 + wave * AROWS + s;
             float v = 0.f;
             if (live && row < p.M) v = dyn[(long)row * p.dy_sc];
             ra[s] = v;
         }
 #pragma unroll
-        for (int s = 0; s < BROWSW; ++s) {
-            const int j = j0 + wave * BROWSW + s;   // < Jpad by construction of the grid
-            const int4 e = p.jtab[j];
-            float v = gather_one<REFLECT, IS3D>(Xn, e, ots, oys, oxs, g);
-            rb[s] = live ? v : 0.f;
+        for (int gq = 0; gq < BGROUPS; ++gq) {
+            const int grp = (j0 + wave * BROWSW) / 16 + gq;     // < J/16 by construction of the grid
+            const int4* __restrict__ jd = p.jtab + (long)grp * (1 + NS);
+            const int4 hdr = jd[0];
+            int so[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                so[q] = spatial_off(jd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int slot = s / CK, cc = s % CK;                 // compile-time
+                float v = 0.f;
+                if (hdr.y == -2) v = (s == 0) ? 1.f : 0.f;           // ones row (bias gradient)
+                else if (so[slot] >= 0 && cc < hdr.y) v = Xn[hdr.x + cc * p.in_sc + so[slot]];
+                rb[gq * 16 + s] = live ? v : 0.f;
+            }
         }
         __syncthreads();   // previous K-step's fragment reads are done
 #pragma unroll
@@ -336,35 +404,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     }
 }
 
-// dW[m][j] (+ db[m] from the trailing ones column) = sum over splits, fixed order
+// dW[m][c*taps + tap] = sum_s slab[s][m][col(c, tap)] with the (chunk, tap group, slot, channel) row order;
+// db[m] = sum_s slab[s][m][ones_col]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, float* __restrict__ db,
-                                    int M, int J, int Jw, int S) {
-    const long total = (long)M * J;
+                                    int M, int J, int Cin, int taps, int NS, int ntg, int ngroups, int S) {
+    const int CK = 16 / NS;
+    const int per_m = Cin * taps + 1;
+    const long total = (long)M * per_m;
+    const long per = (long)M * J;
+    const int ones_col = ngroups * 16;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / per_m);
+        const int q = (int)(i % per_m);
+        int col;
+        if (q == Cin * taps) col = ones_col;
+        else {
+            const int c = q / taps, tap = q % taps;
+            col = ((c / CK) * ntg + tap / NS) * 16 + (tap % NS) * CK + c % CK;
+        }
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += slab[(long)s * total + i];
-        const int m = (int)(i / J), j = (int)(i % J);
-        if (j < Jw) dW[(long)m * Jw + j] = acc;
-        else if (db) db[m] = acc;
+        for (int s = 0; s < S; ++s) acc += slab[(long)s * per + (long)m * J + col];
+        if (q == Cin * taps) { if (db) db[m] = acc; }
+        else dW[(long)m * Cin * taps + q] = acc;
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-static int launch_wgrad(const WgradP& p, int S, int reflect, int is3d, hipStream_t s) {
-    dim3 grid(c2m_cdiv(p.J, BN), c2m_cdiv(p.M, BM), S);
-    if (reflect) {
-        if (is3d) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (is3d) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), 0, s, p);
-    }
-    return (int)hipGetLastError();
+static void wgrad_tile(int M, int& BM, int& BN) {
+    if (M <= 32) { BM = 32; BN = 128; } else { BM = 64; BN = 64; }
 }
 
 // Number of pixel splits the wgrad launch will use for (M, J, Npix): the caller sizes `slab` = S*M*J floats.
 C2M_API int c2m_conv_wgrad_splits(int M, int J, int Npix) {
-    const int BM = M <= 32 ? 32 : 64, BN = M <= 32 ? 128 : 64;
+    int BM, BN;
+    wgrad_tile(M, BM, BN);
     const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(J, BN);
     long S = (1024 + tiles - 1) / tiles;
     const long maxS = (Npix + 2047) / 2048;   // at least 2048 pixels per split
@@ -373,35 +445,52 @@ C2M_API int c2m_conv_wgrad_splits(int M, int J, int Npix) {
     return (int)S;
 }
 
+// Rows of the slab (a multiple of the tile width) for a conv with `ngroups` 16-row groups (incl. the ones group).
+C2M_API int c2m_conv_wgrad_rows(int M, int ngroups) {
+    int BM, BN;
+    wgrad_tile(M, BM, BN);
+    return c2m_cdiv(ngroups * 16, BN) * BN;
+}
+
 C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
                            const int64_t* g, void* stream) {
     C2M_ENTER();
     WgradP p;
     p.dY = dY; p.X = X; p.slab = slab; p.jtab = reinterpret_cast<const int4*>(jtab);
-    p.M = (int)g[0]; p.J = (int)g[1]; p.Jpad = (int)g[2];
+    p.M = (int)g[0]; p.J = (int)g[1];
     p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
     p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
     p.st = (int)g[10]; p.sh = (int)g[11]; p.sw = (int)g[12];
     p.in_sn = g[13]; p.in_st = g[14]; p.in_sh = g[15];
     p.dy_sn = g[16]; p.dy_sc = g[17];
-    const int reflect = (int)g[22], is3d = (int)g[23];
-    const int Jw = (int)g[24];   // columns that belong to dW (J - 1 when a ones row is present)
+    p.reflect = (int)g[22]; p.is3d = (int)g[23];
+    p.in_sc = (int)g[25];
+    const int NS = (int)g[24], Cin = (int)g[28], taps = (int)g[29], ntg = (int)g[30], ngroups = (int)g[31];
     if (p.M <= 0 || p.J <= 0 || p.Npix <= 0) return 0;
-    const int BN = p.M <= 32 ? 128 : 64;
-    if (p.Jpad < c2m_cdiv(p.J, BN) * BN) return (int)hipErrorInvalidValue;
+    int BM, BN;
+    wgrad_tile(p.M, BM, BN);
+    if (p.J % BN != 0 || p.J < (ngroups + 1) * 16 || (NS != 1 && NS != 2 && NS != 4)) return (int)hipErrorInvalidValue;
     const int S = c2m_conv_wgrad_splits(p.M, p.J, p.Npix);
     int per = c2m_cdiv(p.Npix, S);
     per = ((per + 63) / 64) * 64;
     p.pix_per_split = per;
     const int Seff = c2m_cdiv(p.Npix, per);   // <= S; unused slabs are never read
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (p.M <= 32) rc = launch_wgrad<32, 128, 1, 4>(p, Seff, reflect, is3d, s);
-    else           rc = launch_wgrad<64, 64, 2, 2>(p, Seff, reflect, is3d, s);
+    dim3 grid(p.J / BN, c2m_cdiv(p.M, BM), Seff);
+    if (p.M <= 32) {
+        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 1>), grid, dim3(256), 0, s, p);
+        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 2>), grid, dim3(256), 0, s, p);
+        else              hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 1>), grid, dim3(256), 0, s, p);
+        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        else              hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 4>), grid, dim3(256), 0, s, p);
+    }
+    int rc = (int)hipGetLastError();
     if (rc) return rc;
-    const long total = (long)p.M * p.J;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Jw,
-                       Seff);
+    const long total = (long)p.M * (Cin * taps + 1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
+                       taps, NS, ntg, ngroups, Seff);
     return (int)hipGetLastError();
 }
 

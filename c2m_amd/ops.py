@@ -94,6 +94,10 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
 def _triple(v, nd):
     if isinstance(v, int):
         return (1,) * (3 - nd) + (v,) * nd if nd < 3 else (v, v, v)
@@ -108,32 +112,71 @@ def _pad3(v, nd):
     return (0,) * (3 - len(v)) + v
 
 
-def _ktab(entries, rows, device):
-    tab = np.full((rows, 4), 0, dtype=np.int32)
-    tab[:, 0] = -1
-    n = len(entries)
-    if n:
-        tab[:n] = np.asarray(entries, dtype=np.int32)
-    return torch.from_numpy(tab).to(device)
+def _choose_ck(C, taps):
+    """Channels per tap inside one 16-deep K-step (CK x NS = 16): the padding-minimal choice, larger CK on ties."""
+    best = None
+    for ck in (16, 8, 4):
+        ns = 16 // ck
+        cost = _ceil(C, ck) * _ceil(taps, ns) * (1.0 + 0.03 * (ns - 1))
+        if best is None or cost < best[0] * 0.97:
+            best = (cost, ck)
+    return best[1]
 
 
-def _tap_entries(C, taps, chan_stride, offs):
-    """k = (c, a_t, a_y, a_x) row-major -> (c*chan_stride, off_t[a_t], off_y[a_y], off_x[a_x])."""
-    kt, kh, kw = taps
-    c = np.repeat(np.arange(C, dtype=np.int64), kt * kh * kw) * chan_stride
-    at = np.tile(np.repeat(np.arange(kt), kh * kw), C)
-    ay = np.tile(np.repeat(np.arange(kh), kw), C * kt)
-    ax = np.tile(np.arange(kw), C * kt * kh)
-    ot, oy, ox = (np.asarray(o, dtype=np.int64) for o in offs)
-    return np.stack([c, ot[at], oy[ay], ox[ax]], 1)
+def _tap_offsets(kt, kh, kw, off_t, off_y, off_x):
+    """(dt, dy, dx) per tap in (t, y, x) row-major order."""
+    return [(int(off_t[a]), int(off_y[b]), int(off_x[c])) for a in range(kt) for b in range(kh) for c in range(kw)]
+
+
+def _kstep_table(C, tap_offs, chan_stride, ck, extra_groups=0, ones_group=False):
+    """K-step / row-group table: [(groups), 1 + NS, 4] int32 in (channel chunk, tap group) order.
+    group = header {chan_off, nvalid, 0, 0} + NS x {dt, dy, dx, valid}; optional ones group (nvalid = -2) and zero pads."""
+    ns = 16 // ck
+    taps = len(tap_offs)
+    nch, ntg = _cdiv(C, ck), _cdiv(taps, ns)
+    n = nch * ntg
+    tab = np.zeros((n + (1 if ones_group else 0) + extra_groups, 1 + ns, 4), dtype=np.int32)
+    offs = np.zeros((ntg * ns, 4), dtype=np.int32)
+    offs[:taps, :3] = np.asarray(tap_offs, dtype=np.int32).reshape(taps, 3)
+    offs[:taps, 3] = 1
+    for ch in range(nch):
+        tab[ch * ntg:(ch + 1) * ntg, 0, 0] = ch * ck * chan_stride
+        tab[ch * ntg:(ch + 1) * ntg, 0, 1] = min(ck, C - ch * ck)
+        tab[ch * ntg:(ch + 1) * ntg, 1:, :] = offs.reshape(ntg, ns, 4)
+    if ones_group:
+        tab[n, 0, 1] = -2
+    return tab, nch, ntg
+
+
+def _pack_rows(wm, ck):
+    """[M, C, taps] -> contiguous [M, nk*16] in the kernel's K order (chunk, tap group, tap slot, channel)."""
+    M, C, taps = wm.shape
+    ns = 16 // ck
+    nch, ntg = _cdiv(C, ck), _cdiv(taps, ns)
+    if nch * ck != C or ntg * ns != taps:
+        buf = wm.new_zeros(M, nch * ck, ntg * ns)
+        buf[:, :C, :taps] = wm
+        wm = buf
+    return wm.reshape(M, nch, ck, ntg, ns).permute(0, 1, 3, 4, 2).reshape(M, nch * ntg * 16)
+
+
+def _geom(**kw):
+    g = np.zeros(32, dtype=np.int64)
+    idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
+               in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
+               in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31)
+    for k, v in kw.items():
+        g[idx[k]] = v
+    return g
 
 
 class _ConvPlan:
     """Everything shape-dependent for one conv layer geometry (cached): gather tables + geom arrays."""
 
     def __init__(self, xs, ws, stride, pad, reflect, device):
+        L = _lib.lib()
         nd = len(xs) - 2
-        self.is3d = 1 if nd == 3 else 0
+        self.is3d = is3d = 1 if nd == 3 else 0
         N, Cin = xs[0], xs[1]
         Ti, Hi, Wi = (xs[2], xs[3], xs[4]) if nd == 3 else (1, xs[2], xs[3])
         Cout = ws[0]
@@ -145,30 +188,35 @@ class _ConvPlan:
             raise ValueError("empty convolution output")
         if reflect and (pt >= Ti and pt > 0 or ph >= Hi and ph > 0 or pw >= Wi and pw > 0):
             raise ValueError("reflect padding must be smaller than the input extent")
+        if N * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo) >= 2 ** 31:
+            raise ValueError("tensor too large for 32-bit offsets")
         self.dims = (N, Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw)
         self.stride, self.pad, self.reflect = stride, pad, reflect
         self.out_shape = (N, Cout, To, Ho, Wo) if nd == 3 else (N, Cout, Ho, Wo)
-        K = Cin * kt * kh * kw
-        self.K, self.Kpad = K, _ceil(K, 16)
-        in_sc = Ti * Hi * Wi
-        ent = _tap_entries(Cin, (kt, kh, kw), in_sc, (np.arange(kt) - pt, np.arange(kh) - ph, np.arange(kw) - pw))
-        self.fwd_tab = _ktab(ent, self.Kpad, device)
-        osp = To * Ho * Wo
-        self.fwd_geom = np.array([Cout, self.Kpad, self.Kpad, N * osp, To, Ho, Wo, Ti, Hi, Wi, st, sh, sw,
-                                  Cin * in_sc, Hi * Wi, Wi, Cout * osp, osp, Ho * Wo, Wo, 1, 0, int(reflect),
-                                  self.is3d, 0], dtype=np.int64)
-        # ---- wgrad
-        self.has_ones = True
-        J = K + 1
-        bn = 128 if Cout <= 32 else 64
-        self.J, self.Jpad = J, _ceil(J, bn)
-        went = np.concatenate([ent, np.array([[-2, 0, 0, 0]])], 0)
-        self.wg_tab = _ktab(went, self.Jpad, device)
+        taps = kt * kh * kw
+        self.K = Cin * taps
+        in_sc, osp = Ti * Hi * Wi, To * Ho * Wo
+        # ---- forward
+        self.ck = ck = _choose_ck(Cin, taps)
+        ns = 16 // ck
+        offs = _tap_offsets(kt, kh, kw, np.arange(kt) - pt, np.arange(kh) - ph, np.arange(kw) - pw)
+        tab, nch, ntg = _kstep_table(Cin, offs, in_sc, ck)
+        nk = nch * ntg
+        self.nk = nk
+        self.fwd_tab = torch.from_numpy(tab.reshape(-1)).to(device)
+        self.fwd_splits = L.c2m_conv_igemm_splits(Cout, nk, N * osp)
+        self.fwd_geom = _geom(M=Cout, nk=nk, lda=nk * 16, Npix=N * osp, To=To, Ho=Ho, Wo=Wo, Ti=Ti, Hi=Hi, Wi=Wi, st=st,
+                              sh=sh, sw=sw, in_sn=Cin * in_sc, in_st=Hi * Wi, in_sh=Wi, out_sn=Cout * osp, out_sc=osp,
+                              out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
+                              in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp)
+        # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
+        self.J = L.c2m_conv_wgrad_rows(Cout, nk + 1)
+        wtab, _, _ = _kstep_table(Cin, offs, in_sc, ck, extra_groups=self.J // 16 - nk - 1, ones_group=True)
+        self.wg_tab = torch.from_numpy(wtab.reshape(-1)).to(device)
         self.wg_geom = self.fwd_geom.copy()
-        self.wg_geom[0:3] = (Cout, J, self.Jpad)
-        self.wg_geom[16:18] = (Cout * osp, osp)
-        self.wg_geom[24] = K
-        self.wg_splits = _lib.lib().c2m_conv_wgrad_splits(Cout, J, N * osp)
+        self.wg_geom[[0, 1, 16, 17]] = (Cout, self.J, Cout * osp, osp)
+        self.wg_geom[[28, 29, 30, 31]] = (Cin, taps, ntg, nk)
+        self.wg_splits = L.c2m_conv_wgrad_splits(Cout, self.J, N * osp)
         # ---- dgrad: one launch per stride-parity class
         Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)
         self.dgrad_target = (N, Cin, Tp, Hp, Wp)
@@ -195,16 +243,33 @@ class _ConvPlan:
                 out.append((r, A, qmin, Q, off))
             return out
 
+        tgt_numel = N * Cin * Tp * Hp * Wp
         for (rt, At, qt, Qt, offt) in dim_classes(Ti, To, kt, st, pt):
             for (ry, Ay, qy, Qy, offy) in dim_classes(Hi, Ho, kh, sh, ph):
                 for (rx, Ax, qx, Qx, offx) in dim_classes(Wi, Wo, kw, sw, pw):
-                    Kc = Cout * At * Ay * Ax
-                    Kcp = _ceil(Kc, 16)
-                    e = _tap_entries(Cout, (At, Ay, Ax), osp, (qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax)))
-                    geom = np.array([Cin, Kcp, Kcp, N * Qt * Qy * Qx, Qt, Qy, Qx, To, Ho, Wo, 1, 1, 1,
-                                     Cout * osp, Ho * Wo, Wo, Cin * Tp * Hp * Wp, Tp * Hp * Wp, st * Hp * Wp, sh * Wp, sw,
-                                     offt * Hp * Wp + offy * Wp + offx, 0, self.is3d, 0], dtype=np.int64)
-                    self.classes.append(dict(r=(rt, ry, rx), Kc=Kc, Kcp=Kcp, tab=_ktab(e, Kcp, device), geom=geom))
+                    ctaps = At * Ay * Ax
+                    cck = _choose_ck(Cout, ctaps)
+                    coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
+                    ctab, cnch, cntg = _kstep_table(Cout, coffs, osp, cck)
+                    cnk = cnch * cntg
+                    npix = N * Qt * Qy * Qx
+                    geom = _geom(M=Cin, nk=cnk, lda=cnk * 16, Npix=npix, To=Qt, Ho=Qy, Wo=Qx, Ti=To, Hi=Ho, Wi=Wo, st=1,
+                                 sh=1, sw=1, in_sn=Cout * osp, in_st=Ho * Wo, in_sh=Wo, out_sn=Cin * Tp * Hp * Wp,
+                                 out_sc=Tp * Hp * Wp, out_st=st * Hp * Wp, out_sh=sh * Wp, out_sw=sw,
+                                 out_off=offt * Hp * Wp + offy * Wp + offx, reflect=0, is3d=is3d, ns=16 // cck,
+                                 in_sc=osp, splits=1, slab_stride=tgt_numel)
+                    self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix,
+                                             tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
+        # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
+        S = min(L.c2m_conv_igemm_splits(Cin, c["nk"], c["npix"]) for c in self.classes) if self.classes else 1
+        if S > 1:
+            for c in self.classes:
+                if _cdiv(c["nk"], _cdiv(c["nk"], S)) != S:
+                    S = 1
+                    break
+        self.dgrad_splits = S
+        for c in self.classes:
+            c["geom"][26] = S
 
 
 def _plan(x, w, stride, pad, reflect):
@@ -219,16 +284,6 @@ def _gp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def _padded_rows(mat, Kpad):
-    """[M,K] -> contiguous [M,Kpad] (zero tail) when K is not already a multiple of 16."""
-    mat = _f(mat)
-    if mat.shape[1] == Kpad:
-        return mat
-    out = mat.new_zeros(mat.shape[0], Kpad)
-    out[:, :mat.shape[1]] = mat
-    return out
-
-
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, reflect, act):
@@ -236,13 +291,18 @@ class _ConvFn(torch.autograd.Function):
         x, w = _f(x), _f(w)
         pl = _plan(x, w, stride, pad, reflect)
         L = _lib.lib()
-        Cout = pl.dims[2]
-        A = _padded_rows(w.reshape(Cout, pl.K), pl.Kpad)
+        N, Cin, Cout = pl.dims[0:3]
+        A = _pack_rows(w.reshape(Cout, Cin, -1), pl.ck)
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
+        S = pl.fwd_splits
+        dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
+        tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(y), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
-                                                   ACT[act], LRELU_SLOPE, _stream()),
-                          ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect)), "conv_igemm fwd")
+                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
+                                                   ACT[act], LRELU_SLOPE, _stream()), tag), "conv_igemm fwd")
+        if S > 1:
+            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
+                                           LRELU_SLOPE, _stream()), "splitk_reduce")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
         return y
@@ -261,17 +321,24 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             tgt = (torch.zeros if pl.dgrad_needs_zero else torch.empty)(pl.dgrad_target, device=x.device,
                                                                         dtype=torch.float32)
+            S = pl.dgrad_splits
+            dst = tgt
+            if S > 1:
+                dst = (torch.zeros if pl.dgrad_needs_zero else torch.empty)(S * tgt.numel(), device=x.device,
+                                                                            dtype=torch.float32)
             st, sh, sw = pl.stride
             w5 = w if pl.is3d else w.unsqueeze(2)
             for c in pl.classes:
                 rt, ry, rx = c["r"]
-                wc = w5[:, :, rt::st, ry::sh, rx::sw].permute(1, 0, 2, 3, 4).reshape(Cin, c["Kc"])
-                A = _padded_rows(wc, c["Kcp"])
-                _lib.check(_timed("igemm", 2.0 * Cin * c["Kc"] * int(c["geom"][3]),
-                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(tgt), None, _p(c["tab"]), _gp(c["geom"]), 0,
-                                                           0.0, _stream()),
-                                  ("dgrad", Cin, c["Kc"], int(c["geom"][3]), pl.dims[9:12], pl.stride, pl.reflect)),
-                           "conv_igemm dgrad")
+                wc = w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1)
+                A = _pack_rows(wc, c["ck"])
+                tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
+                _lib.check(_timed("igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
+                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), None, _p(c["tab"]), _gp(c["geom"]), 0,
+                                                           0.0, _stream()), tag), "conv_igemm dgrad")
+            if S > 1:
+                _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
+                           "splitk_reduce dgrad")
             if pl.reflect and any(pl.pad):
                 gx = torch.empty_like(x)
                 Ti, Hi, Wi = pl.dims[3:6]
@@ -283,10 +350,10 @@ class _ConvFn(torch.autograd.Function):
             slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
             _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
-                                                       _gp(pl.wg_geom), _stream()),
-                              ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect)), "conv_wgrad")
+                                                       _gp(pl.wg_geom), _stream()), tag), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
         return gx, gw, gb, None, None, None, None
 

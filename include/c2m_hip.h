@@ -28,20 +28,29 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  *   and their autograd backward (aten::convolution_backward).
  *
  * D[m][pix] = act( sum_k A[m][k] * G(k,pix) + bias[m] ),  G = input gathered through `ktab`.
- * geom[] (int64, 25 entries):
- *   0 M   1 K (multiple of 16)   2 lda   3 Npix = N*To*Ho*Wo   4 To 5 Ho 6 Wo   7 Ti 8 Hi 9 Wi
- *   10 st 11 sh 12 sw (input coord = o*stride + tap offset from ktab)
- *   13 in_sn 14 in_st 15 in_sh (input strides in elements; w stride 1; channel offset is in ktab)
+ * K order: (channel chunk, tap group, tap slot, channel in chunk); one 16-deep K-step = NS taps x CK channels.
+ * ktab: nk groups of (1 + NS) int4: header {channel_offset, nvalid_channels (-2: ones row), 0, 0} then NS taps
+ *       {dt, dy, dx, valid}; A is the weight matrix packed by the host into the same order ([M][nk*16]).
+ * geom[] (int64, 32 entries):
+ *   0 M   1 nk (K-steps; for wgrad: J rows)   2 lda   3 Npix = N*To*Ho*Wo   4 To 5 Ho 6 Wo   7 Ti 8 Hi 9 Wi
+ *   10 st 11 sh 12 sw (input coord = o*stride + tap offset)   13 in_sn 14 in_st 15 in_sh (elements; w stride 1)
  *   16 out_sn 17 out_sc 18 out_st 19 out_sh 20 out_sw 21 out_off   22 reflect (0 zeros / 1 reflect) 23 is3d
- *   24 (wgrad only) Jw
- * ktab: K x int4 {channel_offset, t_off, y_off, x_off}; channel_offset -1 = zero row, -2 = ones row.        */
+ *   24 NS (1, 2 or 4)   25 in_sc (channel stride)   26 splits (from c2m_conv_igemm_splits, or 1)
+ *   27 slab_stride (elements between split-K slabs)   28 Cin 29 taps 30 tap groups per chunk 31 real groups (wgrad)
+ * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
+ * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
+int c2m_conv_igemm_splits(int M, int nk, int Npix);
 int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
                    const int64_t* geom, int act, float slope, void* stream);
+int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits, long chan_stride,
+                      int M, int act, float slope, void* stream);
 
-/* dW[m][j] = sum_pix dY[m][pix] * G(j,pix) with deterministic split-K slabs; a trailing ones-row yields db.
- * geom as above with 0 M, 1 J, 2 Jpad (jtab length), 16 dy_sn, 17 dy_sc, 24 Jw (= J or J-1).
- * slab: c2m_conv_wgrad_splits(M, J, Npix) * M * J floats.                                                     */
+/* dW[m][c][tap] (+ db[m]) = sum_pix dY[m][pix] * G(row,pix): rows in the same (chunk, tap group, slot, channel)
+ * order as the forward K, plus one ones-row group (bias gradient), padded to c2m_conv_wgrad_rows(M, groups+1).
+ * Deterministic split-K over pixels: slab = c2m_conv_wgrad_splits(M, J, Npix) * M * J floats; the slab reduction
+ * writes dW in the native [Cout][Cin][taps] layout.  geom: 0 M, 1 J, 16 dy_sn, 17 dy_sc, 24 NS, 28..31 as above. */
 int c2m_conv_wgrad_splits(int M, int J, int Npix);
+int c2m_conv_wgrad_rows(int M, int ngroups);
 int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
                    const int64_t* geom, void* stream);
 
