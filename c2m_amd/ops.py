@@ -157,7 +157,8 @@ def _pack_rows(wm, ck):
         buf = wm.new_zeros(M, nch * ck, ntg * ns)
         buf[:, :C, :taps] = wm
         wm = buf
-    return wm.reshape(M, nch, ck, ntg, ns).permute(0, 1, 3, 4, 2).reshape(M, nch * ntg * 16)
+    # .contiguous(): in degenerate cases (one tap, one chunk) the reshape chain is a strided VIEW of the weights
+    return wm.reshape(M, nch, ck, ntg, ns).permute(0, 1, 3, 4, 2).reshape(M, nch * ntg * 16).contiguous()
 
 
 def _geom(**kw):

@@ -32,6 +32,9 @@ CONV_CASES = [
     ((3, 48, 8, 16), 80, (3, 3), 1, 1, "reflect"),
     ((2, 64, 8, 8), 130, (3, 3), 1, 1, "reflect"),
     ((2, 8, 6, 8), 4, (1, 1), 1, 0, "zeros"),
+    ((10, 32, 16, 32), 16, (1, 1), 1, 0, "zeros"),     # 1x1, one K-step: packed dgrad weights are a pure transpose
+    ((8, 512, 2, 4), 512, (3, 3), 1, 1, "reflect"),    # 64 pixels, K = 4608: split-K path (fwd and dgrad)
+    ((2, 64, 4, 8), 96, (4, 4), 2, 1, "reflect"),      # stride-2 dgrad classes sharing one split-K slab set
     ((2, 21, 16, 32), 64, (4, 4), 2, 1, "reflect"),
     ((1, 32, 16, 32), 1, (3, 3), 1, 1, "reflect"),
     ((5, 40, 4, 8), 40, (3, 3), 1, 1, "reflect"),
