@@ -159,13 +159,16 @@ def test_train_step_vs_golden(name):
             # ~2 % of an object's interior pixels are decided by the last ulp of theta
             budget = 0.06 * float(c.mask("sparse_motion_bin").sum())
             assert mism <= budget, f"{k}: {mism} pixels differ (predicted-theta raster, budget {budget:.0f})"
-    otol = (1e-3, 1e-4) if exact_masks else (3e-2, 3e-2)
-    for k, ref in c.group("sub.out").items():
-        if k.startswith(("sparse_motion", "generated_sparse")) and not exact_masks:
-            continue
-        close(out[k][:, :, :, ::16, ::16], ref, *otol, f"out {k}")
-    for k, ref in c.group("out").items():
-        close(out[k], ref, *otol, f"out {k}")
+    if exact_masks:
+        for k, ref in c.group("sub.out").items():
+            close(out[k][:, :, :, ::16, ::16], ref, 1e-3, 1e-4, f"out {k}")
+    else:
+        # a few hundred support pixels legitimately differ (see above): compare the fields in the mean, not per pixel
+        for k, ref in c.group("sum.out").items():
+            got = summarize(out[k].cpu())
+            assert abs(got[1] - ref[1].item()) <= 3e-2 * abs(ref[1].item()) + 1e-6, f"|{k}| sum {got[1]} vs {ref[1].item()}"
+    for k, ref in c.group("out").items():          # mu, logvar, thetas: upstream of the raster
+        close(out[k], ref, 1e-3, 1e-4, f"out {k}")
     got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     ref_g = c.group("sum.grad")
     assert set(got) == set(ref_g), f"grad key set differs: {sorted(set(got) ^ set(ref_g))[:6]}"
