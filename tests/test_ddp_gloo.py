@@ -1,0 +1,114 @@
+"""N>1 path on CPU: 2 ranks over gloo.  The reducer must deliver mean-of-ranks gradients for a model that is called
+directly, with several backward calls per step and parameters that never receive a gradient (the C2M pattern)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from c2m_amd.ddp import GradientReducer
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 8)
+        self.b = nn.Linear(8, 8)
+        self.head_g = nn.Linear(8, 3)
+        self.head_d = nn.Linear(8, 2)
+        self.unused = nn.Linear(4, 4)          # never touched: must end the step with grad None
+
+    def forward(self, x):
+        h = torch.tanh(self.b(torch.relu(self.a(x))))
+        return self.head_g(h), self.head_d(h.detach()), self.head_d(h)
+
+
+def _losses(model, x):
+    g, d_det, d_att = model(x)
+    return d_det.pow(2).mean(), g.abs().mean() + 0.1 * d_att.mean()      # "D" loss, "G" loss (also reaches head_d)
+
+
+def _single_rank_grads(seed_rank):
+    torch.manual_seed(0)
+    m = Toy()
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + seed_rank))
+    ld, lg = _losses(m, x)
+    ld.backward()
+    lg.backward()
+    return {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+
+
+def _worker(rank, world, port, bucket_mb, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = Toy()
+        red = GradientReducer(list(model.parameters()), bucket_mb=bucket_mb)
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + rank))
+        out = None
+        for step in range(3):                  # step 0 learns the fired set, later steps overlap bucket launches
+            red.zero_grad()
+            ld, lg = _losses(model, x)
+            ld.backward()
+            red.arm()
+            lg.backward()
+            red.finish()
+            out = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+        q.put((rank, out, len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("bucket_mb", [25.0, 0.0002])   # one bucket / several tiny buckets
+def test_mean_of_rank_gradients_two_ranks(bucket_mb):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_mb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [_single_rank_grads(r) for r in range(world)]
+    for rank, got, nbuckets in results:
+        if bucket_mb < 1:
+            assert nbuckets > 2
+        for k in got:
+            if expect[0][k] is None:
+                assert got[k] is None, f"{k} never receives a gradient and must stay None"
+                continue
+            mean = (expect[0][k] + expect[1][k]) / 2
+            torch.testing.assert_close(got[k], mean, rtol=1e-5, atol=1e-7, msg=lambda m: f"rank {rank} {k}: {m}")
+
+
+def test_single_process_reducer_matches_plain_autograd():
+    torch.manual_seed(0)
+    model = Toy()
+    red = GradientReducer(list(model.parameters()), bucket_mb=0.0002)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100))
+    for _ in range(2):
+        red.zero_grad()
+        ld, lg = _losses(model, x)
+        ld.backward()
+        red.arm()
+        lg.backward()
+        red.finish()
+    ref = _single_rank_grads(0)
+    for k, p in model.named_parameters():
+        if ref[k] is None:
+            assert p.grad is None
+        else:
+            torch.testing.assert_close(p.grad, ref[k], rtol=1e-6, atol=1e-8)
