@@ -30,6 +30,8 @@ _SIGS = {
     "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_void_p]),
     "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
+    "c2m_roi_align_bwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "c2m_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "c2m_maxpool2x2_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p]),
     "c2m_sparse_raster": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),

@@ -430,7 +430,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 }
 
 static void wgrad_tile(int M, int& BM, int& BN) {
-    if (M <= 32) { BM = 32; BN = 128; } else { BM = 64; BN = 64; }
+    if (M <= 32) { BM = 32; BN = 128; }
+    else if (M <= 64) { BM = 64; BN = 64; }
+    else { BM = 128; BN = 128; }
 }
 
 // Number of pixel splits the wgrad launch will use for (M, J, Npix): the caller sizes `slab` = S*M*J floats.
@@ -481,6 +483,10 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
         if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 1>), grid, dim3(256), 0, s, p);
         else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 2>), grid, dim3(256), 0, s, p);
         else              hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, p);
+    } else if (p.M > 64) {
+        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, p);
+        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        else              hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, s, p);
     } else {
         if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 1>), grid, dim3(256), 0, s, p);
         else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 2>), grid, dim3(256), 0, s, p);

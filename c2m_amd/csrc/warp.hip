@@ -313,3 +313,85 @@ C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, l
                        NC, Hi, Wi);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------- RoIAlign
+// torchvision.ops.roi_align(aligned=False, sampling_ratio=-1) as called at appearance_encoder.py:67-69.
+// feat [N,C,H,W]; boxes [K,5] = (batch index, x1, y1, x2, y2) on the DEVICE (no host round trip for the adaptive
+// sampling grid); out [K,C,PH,PW].  Backward scatters with float atomics like torchvision's own kernel.
+struct RoiSample { int yl, yh, xl, xh; float w1, w2, w3, w4; bool ok; };
+
+__device__ __forceinline__ RoiSample roi_sample(float y, float x, int H, int W) {
+    RoiSample s;
+    s.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    s.yl = (int)y; s.xl = (int)x;
+    if (s.yl >= H - 1) { s.yh = s.yl = H - 1; y = (float)s.yl; } else s.yh = s.yl + 1;
+    if (s.xl >= W - 1) { s.xh = s.xl = W - 1; x = (float)s.xl; } else s.xh = s.xl + 1;
+    const float ly = y - (float)s.yl, lx = x - (float)s.xl, hy = 1.f - ly, hx = 1.f - lx;
+    s.w1 = hy * hx; s.w2 = hy * lx; s.w3 = ly * hx; s.w4 = ly * lx;
+    return s;
+}
+
+template <bool BWD>
+__global__ void roi_align_kernel(const float* __restrict__ feat, const float* __restrict__ boxes,
+                                 float* __restrict__ out_or_gfeat, const float* __restrict__ gout, int K, int C, int H,
+                                 int W, int PH, int PW, float scale) {
+    const long total = (long)K * C * PH * PW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int pw = (int)(i % PW); long r = i / PW;
+        const int ph = (int)(r % PH); r /= PH;
+        const int c = (int)(r % C); const int k = (int)(r / C);
+        const float* __restrict__ bx = boxes + (long)k * 5;
+        const int b = (int)bx[0];
+        const float x1 = bx[1] * scale, y1 = bx[2] * scale, x2 = bx[3] * scale, y2 = bx[4] * scale;
+        const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+        const float bh = rh / (float)PH, bw = rw / (float)PW;
+        const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+        const float cnt = fmaxf((float)(gh * gw), 1.f);
+        const long plane = ((long)b * C + c) * H * W;
+        float acc = 0.f;
+        const float g = BWD ? gout[i] / cnt : 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                const RoiSample s = roi_sample(y, x, H, W);
+                if (!s.ok) continue;
+                if (BWD) {
+                    float* __restrict__ gf = out_or_gfeat + plane;
+                    atomicAdd(gf + (long)s.yl * W + s.xl, g * s.w1);
+                    atomicAdd(gf + (long)s.yl * W + s.xh, g * s.w2);
+                    atomicAdd(gf + (long)s.yh * W + s.xl, g * s.w3);
+                    atomicAdd(gf + (long)s.yh * W + s.xh, g * s.w4);
+                } else {
+                    const float* __restrict__ f = feat + plane;
+                    acc += s.w1 * f[(long)s.yl * W + s.xl] + s.w2 * f[(long)s.yl * W + s.xh] +
+                           s.w3 * f[(long)s.yh * W + s.xl] + s.w4 * f[(long)s.yh * W + s.xh];
+                }
+            }
+        }
+        if (!BWD) out_or_gfeat[i] = acc / cnt;
+    }
+}
+
+C2M_API int c2m_roi_align_fwd(const float* feat, const float* boxes, float* out, int K, int C, int H, int W, int PH,
+                              int PW, float spatial_scale, void* stream) {
+    C2M_ENTER();
+    const long total = (long)K * C * PH * PW;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(roi_align_kernel<false>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat,
+                       boxes, out, (const float*)nullptr, K, C, H, W, PH, PW, spatial_scale);
+    return (int)hipGetLastError();
+}
+
+// gfeat must be zero-initialised by the caller
+C2M_API int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int K, int C, int H, int W, int PH,
+                              int PW, float spatial_scale, void* stream) {
+    C2M_ENTER();
+    const long total = (long)K * C * PH * PW;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(roi_align_kernel<true>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, boxes, gfeat, gout, K, C, H, W, PH, PW, spatial_scale);
+    return (int)hipGetLastError();
+}

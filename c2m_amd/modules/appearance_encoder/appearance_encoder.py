@@ -7,7 +7,7 @@ from torch import nn
 
 from ..layers.same_block import SameBlock2d
 from ..layers.down_block import DownBlock2d
-from ...thirdparty import roi_align
+from ... import ops
 
 
 class AppearanceEncoder(nn.Module):
@@ -58,7 +58,7 @@ class AppearanceEncoder(nn.Module):
         boxes = torch.cat([gnn.batch.unsqueeze(1).repeat_interleave(t_in, dim=0),
                            torch.cat(torch.unbind(gnn.source_frames_nodes_roi_padded, dim=1), dim=0)], dim=1)
         pooled_src = torch.cat(out[f"enco{self.pooling_after - 1}"].chunk(t_in, 1), dim=0)
-        obj = roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
+        obj = ops.roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
         obj = self.roi_align_regressor(self.roi_align_blocks(obj))
         scene = torch.repeat_interleave(out["app_encoded"].flatten(1), gnn.num_real_nodes * t_in, dim=0)
         fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))

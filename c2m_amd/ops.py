@@ -519,6 +519,36 @@ def maxpool2x2(x):
     return _MaxPool2Fn.apply(x)
 
 
+class _RoiAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, boxes, ph, pw, scale):
+        _dev(feat, boxes)
+        feat, boxes = _f(feat), _f(boxes)
+        N, C, H, W = feat.shape
+        K = boxes.shape[0]
+        out = torch.empty(K, C, ph, pw, device=feat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_roi_align_fwd(_p(feat), _p(boxes), _p(out), K, C, H, W, ph, pw, scale, _stream()),
+                   "roi_align")
+        ctx.cfg = (N, C, H, W, K, ph, pw, scale)
+        ctx.save_for_backward(boxes)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (boxes,) = ctx.saved_tensors
+        N, C, H, W, K, ph, pw, scale = ctx.cfg
+        gfeat = torch.zeros(N, C, H, W, device=gout.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_roi_align_bwd(_p(boxes), _p(_f(gout)), _p(gfeat), K, C, H, W, ph, pw, scale, _stream()),
+                   "roi_align_bwd")
+        return gfeat, None, None, None, None
+
+
+def roi_align(feat, boxes, output_size, spatial_scale=1.0):
+    """torchvision.ops.roi_align(feat, boxes[K,5], output_size, spatial_scale) with aligned=False, sampling_ratio=-1."""
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    return _RoiAlignFn.apply(feat, boxes.to(torch.float32), int(ph), int(pw), float(spatial_scale))
+
+
 # =============================================================================================== index / mask path
 def sparse_raster(instance, obj_id, obj_batch, thetas):
     """instance [B,H,W] float ids, obj_id/obj_batch [K], thetas [K,T,6] -> (bw [B,2,T,H,W], fw, bin [B,1,T,H,W])."""

@@ -1,56 +1,11 @@
-"""Product-side restatements of the two small third-party ops on the path (PyTorch device ops, negligible FLOPs --
-SURVEY.md §2.4 marks them "support"): torchvision.ops.roi_align and torch_geometric.nn.GATv2Conv.
-Neither package is a dependency; parameter names follow the originals so checkpoints load."""
+"""Product-side restatement of torch_geometric.nn.GATv2Conv (PyTorch device ops on a 24-node graph, negligible FLOPs --
+SURVEY.md §2.4 marks it "support").  torch_geometric is not a dependency; parameter names follow the original so
+checkpoints load.  (torchvision.ops.roi_align is a HIP kernel: c2m_amd.ops.roi_align.)"""
 import math
 
 import torch
 import torch.nn.functional as F
 from torch import nn
-
-
-def roi_align(inp, boxes, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
-    """RoIAlign (aligned=False, adaptive sampling grid); inp [N,C,H,W], boxes [K,5] = (batch, x1, y1, x2, y2).
-    The sampling-grid sizes need the box extents on the host: one small D2H copy of the [K,5] box table."""
-    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
-    _, C, H, W = inp.shape
-    bx = boxes.detach().to("cpu", torch.float64)
-    off = 0.5 if aligned else 0.0
-    out = []
-    for k in range(bx.shape[0]):
-        b = int(bx[k, 0])
-        x1, y1, x2, y2 = (float(bx[k, j]) * spatial_scale - off for j in (1, 2, 3, 4))
-        rw, rh = x2 - x1, y2 - y1
-        if not aligned:
-            rw, rh = max(rw, 1.0), max(rh, 1.0)
-        bh, bw = rh / ph, rw / pw
-        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
-        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
-        if gh <= 0 or gw <= 0:
-            out.append(inp.new_zeros(C, ph, pw))
-            continue
-        dev, dt = inp.device, inp.dtype
-        ys = (y1 + torch.arange(ph, device=dev, dtype=dt)[:, None] * bh +
-              (torch.arange(gh, device=dev, dtype=dt)[None, :] + 0.5) * bh / gh).reshape(-1)
-        xs = (x1 + torch.arange(pw, device=dev, dtype=dt)[:, None] * bw +
-              (torch.arange(gw, device=dev, dtype=dt)[None, :] + 0.5) * bw / gw).reshape(-1)
-        oy, ox = (ys < -1.0) | (ys > H), (xs < -1.0) | (xs > W)
-        y, x = ys.clamp(min=0.0), xs.clamp(min=0.0)
-        yl, xl = y.floor().long(), x.floor().long()
-        ty, tx = yl >= H - 1, xl >= W - 1
-        yh = torch.where(ty, torch.full_like(yl, H - 1), yl + 1)
-        yl = torch.where(ty, torch.full_like(yl, H - 1), yl)
-        y = torch.where(ty, yl.to(dt), y)
-        xh = torch.where(tx, torch.full_like(xl, W - 1), xl + 1)
-        xl = torch.where(tx, torch.full_like(xl, W - 1), xl)
-        x = torch.where(tx, xl.to(dt), x)
-        ly, lx = y - yl.to(dt), x - xl.to(dt)
-        hy, hx = 1.0 - ly, 1.0 - lx
-        f = inp[b]
-        val = (hy[:, None] * hx[None, :]) * f[:, yl][:, :, xl] + (hy[:, None] * lx[None, :]) * f[:, yl][:, :, xh] + \
-              (ly[:, None] * hx[None, :]) * f[:, yh][:, :, xl] + (ly[:, None] * lx[None, :]) * f[:, yh][:, :, xh]
-        val = val * ((~oy)[:, None] & (~ox)[None, :]).to(dt)
-        out.append(val.reshape(C, ph, gh, pw, gw).sum(dim=(2, 4)) / max(gh * gw, 1))
-    return torch.stack(out, 0) if out else inp.new_zeros(0, C, ph, pw)
 
 
 class GATv2Conv(nn.Module):

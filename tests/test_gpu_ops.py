@@ -323,3 +323,19 @@ def test_l1_mean_grad_to_second_argument():
     bg = g(b).requires_grad_(True)
     ops.l1_mean(g(a), bg).backward()
     close(bg.grad, br.grad, 1e-6, 1e-9)
+
+
+def test_roi_align_vs_oracle():
+    from oracle import thirdparty
+    feat = rnd(1, 4, 6, 32, 64)
+    boxes = torch.tensor([[0, 5.3, 30.2, 95.7, 80.1], [1, 0.0, 0.0, 256.0, 128.0], [3, 100.5, 60.0, 101.0, 60.4],
+                          [2, 200.0, 100.0, 270.0, 140.0], [0, 20.0, 40.0, 75.0, 85.0]], dtype=torch.float32)
+    fr = feat.clone().requires_grad_(True)
+    yr = thirdparty.roi_align(fr, boxes, 7, spatial_scale=0.25)
+    go = rnd(2, *yr.shape)
+    (yr * go).sum().backward()
+    fg = g(feat).requires_grad_(True)
+    y = ops.roi_align(fg, g(boxes), 7, spatial_scale=0.25)
+    (y * g(go)).sum().backward()
+    close(y, yr, 1e-4, 1e-5, "roi_align fwd")
+    close(fg.grad, fr.grad, 1e-4, 1e-5, "roi_align bwd")
