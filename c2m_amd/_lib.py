@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libc2m_hip.so")
+LIB_PATH = os.environ.get("C2M_AMD_LIB") or os.path.join(_HERE, "lib", "libc2m_hip.so")   # override: tuning builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "c2m_hip.h")
 _lib = None
 

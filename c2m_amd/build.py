@@ -20,27 +20,35 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, defines=()):
+    """variant/defines: tuning builds (lib/libc2m_hip_<variant>.so compiled with -D...), selected at run time with
+    the environment variable C2M_AMD_LIB; the default build takes neither."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [os.path.join(CSRC, "common.h")]
+    suffix = f"_{variant}" if variant else ""
+    lib = LIB.replace(".so", suffix + ".so")
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + common):
-            cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-c", s, "-o", o] + extra
+        o = os.path.join(LIB_DIR, src.replace(".hip", suffix + ".o"))
+        if force or variant or _stale(o, [s] + common):
+            cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-c", s, "-o", o] + extra + \
+                  [f"-D{d}" for d in defines]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if force or variant or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = args[0] if args and not args[0].startswith("-D") else None
+    print(build(force="--force" in sys.argv, verbose=True, variant=variant,
+                defines=[a[2:] for a in args if a.startswith("-D")]))

@@ -38,6 +38,7 @@ struct ConvP {
     long in_sn, in_st, in_sh;
     long out_sn, out_sc, out_st, out_sh, out_sw, out_off;
     long slab_stride;    // elements between split slabs
+    unsigned x_bytes;    // size of X in bytes (buffer-load bounds: out-of-range lanes read 0)
     int ksteps_per_split;
     int reflect, is3d;
     int act;
@@ -59,6 +60,8 @@ __device__ __forceinline__ int spatial_off(const int4 tp, int ots, int oys, int 
     }
     return ok ? it * in_st + iy * in_sh + ix : -1;
 }
+
+#define C2M_OOB 0x80000000u   // voffset beyond any tensor we accept (< 2 GiB): the buffer load returns 0
 
 template <class P>
 __device__ __forceinline__ void decompose_pix(int pix, const P& p, int& n, int& ot, int& oy, int& ox) {
@@ -113,30 +116,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     float4 ra[APASS];
     float rb[BPASS];
 
+    // per-thread weight row pointers (fixed for the whole K loop)
+    const float* __restrict__ aptr[APASS];
+#pragma unroll
+    for (int s = 0; s < APASS; ++s) {
+        int row = m0 + arow + s * 64; row = row < p.M ? row : p.M - 1;
+        aptr[s] = p.A + (long)row * p.lda + akq;
+    }
+    // gather table of the NEXT tile to load, fetched one K-step ahead (scalar loads: their latency must not sit in
+    // front of the address arithmetic)
+    int4 t_hdr, t_tap[NS];
+    auto fetch_table = [&](int kt) {
+        const int4* __restrict__ kd = p.ktab + (long)kt * (1 + NS);
+        t_hdr = kd[0];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) t_tap[q] = kd[1 + q];
+    };
+
+    // B gather through a raw buffer descriptor: per element the VECTOR offset is the per-tap spatial byte offset of
+    // this lane (computed once per tap) and the SCALAR offset is the channel offset (SALU only); padding taps and
+    // lanes outside the image carry an out-of-range voffset and read 0 -- no per-element VALU at all.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const unsigned img_byte = (unsigned)(pn * (int)p.in_sn) * 4u;
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int s = 0; s < APASS; ++s) {
-            int r = arow + s * 64;
-            if (A_F4 >= 256 || r < BM) {
-                int row = m0 + r; row = row < p.M ? row : p.M - 1;
-                ra[s] = *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + kt * BK + akq);
-            }
+            if (A_F4 >= 256 || arow + s * 64 < BM) ra[s] = *reinterpret_cast<const float4*>(aptr[s] + kt * BK);
         }
-        const int4* __restrict__ kd = p.ktab + (long)kt * (1 + NS);
-        const int4 hdr = kd[0];
-        int sp[NS];
+        const int4 hdr = t_hdr;
+        unsigned vo[NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q)
-            sp[q] = spatial_off(kd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+        for (int q = 0; q < NS; ++q) {
+            const int so = spatial_off(t_tap[q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+            vo[q] = so >= 0 ? img_byte + (unsigned)so * 4u : C2M_OOB;
+        }
 #pragma unroll
         for (int s = 0; s < BPASS; ++s) {
             const int slot = (s * BROWS) / CK;                       // compile-time
             const int cc = (s * BROWS) % CK + brow0;                  // wave-uniform
-            const int so = sp[slot];
-            float v = 0.f;
-            if (so >= 0 && cc < hdr.y) v = Xn[hdr.x + cc * p.in_sc + so];
-            rb[s] = v;
+            // channels beyond nvalid only meet zero weights (A is zero-padded); they read in-range data or 0
+            const int soff = (hdr.x + cc * p.in_sc) * 4;
+            rb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[slot], soff, 0));
         }
+        fetch_table(kt + 1 < p.nk ? kt + 1 : kt);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -151,7 +173,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         for (int s = 0; s < BPASS; ++s) sB[buf][brow0 + s * BROWS][bp] = rb[s];
     };
 
+#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 1
+    { const int bid = blockIdx.x + blockIdx.y * gridDim.x;
+      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
+#elif defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 2
+    { const int bid = (blockIdx.x + blockIdx.y * gridDim.x) >> 3;
+      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
+#elif defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 4
+    { const int bid = (blockIdx.x + blockIdx.y * gridDim.x) >> 8;
+      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
+#endif
     if (kt_beg < kt_end) {
+        fetch_table(kt_beg);
         load_tile(kt_beg);
         store_tile(0);
     }
@@ -159,21 +192,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     int cur = 0;
     for (int kt = kt_beg; kt < kt_end; ++kt) {
         const bool more = kt + 1 < kt_end;
+#ifndef C2M_IGEMM_READS_FIRST
         if (more) load_tile(kt + 1);
+#endif
+        // all fragment reads of the K-step are issued first (own registers each), so the LDS latency of k-pair
+        // kk+1.. hides behind the MFMAs of kk (the compiler otherwise recycles 4 VGPRs and serialises read -> mfma)
+        float a[BK / 2][MI], b[BK / 2][NI];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = kk * 2 + (lane >> 5);
-            float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = sA[cur][krow][wm * TM + i * 32 + (lane & 31)];
+            for (int i = 0; i < MI; ++i) a[kk][i] = sA[cur][krow][wm * TM + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = sB[cur][krow][wn * TN + j * 32 + (lane & 31)];
+            for (int j = 0; j < NI; ++j) b[kk][j] = sB[cur][krow][wn * TN + j * 32 + (lane & 31)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef C2M_IGEMM_READS_FIRST
+        if (more) load_tile(kt + 1);      // address arithmetic + global loads fill the LDS read latency
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);    // MFMA phase: low priority, the load/LDS phases of other waves go first
+#endif
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 3
+        __builtin_amdgcn_s_setprio(2);
+#endif
         if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -269,6 +321,8 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float
     p.in_sc = (int)g[25];
     const int splits = (int)g[26];           // 1, or the value returned by c2m_conv_igemm_splits
     p.slab_stride = g[27];
+    if (g[32] <= 0 || g[32] >= 0x80000000LL) return (int)hipErrorInvalidValue;   // X must be < 2 GiB
+    p.x_bytes = (unsigned)g[32];
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.Npix <= 0) return 0;
     if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
@@ -303,6 +357,7 @@ struct WgradP {
     long dy_sn, dy_sc;   // dY strides (pix stride 1)
     int pix_per_split;   // multiple of 64
     int reflect, is3d;
+    unsigned x_bytes, dy_bytes;
 };
 
 template <int BM, int BN, int WGM, int WGN, int NS>
@@ -334,38 +389,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[AROWS], rb[BROWSW];
+    // raw buffer descriptors: per-lane byte offset = this lane's pixel (out of range for dead lanes -> reads 0),
+    // scalar offset = row / channel offset (SALU): no per-element VALU
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     for (int pk = pbeg; pk < pend; pk += BK) {
         const int pix = pk + lane;
         const bool live = pix < pend;
         int n, ot, oy, ox;
         decompose_pix(live ? pix : pend - 1, p, n, ot, oy, ox);
         const int sp = (ot * p.Ho + oy) * p.Wo + ox;
-        const float* __restrict__ dyn = p.dY + (long)n * p.dy_sn + sp;
-        const float* __restrict__ Xn = p.X + (long)n * p.in_sn;
+        const unsigned yvo = live ? (unsigned)(n * (int)p.dy_sn + sp) * 4u : C2M_OOB;
+        const unsigned ximg = (unsigned)(n * (int)p.in_sn) * 4u;
         const int ots = ot * p.st, oys = oy * p.sh, oxs = ox * p.sw;
 #pragma unroll
         for (int s = 0; s < AROWS; ++s) {
-            const int row = m0 + wave * AROWS + s;
-            float v = 0.f;
-            if (live && row < p.M) v = dyn[(long)row * p.dy_sc];
-            ra[s] = v;
+            const int row = m0 + wave * AROWS + s;            // rows >= M give columns that are never stored
+            ra[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, yvo, row * (int)p.dy_sc * 4, 0));
         }
 #pragma unroll
         for (int gq = 0; gq < BGROUPS; ++gq) {
             const int grp = (j0 + wave * BROWSW) / 16 + gq;     // < J/16 by construction of the grid
             const int4* __restrict__ jd = p.jtab + (long)grp * (1 + NS);
             const int4 hdr = jd[0];
-            int so[NS];
+            unsigned vo[NS];
 #pragma unroll
-            for (int q = 0; q < NS; ++q)
-                so[q] = spatial_off(jd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+            for (int q = 0; q < NS; ++q) {
+                const int so = spatial_off(jd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+                vo[q] = (live && so >= 0) ? ximg + (unsigned)so * 4u : C2M_OOB;
+            }
+            if (hdr.y == -2) {                                   // ones row (bias gradient); wave-uniform branch
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int slot = s / CK, cc = s % CK;                 // compile-time
-                float v = 0.f;
-                if (hdr.y == -2) v = (s == 0) ? 1.f : 0.f;           // ones row (bias gradient)
-                else if (so[slot] >= 0 && cc < hdr.y) v = Xn[hdr.x + cc * p.in_sc + so[slot]];
-                rb[gq * 16 + s] = live ? v : 0.f;
+                for (int s = 0; s < 16; ++s) rb[gq * 16 + s] = (s == 0) ? 1.f : 0.f;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int slot = s / CK, cc = s % CK;         // compile-time
+                    // channels >= nvalid produce columns the reduction never reads
+                    rb[gq * 16 + s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        xrsrc, vo[slot], (hdr.x + cc * p.in_sc) * 4, 0));
+                }
             }
         }
         __syncthreads();   // previous K-step's fragment reads are done
@@ -374,19 +437,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int s = 0; s < BROWSW; ++s) sB[wave * BROWSW + s][lane] = rb[s];
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int kcol = kk * 2 + (lane >> 5);
-            float a[MI], b[NI];
+        // fragment reads in groups of 8 k-pairs issued ahead of their MFMAs (see the igemm kernel)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = sA[wm * TM + i * 32 + (lane & 31)][kcol];
+        for (int kg = 0; kg < BK / 16; ++kg) {
+            float a[8][MI], b[8][NI];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = sB[wn * TN + j * 32 + (lane & 31)][kcol];
+            for (int kk = 0; kk < 8; ++kk) {
+                const int kcol = (kg * 8 + kk) * 2 + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i) a[kk][i] = sA[wm * TM + i * 32 + (lane & 31)][kcol];
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) b[kk][j] = sB[wn * TN + j * 32 + (lane & 31)][kcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float* __restrict__ out = p.slab + (long)split * p.M * p.J;
@@ -468,6 +539,8 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
     p.reflect = (int)g[22]; p.is3d = (int)g[23];
     p.in_sc = (int)g[25];
     const int NS = (int)g[24], Cin = (int)g[28], taps = (int)g[29], ntg = (int)g[30], ngroups = (int)g[31];
+    if (g[32] <= 0 || g[32] >= 0x80000000LL || g[33] <= 0 || g[33] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[32]; p.dy_bytes = (unsigned)g[33];
     if (p.M <= 0 || p.J <= 0 || p.Npix <= 0) return 0;
     int BM, BN;
     wgrad_tile(p.M, BM, BN);

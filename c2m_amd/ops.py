@@ -162,10 +162,10 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(32, dtype=np.int64)
+    g = np.zeros(36, dtype=np.int64)
     idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
                in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
-               in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31)
+               in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
     for k, v in kw.items():
         g[idx[k]] = v
     return g
@@ -189,8 +189,8 @@ class _ConvPlan:
             raise ValueError("empty convolution output")
         if reflect and (pt >= Ti and pt > 0 or ph >= Hi and ph > 0 or pw >= Wi and pw > 0):
             raise ValueError("reflect padding must be smaller than the input extent")
-        if N * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo) >= 2 ** 31:
-            raise ValueError("tensor too large for 32-bit offsets")
+        if 4 * N * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo) >= 2 ** 31:
+            raise ValueError("tensor too large: the gather uses 32-bit byte offsets (< 2 GiB per tensor)")
         self.dims = (N, Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw)
         self.stride, self.pad, self.reflect = stride, pad, reflect
         self.out_shape = (N, Cout, To, Ho, Wo) if nd == 3 else (N, Cout, Ho, Wo)
@@ -209,7 +209,8 @@ class _ConvPlan:
         self.fwd_geom = _geom(M=Cout, nk=nk, lda=nk * 16, Npix=N * osp, To=To, Ho=Ho, Wo=Wo, Ti=Ti, Hi=Hi, Wi=Wi, st=st,
                               sh=sh, sw=sw, in_sn=Cin * in_sc, in_st=Hi * Wi, in_sh=Wi, out_sn=Cout * osp, out_sc=osp,
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
-                              in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp)
+                              in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp,
+                              x_bytes=4 * N * Cin * in_sc)
         # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
         self.J = L.c2m_conv_wgrad_rows(Cout, nk + 1)
         wtab, _, _ = _kstep_table(Cin, offs, in_sc, ck, extra_groups=self.J // 16 - nk - 1, ones_group=True)
@@ -217,6 +218,7 @@ class _ConvPlan:
         self.wg_geom = self.fwd_geom.copy()
         self.wg_geom[[0, 1, 16, 17]] = (Cout, self.J, Cout * osp, osp)
         self.wg_geom[[28, 29, 30, 31]] = (Cin, taps, ntg, nk)
+        self.wg_geom[33] = 4 * N * Cout * osp
         self.wg_splits = L.c2m_conv_wgrad_splits(Cout, self.J, N * osp)
         # ---- dgrad: one launch per stride-parity class
         Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)
@@ -258,7 +260,7 @@ class _ConvPlan:
                                  sh=1, sw=1, in_sn=Cout * osp, in_st=Ho * Wo, in_sh=Wo, out_sn=Cin * Tp * Hp * Wp,
                                  out_sc=Tp * Hp * Wp, out_st=st * Hp * Wp, out_sh=sh * Wp, out_sw=sw,
                                  out_off=offt * Hp * Wp + offy * Wp + offx, reflect=0, is3d=is3d, ns=16 // cck,
-                                 in_sc=osp, splits=1, slab_stride=tgt_numel)
+                                 in_sc=osp, splits=1, slab_stride=tgt_numel, x_bytes=4 * N * Cout * osp)
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree

@@ -191,6 +191,9 @@ def test_train_step_vs_golden(name):
     assert nograd == sorted(c.json("nograd")), "set of trainable params that never get a gradient"
     bufs = dict(model.named_buffers())
     for k, ref in c.group("sum.buf").items():
+        if not exact_masks:
+            assert np.all(np.isfinite(summarize(bufs[k].cpu())))
+            continue
         np.testing.assert_allclose(summarize(bufs[k].cpu()), ref.numpy(), rtol=1e-3, atol=1e-5, err_msg=f"buf {k}")
 
 
