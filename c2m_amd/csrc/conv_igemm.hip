@@ -272,6 +272,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
     }
 }
 
+template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
+
 template <int BM, int BN, int WGM, int WGN>
 static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s) {
     dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits);
@@ -291,12 +293,15 @@ static void igemm_tile(int M, int& BM, int& BN) {
 }
 
 // Number of K splits the launch will use (the caller sizes the slab = splits * slab_stride floats when > 1).
+// Blocks are dispatched dynamically, so a grid only loses time when it is too small to keep every CU busy to the end:
+// below ~4 blocks per CU the K loop is split until there are ~5 per CU (e.g. 640 tiles = 2.5/CU would leave the CUs
+// that got 2 blocks idle for a third of the launch).
 C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
     int BM, BN;
     igemm_tile(M, BM, BN);
     const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(Npix, BN);
-    if (tiles >= 384 || nk < 8) return 1;
-    long S = (768 + tiles - 1) / tiles;
+    if (tiles >= 1024 || nk < 8) return 1;
+    long S = (1280 + tiles - 1) / tiles;
     if (S > nk / 4) S = nk / 4;
     if (S > 128) S = 128;
     if (S < 2) return 1;
@@ -329,6 +334,11 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
     if (c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // a split would be empty
     hipStream_t s = (hipStream_t)stream;
+    if (p.M <= 4 && splits == 1 && p.Npix >= 16384) {      // thin output: vector-ALU kernel
+        if (ns == 1) return launch_thin_fwd<1>(p, s);
+        if (ns == 2) return launch_thin_fwd<2>(p, s);
+        return launch_thin_fwd<4>(p, s);
+    }
     if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s);
     else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s);
     else                return launch_igemm<128, 128, 2, 2>(p, ns, splits, s);
@@ -500,6 +510,145 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ thin layers
+// Convolutions with <= 4 output channels (flow / occlusion heads, the RGB output conv) waste >= 87 % of a 32-row MFMA
+// tile; they run on the vector ALU instead: one pixel per lane, the same K-step table and buffer-load gather, weights
+// through scalar loads (the k index is wave-uniform).  Forward only needs this; the data gradient of these layers has
+// M = Cin >= 32 and stays on the MFMA path.
+template <int MT, int NS>
+__global__ __launch_bounds__(256) void conv_thin_fwd_kernel(const ConvP p) {
+    constexpr int CK = 16 / NS;
+    const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < p.Npix; pix += gridDim.x * 256) {
+        int n, ot, oy, ox;
+        decompose_pix(pix, p, n, ot, oy, ox);
+        const unsigned img_byte = (unsigned)(n * (int)p.in_sn) * 4u;
+        const int ots = ot * p.st, oys = oy * p.sh, oxs = ox * p.sw;
+        float acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const int4* __restrict__ kd = p.ktab + (long)kt * (1 + NS);
+            const int4 hdr = kd[0];
+            unsigned vo[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int so = spatial_off(kd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+                vo[q] = so >= 0 ? img_byte + (unsigned)so * 4u : C2M_OOB;
+            }
+            float xv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    xrsrc, vo[e / CK], (hdr.x + (e % CK) * p.in_sc) * 4, 0));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float* __restrict__ wr = p.A + (long)m * p.lda + kt * 16;      // uniform -> scalar loads
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m] = fmaf(xv[e], wr[e], acc[m]);
+            }
+        }
+        float* __restrict__ yb = p.Y + p.out_off + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
+                                 (long)ox * p.out_sw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < p.M) {
+                float v = acc[m];
+                if (p.bias) v += p.bias[m];
+                yb[(long)m * p.out_sc] = c2m_act(v, p.act, p.slope);
+            }
+        }
+    }
+}
+
+template <int NS>
+static int launch_thin_fwd(const ConvP& p, hipStream_t s) {
+    dim3 grid(c2m_grid(p.Npix, 256));
+    switch (p.M) {
+        case 1: hipLaunchKernelGGL((conv_thin_fwd_kernel<1, NS>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_thin_fwd_kernel<2, NS>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((conv_thin_fwd_kernel<3, NS>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_thin_fwd_kernel<4, NS>), grid, dim3(256), 0, s, p); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// wgrad for <= 4 output channels: lanes = pixels, each thread keeps GPB*16*MT partial sums in registers over its
+// pixels of the split, then a block reduction; slab layout identical to the MFMA wgrad so the same reduction finishes.
+template <int MT, int NS, int GPB>
+__global__ __launch_bounds__(256) void conv_thin_wgrad_kernel(const WgradP p, int ngroups_total) {
+    constexpr int CK = 16 / NS;
+    __shared__ float red[4][GPB * 16 * MT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = blockIdx.x * GPB;
+    const int split = blockIdx.z;
+    const int pbeg = split * p.pix_per_split;
+    int pend = pbeg + p.pix_per_split; pend = pend < p.Npix ? pend : p.Npix;
+    const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    float acc[GPB][16][MT];
+#pragma unroll
+    for (int g = 0; g < GPB; ++g)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[g][s][m] = 0.f;
+    for (int pix = pbeg + threadIdx.x; pix < pend; pix += 256) {
+        int n, ot, oy, ox;
+        decompose_pix(pix, p, n, ot, oy, ox);
+        const int sp = (ot * p.Ho + oy) * p.Wo + ox;
+        float dy[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dy[m] = m < p.M ? p.dY[(long)n * p.dy_sn + (long)m * p.dy_sc + sp] : 0.f;
+        const unsigned ximg = (unsigned)(n * (int)p.in_sn) * 4u;
+        const int ots = ot * p.st, oys = oy * p.sh, oxs = ox * p.sw;
+#pragma unroll
+        for (int g = 0; g < GPB; ++g) {
+            const int grp = g0 + g;
+            if (grp >= ngroups_total) break;
+            const int4* __restrict__ jd = p.jtab + (long)grp * (1 + NS);
+            const int4 hdr = jd[0];
+            if (hdr.y == -2) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[g][0][m] += dy[m];
+                continue;
+            }
+            unsigned vo[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int so = spatial_off(jd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+                vo[q] = so >= 0 ? ximg + (unsigned)so * 4u : C2M_OOB;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    xrsrc, vo[s / CK], (hdr.x + (s % CK) * p.in_sc) * 4, 0));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[g][s][m] = fmaf(dy[m], x, acc[g][s][m]);
+            }
+        }
+    }
+    // block reduction: wave shuffles, then 4 partials through LDS (fixed order)
+#pragma unroll
+    for (int g = 0; g < GPB; ++g)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float v = wave_sum(acc[g][s][m]);
+                if (lane == 0) red[wave][(g * 16 + s) * MT + m] = v;
+            }
+    __syncthreads();
+    float* __restrict__ out = p.slab + (long)split * p.M * p.J;
+    for (int i = threadIdx.x; i < GPB * 16 * MT; i += 256) {
+        const int m = i % MT, gs = i / MT;
+        const int col = g0 * 16 + gs;
+        if (m < p.M && col < ngroups_total * 16)
+            out[(long)m * p.J + col] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
 static void wgrad_tile(int M, int& BM, int& BN) {
     if (M <= 32) { BM = 32; BN = 128; }
     else if (M <= 64) { BM = 64; BN = 64; }
@@ -552,6 +701,31 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
     const int Seff = c2m_cdiv(p.Npix, per);   // <= S; unused slabs are never read
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.J / BN, c2m_cdiv(p.M, BM), Seff);
+    if (p.M <= 4 && p.Npix >= 16384) {                    // thin output: vector-ALU kernel, same slab layout
+        constexpr int GPB = 2;
+        const int ng = ngroups + 1;                       // real groups + the ones group
+        // pixel splits sized for ~1024 blocks but >= 16K pixels each (the block reduction is per block)
+        int St = (1024 + c2m_cdiv(ng, GPB) - 1) / c2m_cdiv(ng, GPB);
+        const int maxS = S;                               // the caller's slab holds S splits
+        if (St > maxS) St = maxS;
+        if (St < 1) St = 1;
+        int per2 = ((c2m_cdiv(p.Npix, St) + 255) / 256) * 256;
+        p.pix_per_split = per2;
+        const int Sthin = c2m_cdiv(p.Npix, per2);
+        dim3 tg(c2m_cdiv(ng, GPB), 1, Sthin);
+#define C2M_THIN_W(MT) \
+        if (NS == 1)      hipLaunchKernelGGL((conv_thin_wgrad_kernel<MT, 1, GPB>), tg, dim3(256), 0, s, p, ng); \
+        else if (NS == 2) hipLaunchKernelGGL((conv_thin_wgrad_kernel<MT, 2, GPB>), tg, dim3(256), 0, s, p, ng); \
+        else              hipLaunchKernelGGL((conv_thin_wgrad_kernel<MT, 4, GPB>), tg, dim3(256), 0, s, p, ng);
+        if (p.M == 1) { C2M_THIN_W(1) } else if (p.M == 2) { C2M_THIN_W(2) } else if (p.M == 3) { C2M_THIN_W(3) } else { C2M_THIN_W(4) }
+#undef C2M_THIN_W
+        int rc2 = (int)hipGetLastError();
+        if (rc2) return rc2;
+        const long total2 = (long)p.M * (Cin * taps + 1);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total2, 256)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
+                           taps, NS, ntg, ngroups, Sthin);
+        return (int)hipGetLastError();
+    }
     if (p.M <= 32) {
         if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 1>), grid, dim3(256), 0, s, p);
         else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 2>), grid, dim3(256), 0, s, p);

@@ -35,6 +35,10 @@ CONV_CASES = [
     ((10, 32, 16, 32), 16, (1, 1), 1, 0, "zeros"),     # 1x1, one K-step: packed dgrad weights are a pure transpose
     ((8, 512, 2, 4), 512, (3, 3), 1, 1, "reflect"),    # 64 pixels, K = 4608: split-K path (fwd and dgrad)
     ((2, 64, 4, 8), 96, (4, 4), 2, 1, "reflect"),      # stride-2 dgrad classes sharing one split-K slab set
+    ((2, 8, 96, 96), 3, (3, 3), 1, 1, "reflect"),       # thin output (<= 4 channels, many pixels): vector-ALU kernels
+    ((1, 32, 128, 160), 1, (3, 3), 1, 1, "reflect"),
+    ((1, 6, 128, 144), 3, (7, 7), 1, 3, "zeros"),
+    ((1, 5, 3, 40, 160), 2, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
     ((2, 21, 16, 32), 64, (4, 4), 2, 1, "reflect"),
     ((1, 32, 16, 32), 1, (3, 3), 1, 1, "reflect"),
     ((5, 40, 4, 8), 40, (3, 3), 1, 1, "reflect"),
