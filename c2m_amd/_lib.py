@@ -12,7 +12,8 @@ _lib = None
 c_void_p, c_int, c_long, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
 _SIGS = {
-    "c2m_conv_igemm": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),
+    "c2m_conv_igemm": (c_int, [c_void_p] * 7 + [c_int, c_float, c_void_p]),
+    "c2m_reflect_border_add": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
     "c2m_conv_igemm_splits": (c_int, [c_int, c_int, c_int]),
     "c2m_splitk_reduce": (c_int, [c_void_p] * 3 + [c_long, c_int, c_long, c_int, c_int, c_float, c_void_p]),
     "c2m_conv_wgrad_splits": (c_int, [c_int, c_int, c_int]),

@@ -39,6 +39,11 @@ struct ConvP {
     long out_sn, out_sc, out_st, out_sh, out_sw, out_off;
     long slab_stride;    // elements between split slabs
     unsigned x_bytes;    // size of X in bytes (buffer-load bounds: out-of-range lanes read 0)
+    // optional second target (reflect-pad dgrad): outputs whose padded coordinate (o*ps + po) lies inside
+    // [lo, lo+ext) go straight to the unpadded gradient Y2, only the pad ring is written to Y
+    float* Y2;
+    int ps_t, ps_y, ps_x, po_t, po_y, po_x, lo_t, lo_y, lo_x, ext_t, ext_y, ext_x;
+    long y2_sn, y2_sc, y2_st, y2_sh;
     int ksteps_per_split;
     int reflect, is3d;
     int act;
@@ -242,6 +247,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         decompose_pix(pix, p, n, ot, oy, ox);
         float* __restrict__ yb = Yb + p.out_off + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
                                  (long)ox * p.out_sw;
+        long row_stride = p.out_sc;
+        if (p.Y2) {
+            const int tp = ot * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
+                      xp = ox * p.ps_x + p.po_x - p.lo_x;
+            if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+                yb = p.Y2 + (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                row_stride = p.y2_sc;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         if (p.bias) v += p.bias[row];
                         v = c2m_act(v, p.act, p.slope);
                     }
-                    yb[(long)row * p.out_sc] = v;
+                    yb[(long)row * row_stride] = v;
                 }
             }
         }
@@ -300,7 +314,7 @@ C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
     int BM, BN;
     igemm_tile(M, BM, BN);
     const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(Npix, BN);
-    if (tiles >= 1024 || nk < 8) return 1;
+    if (tiles >= 768 || nk < 8) return 1;
     long S = (1280 + tiles - 1) / tiles;
     if (S > nk / 4) S = nk / 4;
     if (S > 128) S = 128;
@@ -310,11 +324,15 @@ C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
 }
 
 // geom[] layout (int64): see include/c2m_hip.h
-C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
-                           const int64_t* g, int act, float slope, void* stream) {
+C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_interior, const float* bias,
+                           const int* ktab, const int64_t* g, int act, float slope, void* stream) {
     C2M_ENTER();
     ConvP p;
     p.A = A; p.X = X; p.Y = Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
+    p.Y2 = Y_interior;
+    p.ps_t = (int)g[36]; p.ps_y = (int)g[37]; p.ps_x = (int)g[38]; p.po_t = (int)g[39]; p.po_y = (int)g[40];
+    p.po_x = (int)g[41]; p.lo_t = (int)g[42]; p.lo_y = (int)g[43]; p.lo_x = (int)g[44]; p.ext_t = (int)g[45];
+    p.ext_y = (int)g[46]; p.ext_x = (int)g[47]; p.y2_sn = g[48]; p.y2_sc = g[49]; p.y2_st = g[50]; p.y2_sh = g[51];
     p.M = (int)g[0]; p.nk = (int)g[1]; p.lda = (int)g[2];
     p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
     p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
@@ -331,10 +349,11 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, const float
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.Npix <= 0) return 0;
     if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
+    if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;   // the two-target epilogue is a direct-store feature
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
     if (c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // a split would be empty
     hipStream_t s = (hipStream_t)stream;
-    if (p.M <= 4 && splits == 1 && p.Npix >= 16384) {      // thin output: vector-ALU kernel
+    if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2) {      // thin output: vector-ALU kernel
         if (ns == 1) return launch_thin_fwd<1>(p, s);
         if (ns == 2) return launch_thin_fwd<2>(p, s);
         return launch_thin_fwd<4>(p, s);
@@ -777,6 +796,38 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __rest
                 for (int c = 0; c < nx; ++c) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
         dX[idx] = acc;
     }
+}
+
+// In-place variant for the two-target dgrad: dX already holds the direct term, add the mirrored pad-ring terms
+// (only pixels within `pad` of a border have any).
+__global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
+    const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < f.total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % f.W); long r = idx / f.W;
+        const int y = (int)(r % f.H); r /= f.H;
+        const int t = (int)(r % f.T); const long nc = r / f.T;
+        int st[3], sy[3], sx[3];
+        const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy),
+                  nx = fold_sources(x, f.W, f.pw, sx);
+        if (nt * ny * nx == 1) continue;
+        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        float acc = 0.f;
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < ny; ++b)
+                for (int c = 0; c < nx; ++c)
+                    if (a + b + c > 0) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
+        dX[idx] += acc;
+    }
+}
+
+C2M_API int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
+                                   void* stream) {
+    C2M_ENTER();
+    FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
+    if (f.total <= 0) return 0;
+    hipLaunchKernelGGL(reflect_border_add_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dXpad, dX, f);
+    return (int)hipGetLastError();
 }
 
 C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,

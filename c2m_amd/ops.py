@@ -162,7 +162,7 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(36, dtype=np.int64)
+    g = np.zeros(52, dtype=np.int64)
     idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
                in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
                in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
@@ -261,6 +261,8 @@ class _ConvPlan:
                                  out_sc=Tp * Hp * Wp, out_st=st * Hp * Wp, out_sh=sh * Wp, out_sw=sw,
                                  out_off=offt * Hp * Wp + offy * Wp + offx, reflect=0, is3d=is3d, ns=16 // cck,
                                  in_sc=osp, splits=1, slab_stride=tgt_numel, x_bytes=4 * N * Cout * osp)
+                    # two-target epilogue (reflect): padded coord = q*stride + r per dim; interior = [pad, pad + extent)
+                    geom[36:52] = (st, sh, sw, offt, offy, offx, pt, ph, pw, Ti, Hi, Wi, Cin * in_sc, in_sc, Hi * Wi, Wi)
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
@@ -301,7 +303,7 @@ class _ConvFn(torch.autograd.Function):
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
+                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
                                                    ACT[act], LRELU_SLOPE, _stream()), tag), "conv_igemm fwd")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
@@ -322,13 +324,13 @@ class _ConvFn(torch.autograd.Function):
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            tgt = (torch.zeros if pl.dgrad_needs_zero else torch.empty)(pl.dgrad_target, device=x.device,
-                                                                        dtype=torch.float32)
             S = pl.dgrad_splits
-            dst = tgt
-            if S > 1:
-                dst = (torch.zeros if pl.dgrad_needs_zero else torch.empty)(S * tgt.numel(), device=x.device,
-                                                                            dtype=torch.float32)
+            folded = pl.reflect and any(pl.pad)
+            two_target = folded and S == 1 and not pl.dgrad_needs_zero
+            alloc = torch.zeros if pl.dgrad_needs_zero else torch.empty
+            tgt = alloc(pl.dgrad_target, device=x.device, dtype=torch.float32)
+            gx = torch.empty_like(x) if folded else tgt.view(x.shape)
+            dst = tgt if S == 1 else alloc(S * tgt.numel(), device=x.device, dtype=torch.float32)
             st, sh, sw = pl.stride
             w5 = w if pl.is3d else w.unsqueeze(2)
             for c in pl.classes:
@@ -337,18 +339,17 @@ class _ConvFn(torch.autograd.Function):
                 A = _pack_rows(wc, c["ck"])
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
                 _lib.check(_timed("igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
-                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), None, _p(c["tab"]), _gp(c["geom"]), 0,
-                                                           0.0, _stream()), tag), "conv_igemm dgrad")
+                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
+                                                           _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag),
+                           "conv_igemm dgrad")
             if S > 1:
                 _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
                            "splitk_reduce dgrad")
-            if pl.reflect and any(pl.pad):
-                gx = torch.empty_like(x)
+            if folded:
                 Ti, Hi, Wi = pl.dims[3:6]
-                _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2],
-                                              _stream()), "reflect_fold")
-            else:
-                gx = tgt.view(x.shape)
+                fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
+                _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
+                           "reflect fold")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)

@@ -37,10 +37,13 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  *   16 out_sn 17 out_sc 18 out_st 19 out_sh 20 out_sw 21 out_off   22 reflect (0 zeros / 1 reflect) 23 is3d
  *   24 NS (1, 2 or 4)   25 in_sc (channel stride)   26 splits (from c2m_conv_igemm_splits, or 1)
  *   27 slab_stride (elements between split-K slabs)   28 Cin 29 taps 30 tap groups per chunk 31 real groups (wgrad)
+ *   32 x_bytes 33 dy_bytes (wgrad)   36..51 two-target epilogue (reflect-pad dgrad, Y_interior != NULL): padded
+ *   coordinate = o*ps + po per dim (36-38 ps, 39-41 po); outputs inside [lo, lo+ext) (42-44 lo, 45-47 ext) are stored
+ *   to Y_interior with strides 48 sn 49 sc 50 st 51 sh, the pad ring to Y; c2m_reflect_border_add then folds the ring.
  * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
  * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
 int c2m_conv_igemm_splits(int M, int nk, int Npix);
-int c2m_conv_igemm(const float* A, const float* X, float* Y, const float* bias, const int* ktab,
+int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_interior, const float* bias, const int* ktab,
                    const int64_t* geom, int act, float slope, void* stream);
 int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits, long chan_stride,
                       int M, int act, float slope, void* stream);
@@ -54,7 +57,10 @@ int c2m_conv_wgrad_rows(int M, int ngroups);
 int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
                    const int64_t* geom, void* stream);
 
-/* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward). */
+/* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
+ * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
+int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
+                           void* stream);
 int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
                      void* stream);
 
