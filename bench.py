@@ -82,8 +82,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     args = ap.parse_args()
 
+    if "--force-reducer" in sys.argv:
+        os.environ["C2M_FORCE_PROCESS_GROUP"] = "1"
     rank, local_rank, world = init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -94,7 +98,8 @@ def main():
     model = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
                                model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
     model.to(dev).train()
-    step = TrainStep(model, run_optimizers=False, distributed=world > 1)
+    step = TrainStep(model, run_optimizers=False, distributed=world > 1 or args.force_reducer,
+                     force_collectives=args.force_reducer)
     batch = batch_to(make_batch(args.batch, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)
     batch["rng"] = {k: v.to(dev) for k, v in rng.items()}
@@ -159,7 +164,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -75,9 +75,10 @@ __device__ __forceinline__ void decompose_pix(int pix, const P& p, int& n, int& 
     ot = r % p.To;   n = r / p.To;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, int U>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
-    constexpr int BK = 16, CK = BK / NS;
+    // U = table K-steps (16 deep each) staged per barrier: U = 2 halves the barriers per MFMA at twice the LDS
+    constexpr int BK = 16, CK = BK / NS, BKU = BK * U;
     constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
     constexpr int LDA_S = BM + 4, LDB_S = BN;
     constexpr int BROWS = 256 / BN;           // k rows gathered per pass
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int A_F4 = BM * BK / 4;         // float4 loads per K-step (whole block)
     constexpr int APASS = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4 && BN >= 64 && CK % BROWS == 0, "tile");
-    __shared__ float sA[2][BK][LDA_S];
-    __shared__ float sB[2][BK][LDB_S];
+    __shared__ float sA[2][BKU][LDA_S];
+    __shared__ float sB[2][BKU][LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -102,7 +103,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         int pix = n0 + bp; pix = pix < p.Npix ? pix : p.Npix - 1;
         decompose_pix(pix, p, pn, pt, py, px);
     }
-    const float* __restrict__ Xn = p.X + (long)pn * p.in_sn;
     const int ots = pt * p.st, oys = py * p.sh, oxs = px * p.sw;
     const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
 
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[APASS];
-    float rb[BPASS];
+    float4 ra[U][APASS];
+    float rb[U][BPASS];
 
     // per-thread weight row pointers (fixed for the whole K loop)
     const float* __restrict__ aptr[APASS];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         int row = m0 + arow + s * 64; row = row < p.M ? row : p.M - 1;
         aptr[s] = p.A + (long)row * p.lda + akq;
     }
-    // gather table of the NEXT tile to load, fetched one K-step ahead (scalar loads: their latency must not sit in
+    // gather table of the NEXT K-step to load, fetched one step ahead (scalar loads: their latency must not sit in
     // front of the address arithmetic)
     int4 t_hdr, t_tap[NS];
     auto fetch_table = [&](int kt) {
@@ -143,17 +143,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     // lanes outside the image carry an out-of-range voffset and read 0 -- no per-element VALU at all.
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     const unsigned img_byte = (unsigned)(pn * (int)p.in_sn) * 4u;
-    auto load_tile = [&](int kt) {
+    // one 16-deep table step into register set u; kt >= kt_end (odd tail of a U = 2 pair) loads zeros
+    auto load_step = [&](int kt, float4 (&fa)[APASS], float (&fb)[BPASS]) {
+        const bool real = kt < kt_end;
 #pragma unroll
         for (int s = 0; s < APASS; ++s) {
-            if (A_F4 >= 256 || arow + s * 64 < BM) ra[s] = *reinterpret_cast<const float4*>(aptr[s] + kt * BK);
+            if (A_F4 >= 256 || arow + s * 64 < BM)
+                fa[s] = real ? *reinterpret_cast<const float4*>(aptr[s] + kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int4 hdr = t_hdr;
         unsigned vo[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int so = spatial_off(t_tap[q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
-            vo[q] = so >= 0 ? img_byte + (unsigned)so * 4u : C2M_OOB;
+            vo[q] = (real && so >= 0) ? img_byte + (unsigned)so * 4u : C2M_OOB;
         }
 #pragma unroll
         for (int s = 0; s < BPASS; ++s) {
@@ -161,33 +164,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
             const int cc = (s * BROWS) % CK + brow0;                  // wave-uniform
             // channels beyond nvalid only meet zero weights (A is zero-padded); they read in-range data or 0
             const int soff = (hdr.x + cc * p.in_sc) * 4;
-            rb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[slot], soff, 0));
+            fb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[slot], soff, 0));
         }
-        fetch_table(kt + 1 < p.nk ? kt + 1 : kt);
+        fetch_table(kt + 1 < p.nk ? kt + 1 : p.nk - 1);
+    };
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_step(kt + u, ra[u], rb[u]);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < APASS; ++s) {
-            int r = arow + s * 64;
-            if (A_F4 >= 256 || r < BM) {
-                sA[buf][akq + 0][r] = ra[s].x; sA[buf][akq + 1][r] = ra[s].y;
-                sA[buf][akq + 2][r] = ra[s].z; sA[buf][akq + 3][r] = ra[s].w;
-            }
-        }
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int s = 0; s < BPASS; ++s) sB[buf][brow0 + s * BROWS][bp] = rb[s];
+            for (int s = 0; s < APASS; ++s) {
+                int r = arow + s * 64;
+                if (A_F4 >= 256 || r < BM) {
+                    sA[buf][u * BK + akq + 0][r] = ra[u][s].x; sA[buf][u * BK + akq + 1][r] = ra[u][s].y;
+                    sA[buf][u * BK + akq + 2][r] = ra[u][s].z; sA[buf][u * BK + akq + 3][r] = ra[u][s].w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < BPASS; ++s) sB[buf][u * BK + brow0 + s * BROWS][bp] = rb[u][s];
+        }
     };
 
-#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 1
-    { const int bid = blockIdx.x + blockIdx.y * gridDim.x;
-      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
-#elif defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 2
-    { const int bid = (blockIdx.x + blockIdx.y * gridDim.x) >> 3;
-      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
-#elif defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 4
-    { const int bid = (blockIdx.x + blockIdx.y * gridDim.x) >> 8;
-      if (bid % 3 == 1) __builtin_amdgcn_s_setprio(1); else if (bid % 3 == 2) __builtin_amdgcn_s_setprio(2); }
-#endif
     if (kt_beg < kt_end) {
         fetch_table(kt_beg);
         load_tile(kt_beg);
@@ -195,42 +195,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
     __syncthreads();
     int cur = 0;
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-#ifndef C2M_IGEMM_READS_FIRST
-        if (more) load_tile(kt + 1);
-#endif
-        // all fragment reads of the K-step are issued first (own registers each), so the LDS latency of k-pair
+    for (int kt = kt_beg; kt < kt_end; kt += U) {
+        const bool more = kt + U < kt_end;
+        if (more) load_tile(kt + U);
+        // all fragment reads of a 16-deep step are issued first (own registers each), so the LDS latency of k-pair
         // kk+1.. hides behind the MFMAs of kk (the compiler otherwise recycles 4 VGPRs and serialises read -> mfma)
-        float a[BK / 2][MI], b[BK / 2][NI];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int krow = kk * 2 + (lane >> 5);
+        for (int u = 0; u < U; ++u) {
+            float a[BK / 2][MI], b[BK / 2][NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[kk][i] = sA[cur][krow][wm * TM + i * 32 + (lane & 31)];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int krow = u * BK + kk * 2 + (lane >> 5);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[kk][j] = sB[cur][krow][wn * TN + j * 32 + (lane & 31)];
+                for (int i = 0; i < MI; ++i) a[kk][i] = sA[cur][krow][wm * TM + i * 32 + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[kk][j] = sB[cur][krow][wn * TN + j * 32 + (lane & 31)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef C2M_IGEMM_READS_FIRST
-        if (more) load_tile(kt + 1);      // address arithmetic + global loads fill the LDS read latency
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 3
-        __builtin_amdgcn_s_setprio(0);    // MFMA phase: low priority, the load/LDS phases of other waves go first
-#endif
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#if defined(C2M_IGEMM_PRIO) && C2M_IGEMM_PRIO == 3
-        __builtin_amdgcn_s_setprio(2);
-#endif
         if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -288,13 +279,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 
 template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
 
+#ifndef C2M_IGEMM_U
+#define C2M_IGEMM_U 1
+#endif
+
 template <int BM, int BN, int WGM, int WGN>
 static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s) {
     dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits);
+    constexpr int U = (BM == 128) ? C2M_IGEMM_U : 1;
     switch (ns) {
-        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 2>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 4>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1, U>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 2, 1>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 4, 1>), grid, dim3(256), 0, s, p); break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();

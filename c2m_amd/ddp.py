@@ -33,9 +33,12 @@ class _Bucket:
 
 
 class GradientReducer:
-    def __init__(self, params, bucket_mb=25.0, process_group=None):
+    def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives: issue the all-reduces even in a 1-rank group (exercises the RCCL / side-stream path on a
+        # single GPU; used by the tests)
+        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
         params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in params:
@@ -104,7 +107,7 @@ class GradientReducer:
 
     def _launch(self, b):
         b.launched = True
-        if self.world == 1:
+        if not self.collectives:
             return
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -120,7 +123,7 @@ class GradientReducer:
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)
-        if self.on_gpu and self.world > 1:
+        if self.on_gpu and self.collectives:
             for b in self.buckets:
                 if b.work is not None:
                     b.work.wait()

@@ -16,13 +16,15 @@ def init_distributed():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("C2M_FORCE_PROCESS_GROUP")) and "MASTER_ADDR" in os.environ \
+            and not dist.is_initialized():
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     return int(os.environ.get("RANK", "0")), local_rank, world
 
 
 class TrainStep:
-    def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0):
+    def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0,
+                 force_collectives=False):
         self.c2m = c2m
         self.tp = c2m.train_params
         self.loss_weights = loss_weights or self.tp["loss_weights"]
@@ -33,7 +35,8 @@ class TrainStep:
         if self.tp["use_video_discriminator"]:
             self.optimizers.append(c2m.d_optimizer_video)
         distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
-        self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb) if distributed else None
+        self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb,
+                                       force_collectives=force_collectives) if distributed else None
 
     def zero_grad(self):
         if self.reducer is not None:
