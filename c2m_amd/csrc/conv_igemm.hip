@@ -44,6 +44,8 @@ struct ConvP {
     float* Y2;
     int ps_t, ps_y, ps_x, po_t, po_y, po_x, lo_t, lo_y, lo_x, ext_t, ext_y, ext_x;
     long y2_sn, y2_sc, y2_st, y2_sh;
+    // LDS-patch variant (3x3, stride 1): input origin of a tile = o + (iy0, ix0); per-tap offsets inside the patch
+    int iy0, ix0, pty[3], ptx[3], nchunks;
     int ksteps_per_split;
     int reflect, is3d;
     int act;
@@ -265,6 +267,187 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS patch
+// 3x3 stride-1 convolutions (forward and data gradient; >80 % of the step's conv FLOPs: VGG, SPADE MLPs, generator,
+// decoder): the input patch of a 16-channel chunk ((rows+2) x 34 pixels per channel) is staged in LDS ONCE and serves
+// all 9 taps -- the B fragments of every tap are read straight from the patch with a tap offset.  Compared with the
+// gather kernel there is no per-tap global gather and no per-tap LDS write of B at all; per 16-deep K-step only the
+// weight tile is loaded/stored.  Zero or reflect boundary is resolved while loading the patch.
+// Output tile = (BN/32) rows x 32 columns of one image, so each MFMA column block is one contiguous row segment.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
+    constexpr int BK = 16, TR = BN / 32, PH = TR + 2, PW = 34, PCH = PH * PW, PELEMS = BK * PCH;
+    constexpr int PLOADS = (PELEMS + 255) / 256;
+    constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
+    constexpr int LDA_S = BM + 4;
+    constexpr int A_F4 = BM * BK / 4, APASS = (A_F4 + 255) / 256;
+    static_assert(WGM * WGN == 4, "tile");
+    __shared__ float sA[2][BK][LDA_S];
+    __shared__ float sP[2][PELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.y * BM;
+    // tile -> (image, tile row, tile col)
+    const int tiles_x = (p.Wo + 31) / 32, tiles_y = (p.Ho + TR - 1) / TR;
+    int tb = blockIdx.x;
+    const int tx = tb % tiles_x; tb /= tiles_x;
+    const int ty = tb % tiles_y; const int img = tb / tiles_y;        // img = n*To + ot (2-D planes)
+    const int oy0 = ty * TR, ox0 = tx * 32;
+    const int n_img = img / p.To, t_img = img % p.To;
+
+    // ---- patch loads: this thread's PLOADS elements (fixed (channel, row, col) for the whole K loop)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const unsigned img_byte = (unsigned)(n_img * (int)p.in_sn + t_img * (int)p.in_st) * 4u;
+    unsigned pvo[PLOADS];
+#pragma unroll
+    for (int i = 0; i < PLOADS; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / PCH, r = (e % PCH) / PW, col = e % PW;
+        int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + col;
+        bool ok = e < PELEMS;
+        if (p.reflect) {
+            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+            ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;   // tiles hanging off the image
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        }
+        pvo[i] = ok ? img_byte + (unsigned)(c * p.in_sc + iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
+    }
+    float rp[PLOADS];
+    auto load_patch = [&](int chunk) {
+        const int soff = chunk * BK * p.in_sc * 4;
+#pragma unroll
+        for (int i = 0; i < PLOADS; ++i)
+            rp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvo[i], soff, 0));
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PLOADS; ++i) {
+            const int e = tid + i * 256;
+            if (e < PELEMS) sP[buf][e] = rp[i];
+        }
+    };
+
+    // ---- weight side (same packed K order as the gather kernel with CK = 16: (chunk, tap, channel))
+    const int akq = (tid & 3) * 4, arow = tid >> 2;
+    const float* __restrict__ aptr[APASS];
+#pragma unroll
+    for (int s = 0; s < APASS; ++s) {
+        int row = m0 + arow + s * 64; row = row < p.M ? row : p.M - 1;
+        aptr[s] = p.A + (long)row * p.lda + akq;
+    }
+    float4 ra[APASS];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int s = 0; s < APASS; ++s)
+            if (A_F4 >= 256 || arow + s * 64 < BM) ra[s] = *reinterpret_cast<const float4*>(aptr[s] + kt * BK);
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < APASS; ++s) {
+            const int r = arow + s * 64;
+            if (A_F4 >= 256 || r < BM) {
+                sA[buf][akq + 0][r] = ra[s].x; sA[buf][akq + 1][r] = ra[s].y;
+                sA[buf][akq + 2][r] = ra[s].z; sA[buf][akq + 3][r] = ra[s].w;
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B fragment base inside the patch: channel (lane>>5), tile row (wn*NI + j), column (lane&31)
+    int pbase[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pbase[j] = (lane >> 5) * PCH + (wn * NI + j) * PW + (lane & 31);
+
+    load_patch(0);
+    load_a(0);
+    store_patch(0);
+    store_a(0);
+    __syncthreads();
+    int cur = 0, pcur = 0;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const bool more_chunks = chunk + 1 < p.nchunks;
+        if (more_chunks) load_patch(chunk + 1);            // in flight across the 9 taps of this chunk
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kt = chunk * 9 + tap;
+            const bool more = tap < 8 || more_chunks;
+            if (more) load_a(kt + 1);
+            const int toff = p.pty[tap / 3] * PW + p.ptx[tap % 3];
+            float a[BK / 2][MI], b[BK / 2][NI];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int krow = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[kk][i] = sA[cur][krow][wm * TM + i * 32 + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[kk][j] = sP[pcur][pbase[j] + kk * 2 * PCH + toff];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) store_a(cur ^ 1);
+            if (tap == 8 && more_chunks) store_patch(pcur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+        pcur ^= 1;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int oy = oy0 + wn * NI + j, ox = ox0 + (lane & 31);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        float* __restrict__ yb = p.Y + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
+                                 (long)ox * p.out_sw;
+        long row_stride = p.out_sc;
+        if (p.Y2) {
+            const int tp = t_img * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
+                      xp = ox * p.ps_x + p.po_x - p.lo_x;
+            if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+                yb = p.Y2 + (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                row_stride = p.y2_sc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[row];
+                    yb[(long)row * row_stride] = c2m_act(v, p.act, p.slope);
+                }
+            }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_patch(const ConvP& p, hipStream_t s) {
+    constexpr int TR = BN / 32;
+    const long tiles = (long)(p.Npix / (p.Ho * p.Wo)) * ((p.Ho + TR - 1) / TR) * ((p.Wo + 31) / 32);
+    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM));
+    hipLaunchKernelGGL((conv_patch3x3_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
 // out[i] = act( sum_z slab[z][i] + bias[(i / chan_stride) % M] ), fixed order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                      const float* __restrict__ bias, long total, int S, long chan_stride, int M, int act,
@@ -349,6 +532,16 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
     if (c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // a split would be empty
     hipStream_t s = (hipStream_t)stream;
+    if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
+        if (ns != 1 || splits != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
+        p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
+        for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
+        p.nchunks = p.nk / 9;
+        if (p.nchunks * 9 != p.nk) return (int)hipErrorInvalidValue;
+        if (p.M <= 32)      return launch_patch<32, 256, 1, 4>(p, s);
+        else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, s);
+        else                return launch_patch<128, 128, 2, 2>(p, s);
+    }
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2) {      // thin output: vector-ALU kernel
         if (ns == 1) return launch_thin_fwd<1>(p, s);
         if (ns == 2) return launch_thin_fwd<2>(p, s);

@@ -123,6 +123,26 @@ def _choose_ck(C, taps):
     return best[1]
 
 
+def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
+    """LDS-patch kernel eligibility: 3x3 (kt = 1) stride-1, whole 16-channel chunks without much padding, a grid big
+    enough not to need split-K, output rows/cols that fill the (rows x 32) tile reasonably."""
+    kt, kh, kw = taps3
+    if (kt, kh, kw) != (1, 3, 3) or tuple(stride) != (1, 1, 1) or splits != 1:
+        return False
+    best = _ceil(C, _choose_ck(C, 9))
+    if _ceil(C, 16) > 1.10 * best:
+        return False
+    rows = 8 if M <= 32 else 4
+    return Wo >= 32 and Ho >= rows and (_ceil(Wo, 32) * _ceil(Ho, rows)) <= 1.15 * Wo * Ho
+
+
+def _set_patch(geom, iy0, ix0, pty, ptx):
+    geom[52] = 1
+    geom[53], geom[54] = iy0, ix0
+    geom[55:58] = pty
+    geom[58:61] = ptx
+
+
 def _tap_offsets(kt, kh, kw, off_t, off_y, off_x):
     """(dt, dy, dx) per tap in (t, y, x) row-major order."""
     return [(int(off_t[a]), int(off_y[b]), int(off_x[c])) for a in range(kt) for b in range(kh) for c in range(kw)]
@@ -162,7 +182,7 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(52, dtype=np.int64)
+    g = np.zeros(64, dtype=np.int64)
     idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
                in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
                in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
@@ -199,6 +219,12 @@ class _ConvPlan:
         in_sc, osp = Ti * Hi * Wi, To * Ho * Wo
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
+        self.fwd_patch = False
+        if (kt, kh, kw) == (1, 3, 3):
+            nk16 = _cdiv(Cin, 16) * 9
+            if _patch_ok(Cin, (kt, kh, kw), stride, L.c2m_conv_igemm_splits(Cout, nk16, N * To * Ho * Wo), Ho, Wo, Cout):
+                self.fwd_patch, self.ck = True, 16
+                ck = 16
         ns = 16 // ck
         offs = _tap_offsets(kt, kh, kw, np.arange(kt) - pt, np.arange(kh) - ph, np.arange(kw) - pw)
         tab, nch, ntg = _kstep_table(Cin, offs, in_sc, ck)
@@ -211,11 +237,14 @@ class _ConvPlan:
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
                               in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp,
                               x_bytes=4 * N * Cin * in_sc)
+        if self.fwd_patch:
+            _set_patch(self.fwd_geom, -ph, -pw, (0, 1, 2), (0, 1, 2))
         # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
         self.J = L.c2m_conv_wgrad_rows(Cout, nk + 1)
         wtab, _, _ = _kstep_table(Cin, offs, in_sc, ck, extra_groups=self.J // 16 - nk - 1, ones_group=True)
         self.wg_tab = torch.from_numpy(wtab.reshape(-1)).to(device)
         self.wg_geom = self.fwd_geom.copy()
+        self.wg_geom[52] = 0
         self.wg_geom[[0, 1, 16, 17]] = (Cout, self.J, Cout * osp, osp)
         self.wg_geom[[28, 29, 30, 31]] = (Cin, taps, ntg, nk)
         self.wg_geom[33] = 4 * N * Cout * osp
@@ -252,6 +281,11 @@ class _ConvPlan:
                 for (rx, Ax, qx, Qx, offx) in dim_classes(Wi, Wo, kw, sw, pw):
                     ctaps = At * Ay * Ax
                     cck = _choose_ck(Cout, ctaps)
+                    cpatch = False
+                    if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1):
+                        csp = L.c2m_conv_igemm_splits(Cin, _cdiv(Cout, 16) * 9, N * Qt * Qy * Qx)
+                        if _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), csp, Qy, Qx, Cin):
+                            cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
                     ctab, cnch, cntg = _kstep_table(Cout, coffs, osp, cck)
                     cnk = cnch * cntg
@@ -263,7 +297,9 @@ class _ConvPlan:
                                  in_sc=osp, splits=1, slab_stride=tgt_numel, x_bytes=4 * N * Cout * osp)
                     # two-target epilogue (reflect): padded coord = q*stride + r per dim; interior = [pad, pad + extent)
                     geom[36:52] = (st, sh, sw, offt, offy, offx, pt, ph, pw, Ti, Hi, Wi, Cin * in_sc, in_sc, Hi * Wi, Wi)
-                    self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix,
+                    if cpatch:
+                        _set_patch(geom, qy - 2, qx - 2, (2, 1, 0), (2, 1, 0))
+                    self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
         S = min(L.c2m_conv_igemm_splits(Cin, c["nk"], c["npix"]) for c in self.classes) if self.classes else 1
@@ -272,6 +308,8 @@ class _ConvPlan:
                 if _cdiv(c["nk"], _cdiv(c["nk"], S)) != S:
                     S = 1
                     break
+        if any(c["patch"] for c in self.classes):
+            S = 1
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
