@@ -39,6 +39,9 @@ CONV_CASES = [
     ((1, 32, 128, 160), 1, (3, 3), 1, 1, "reflect"),
     ((1, 6, 128, 144), 3, (7, 7), 1, 3, "zeros"),
     ((1, 5, 3, 40, 160), 2, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
+    ((2, 32, 20, 64), 48, (3, 3), 1, 1, "reflect"),      # LDS-patch kernel, 64-row tile, reflect patch loads
+    ((1, 48, 12, 96), 130, (3, 3), 1, 1, "zeros"),      # LDS-patch kernel, 128-row tiles, 3 channel chunks
+    ((1, 16, 128, 256), 16, (3, 3), 1, 1, "reflect"),   # patch dgrad over the padded 130x258 domain (partial tiles)
     ((2, 21, 16, 32), 64, (4, 4), 2, 1, "reflect"),
     ((1, 32, 16, 32), 1, (3, 3), 1, 1, "reflect"),
     ((5, 40, 4, 8), 40, (3, 3), 1, 1, "reflect"),
