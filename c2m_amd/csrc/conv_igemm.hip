@@ -368,14 +368,17 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) pbase[j] = (lane >> 5) * PCH + (wn * NI + j) * PW + (lane & 31);
 
-    load_patch(0);
-    load_a(0);
+    // split-K over whole channel chunks (gridDim.z); ksteps_per_split holds CHUNKS per split for this kernel
+    const int chunk_beg = blockIdx.z * p.ksteps_per_split;
+    int chunk_end = chunk_beg + p.ksteps_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
+    load_patch(chunk_beg);
+    load_a(chunk_beg * 9);
     store_patch(0);
     store_a(0);
     __syncthreads();
     int cur = 0, pcur = 0;
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const bool more_chunks = chunk + 1 < p.nchunks;
+    for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+        const bool more_chunks = chunk + 1 < chunk_end;
         if (more_chunks) load_patch(chunk + 1);            // in flight across the 9 taps of this chunk
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -410,11 +413,13 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     }
 
     // ---- epilogue
+    const bool direct = gridDim.z == 1;
+    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int oy = oy0 + wn * NI + j, ox = ox0 + (lane & 31);
         if (oy >= p.Ho || ox >= p.Wo) continue;
-        float* __restrict__ yb = p.Y + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
+        float* __restrict__ yb = Yb + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
                                  (long)ox * p.out_sw;
         long row_stride = p.out_sc;
         if (p.Y2) {
@@ -432,18 +437,21 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
                 const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < p.M) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[row];
-                    yb[(long)row * row_stride] = c2m_act(v, p.act, p.slope);
+                    if (direct) {
+                        if (p.bias) v += p.bias[row];
+                        v = c2m_act(v, p.act, p.slope);
+                    }
+                    yb[(long)row * row_stride] = v;
                 }
             }
     }
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_patch(const ConvP& p, hipStream_t s) {
+static int launch_patch(const ConvP& p, int splits, hipStream_t s) {
     constexpr int TR = BN / 32;
     const long tiles = (long)(p.Npix / (p.Ho * p.Wo)) * ((p.Ho + TR - 1) / TR) * ((p.Wo + 31) / 32);
-    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM));
+    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM), splits);
     hipLaunchKernelGGL((conv_patch3x3_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
@@ -530,17 +538,19 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
     if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;   // the two-target epilogue is a direct-store feature
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
-    if (c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // a split would be empty
+    if (!g[52] && c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // empty split
     hipStream_t s = (hipStream_t)stream;
     if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
-        if (ns != 1 || splits != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
+        if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
         p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
         for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
         p.nchunks = p.nk / 9;
         if (p.nchunks * 9 != p.nk) return (int)hipErrorInvalidValue;
-        if (p.M <= 32)      return launch_patch<32, 256, 1, 4>(p, s);
-        else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, s);
-        else                return launch_patch<128, 128, 2, 2>(p, s);
+        p.ksteps_per_split = c2m_cdiv(p.nchunks, splits);           // chunks per split
+        if (c2m_cdiv(p.nchunks, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;
+        if (p.M <= 32)      return launch_patch<32, 256, 1, 4>(p, splits, s);
+        else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, splits, s);
+        else                return launch_patch<128, 128, 2, 2>(p, splits, s);
     }
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2) {      // thin output: vector-ALU kernel
         if (ns == 1) return launch_thin_fwd<1>(p, s);

@@ -127,13 +127,20 @@ def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
     """LDS-patch kernel eligibility: 3x3 (kt = 1) stride-1, whole 16-channel chunks without much padding, a grid big
     enough not to need split-K, output rows/cols that fill the (rows x 32) tile reasonably."""
     kt, kh, kw = taps3
-    if (kt, kh, kw) != (1, 3, 3) or tuple(stride) != (1, 1, 1) or splits != 1:
+    if (kt, kh, kw) != (1, 3, 3) or tuple(stride) != (1, 1, 1):
         return False
     best = _ceil(C, _choose_ck(C, 9))
     if _ceil(C, 16) > 1.10 * best:
         return False
     rows = 8 if M <= 32 else 4
     return Wo >= 32 and Ho >= rows and (_ceil(Wo, 32) * _ceil(Ho, rows)) <= 1.15 * Wo * Ho
+
+
+def _patch_splits(L, M, C, npix):
+    """Split-K count for the patch kernel: whole 16-channel chunks per split, every split non-empty."""
+    nch = _cdiv(C, 16)
+    s0 = L.c2m_conv_igemm_splits(M, nch * 9, npix)
+    return _cdiv(nch, _cdiv(nch, s0))
 
 
 def _set_patch(geom, iy0, ix0, pty, ptx):
@@ -220,18 +227,17 @@ class _ConvPlan:
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
-        if (kt, kh, kw) == (1, 3, 3):
-            nk16 = _cdiv(Cin, 16) * 9
-            if _patch_ok(Cin, (kt, kh, kw), stride, L.c2m_conv_igemm_splits(Cout, nk16, N * To * Ho * Wo), Ho, Wo, Cout):
-                self.fwd_patch, self.ck = True, 16
-                ck = 16
+        if (kt, kh, kw) == (1, 3, 3) and _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout):
+            self.fwd_patch, self.ck = True, 16
+            ck = 16
         ns = 16 // ck
         offs = _tap_offsets(kt, kh, kw, np.arange(kt) - pt, np.arange(kh) - ph, np.arange(kw) - pw)
         tab, nch, ntg = _kstep_table(Cin, offs, in_sc, ck)
         nk = nch * ntg
         self.nk = nk
         self.fwd_tab = torch.from_numpy(tab.reshape(-1)).to(device)
-        self.fwd_splits = L.c2m_conv_igemm_splits(Cout, nk, N * osp)
+        self.fwd_splits = _patch_splits(L, Cout, Cin, N * osp) if self.fwd_patch else \
+            L.c2m_conv_igemm_splits(Cout, nk, N * osp)
         self.fwd_geom = _geom(M=Cout, nk=nk, lda=nk * 16, Npix=N * osp, To=To, Ho=Ho, Wo=Wo, Ti=Ti, Hi=Hi, Wi=Wi, st=st,
                               sh=sh, sw=sw, in_sn=Cin * in_sc, in_st=Hi * Wi, in_sh=Wi, out_sn=Cout * osp, out_sc=osp,
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
@@ -282,10 +288,9 @@ class _ConvPlan:
                     ctaps = At * Ay * Ax
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
-                    if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1):
-                        csp = L.c2m_conv_igemm_splits(Cin, _cdiv(Cout, 16) * 9, N * Qt * Qy * Qx)
-                        if _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), csp, Qy, Qx, Cin):
-                            cpatch, cck = True, 16
+                    if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
+                            _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, Cin):
+                        cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
                     ctab, cnch, cntg = _kstep_table(Cout, coffs, osp, cck)
                     cnk = cnch * cntg
@@ -308,8 +313,8 @@ class _ConvPlan:
                 if _cdiv(c["nk"], _cdiv(c["nk"], S)) != S:
                     S = 1
                     break
-        if any(c["patch"] for c in self.classes):
-            S = 1
+        if any(c["patch"] for c in self.classes):        # stride-1 3x3: a single class
+            S = _patch_splits(L, Cin, Cout, self.classes[0]["npix"])
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
