@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     constexpr int A_F4 = BM * BK / 4, APASS = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4, "tile");
     __shared__ float sA[2][BK][LDA_S];
-    __shared__ float sP[2][PELEMS];
+    __shared__ float sP[2][PLOADS * 256];      // filled by LDS-DMA: 64 consecutive floats per wave-instruction
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -315,19 +315,13 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
         }
         pvo[i] = ok ? img_byte + (unsigned)(c * p.in_sc + iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
     }
-    float rp[PLOADS];
-    auto load_patch = [&](int chunk) {
+    // global -> LDS directly (buffer_load ... lds): no staging registers, no ds_write pass; out-of-range lanes (pad
+    // pixels, the tail beyond PELEMS) read through the OOB offset and land as zeros.
+    auto load_patch = [&](int chunk, int buf) {
         const int soff = chunk * BK * p.in_sc * 4;
 #pragma unroll
         for (int i = 0; i < PLOADS; ++i)
-            rp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvo[i], soff, 0));
-    };
-    auto store_patch = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PLOADS; ++i) {
-            const int e = tid + i * 256;
-            if (e < PELEMS) sP[buf][e] = rp[i];
-        }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, &sP[buf][wave * 64 + i * 256], 4, pvo[i], soff, 0, 0);
     };
 
     // ---- weight side (same packed K order as the gather kernel with CK = 16: (chunk, tap, channel))
@@ -371,16 +365,19 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     // split-K over whole channel chunks (gridDim.z); ksteps_per_split holds CHUNKS per split for this kernel
     const int chunk_beg = blockIdx.z * p.ksteps_per_split;
     int chunk_end = chunk_beg + p.ksteps_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
-    load_patch(chunk_beg);
+    load_patch(chunk_beg, 0);
     load_a(chunk_beg * 9);
-    store_patch(0);
     store_a(0);
     __syncthreads();
     int cur = 0, pcur = 0;
     for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
         const bool more_chunks = chunk + 1 < chunk_end;
-        if (more_chunks) load_patch(chunk + 1);            // in flight across the 9 taps of this chunk
+        if (more_chunks) load_patch(chunk + 1, pcur ^ 1);  // the other buffer was last read before the previous barrier
+#ifdef C2M_PATCH_ROLLED
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int tap = 0; tap < 9; ++tap) {
             const int kt = chunk * 9 + tap;
             const bool more = tap < 8 || more_chunks;
@@ -405,7 +402,6 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (more) store_a(cur ^ 1);
-            if (tap == 8 && more_chunks) store_patch(pcur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
@@ -998,7 +994,7 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __rest
 }
 
 // In-place variant for the two-target dgrad: dX already holds the direct term, add the mirrored pad-ring terms
-// (only pixels within `pad` of a border have any).
+// (only pixels within `pad` of a border have any).  Generic form: every element looks for extra sources.
 __global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
     const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < f.total; idx += (long)gridDim.x * blockDim.x) {
@@ -1019,11 +1015,67 @@ __global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* 
     }
 }
 
+// Border-only form (every extent >= 2*pad + 2, so the low and high mirror bands are disjoint): enumerates just the
+// elements that have a mirrored source, as three disjoint ranges per (n,c) volume:
+//   R1  x in band,                      all y, all t        T * H * 2pw
+//   R2  x outside band, y in band,      all t               T * 2ph * (W - 2pw)
+//   R3  x, y outside their bands,       t in band           2pt * (H - 2ph) * (W - 2pw)
+// band(i) = [1, p] U [L-1-p, L-2]; the complement is {0} U [p+1, L-2-p] U {L-1}.
+__device__ __forceinline__ int band_index(int j, int L, int p) { return j < p ? 1 + j : L - 1 - 2 * p + j; }
+__device__ __forceinline__ int offband_index(int k, int L, int p) {
+    return k == 0 ? 0 : (k == L - 2 * p - 1 ? L - 1 : k + p);
+}
+
+__global__ void reflect_border_only_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f,
+                                           const int r1, const int r2, const int r3, const long NC) {
+    const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
+    const int per = r1 + r2 + r3;
+    const long total = NC * per;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long nc = idx / per;
+        int e = (int)(idx - nc * per);
+        int t, y, x;
+        if (e < r1) {
+            const int bw = 2 * f.pw;
+            x = band_index(e % bw, f.W, f.pw); e /= bw;
+            y = e % f.H; t = e / f.H;
+        } else if (e < r1 + r2) {
+            e -= r1;
+            const int ow = f.W - 2 * f.pw, bh = 2 * f.ph;
+            x = offband_index(e % ow, f.W, f.pw); e /= ow;
+            y = band_index(e % bh, f.H, f.ph); t = e / bh;
+        } else {
+            e -= r1 + r2;
+            const int ow = f.W - 2 * f.pw, oh = f.H - 2 * f.ph;
+            x = offband_index(e % ow, f.W, f.pw); e /= ow;
+            y = offband_index(e % oh, f.H, f.ph); t = band_index(e / oh, f.T, f.pt);
+        }
+        int st[3], sy[3], sx[3];
+        const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy),
+                  nx = fold_sources(x, f.W, f.pw, sx);
+        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        float acc = 0.f;
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < ny; ++b)
+                for (int c = 0; c < nx; ++c)
+                    if (a + b + c > 0) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
+        dX[(nc * f.T + t) * (long)f.H * f.W + (long)y * f.W + x] += acc;
+    }
+}
+
 C2M_API int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
                                    void* stream) {
     C2M_ENTER();
     FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
     if (f.total <= 0) return 0;
+    const bool roomy = (pt == 0 || T >= 2 * pt + 2) && (ph == 0 || H >= 2 * ph + 2) && (pw == 0 || W >= 2 * pw + 2);
+    const long per_l = (long)T * H * 2 * pw + (long)T * 2 * ph * (W - 2 * pw) + 2L * pt * (H - 2 * ph) * (W - 2 * pw);
+    if (roomy && per_l > 0 && per_l < (1L << 30)) {
+        const int r1 = T * H * 2 * pw, r2 = T * 2 * ph * (W - 2 * pw), r3 = 2 * pt * (H - 2 * ph) * (W - 2 * pw);
+        hipLaunchKernelGGL(reflect_border_only_kernel, dim3(c2m_grid(NC * per_l, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dXpad, dX, f, r1, r2, r3, NC);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(reflect_border_add_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
                        dXpad, dX, f);
     return (int)hipGetLastError();

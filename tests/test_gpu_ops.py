@@ -42,6 +42,7 @@ CONV_CASES = [
     ((2, 32, 20, 64), 48, (3, 3), 1, 1, "reflect"),      # LDS-patch kernel, 64-row tile, reflect patch loads
     ((1, 48, 12, 96), 130, (3, 3), 1, 1, "zeros"),      # LDS-patch kernel, 128-row tiles, 3 channel chunks
     ((1, 16, 128, 256), 16, (3, 3), 1, 1, "reflect"),   # patch dgrad over the padded 130x258 domain (partial tiles)
+    ((2, 160, 16, 32), 96, (3, 3), 1, 1, "zeros"),      # LDS-patch kernel with split-K over channel chunks (fwd + dgrad)
     ((2, 21, 16, 32), 64, (4, 4), 2, 1, "reflect"),
     ((1, 32, 16, 32), 1, (3, 3), 1, 1, "reflect"),
     ((5, 40, 4, 8), 40, (3, 3), 1, 1, "reflect"),
