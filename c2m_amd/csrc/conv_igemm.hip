@@ -497,8 +497,11 @@ C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
     int BM, BN;
     igemm_tile(M, BM, BN);
     const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(Npix, BN);
+#ifndef C2M_SPLIT_TARGET
+#define C2M_SPLIT_TARGET 1280
+#endif
     if (tiles >= 768 || nk < 8) return 1;
-    long S = (1280 + tiles - 1) / tiles;
+    long S = (C2M_SPLIT_TARGET + tiles - 1) / tiles;
     if (S > nk / 4) S = nk / 4;
     if (S > 128) S = 128;
     if (S < 2) return 1;
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     // scalar offset = row / channel offset (SALU): no per-element VALU
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    for (int pk = pbeg; pk < pend; pk += BK) {
+    auto issue_loads = [&](int pk) {
         const int pix = pk + lane;
         const bool live = pix < pend;
         int n, ot, oy, ox;
@@ -655,12 +658,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
                 }
             }
         }
+    };
+    // software pipeline (64- and 32-row tiles; +8..15 % measured): the gathers of K-step i+1 are in flight while the
+    // MFMAs of step i run.  The 128x128 tile gains nothing from it (2 blocks/CU already cover the latency) and would
+    // pay 32 more VGPRs, so it loads at the top of its own step.
+    constexpr bool PIPE = BM < 128;
+    issue_loads(pbeg);
+    for (int pk = pbeg; pk < pend; pk += BK) {
+        if (!PIPE && pk > pbeg) issue_loads(pk);
         __syncthreads();   // previous K-step's fragment reads are done
 #pragma unroll
         for (int s = 0; s < AROWS; ++s) sA[wave * AROWS + s][lane] = ra[s];
 #pragma unroll
         for (int s = 0; s < BROWSW; ++s) sB[wave * BROWSW + s][lane] = rb[s];
         __syncthreads();
+        if (PIPE && pk + BK < pend) issue_loads(pk + BK);
         // fragment reads in groups of 8 k-pairs issued ahead of their MFMAs (see the igemm kernel)
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
@@ -863,9 +875,12 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_kernel(const WgradP p, in
     }
 }
 
+#ifndef C2M_WG64_BN
+#define C2M_WG64_BN 128
+#endif
 static void wgrad_tile(int M, int& BM, int& BN) {
     if (M <= 32) { BM = 32; BN = 128; }
-    else if (M <= 64) { BM = 64; BN = 64; }
+    else if (M <= 64) { BM = 64; BN = C2M_WG64_BN; }
     else { BM = 128; BN = 128; }
 }
 
@@ -874,8 +889,16 @@ C2M_API int c2m_conv_wgrad_splits(int M, int J, int Npix) {
     int BM, BN;
     wgrad_tile(M, BM, BN);
     const long tiles = (long)c2m_cdiv(M, BM) * c2m_cdiv(J, BN);
+#ifdef C2M_WGRAD_OLD_SPLITS
     long S = (1024 + tiles - 1) / tiles;
     const long maxS = (Npix + 2047) / 2048;   // at least 2048 pixels per split
+#else
+    // One resident round: blocks <= CUs x blocks/CU (LDS-limited: 2 for the 128x128 tile, 3 otherwise), so no block
+    // is left to run alone after the others (a 1026-block grid on 512 slots costs a third round for 2 blocks).
+    const long slots = 256L * (BM == 128 ? 2 : 3);
+    long S = slots / tiles;
+    const long maxS = (Npix + 1023) / 1024;   // at least 1024 pixels (16 K-steps) per split
+#endif
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     return (int)S;
@@ -949,9 +972,9 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
         else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
         else              hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, s, p);
     } else {
-        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 1>), grid, dim3(256), 0, s, p);
-        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 2>), grid, dim3(256), 0, s, p);
-        else              hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, 4>), grid, dim3(256), 0, s, p);
+        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 1>), grid, dim3(256), 0, s, p);
+        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        else              hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 4>), grid, dim3(256), 0, s, p);
     }
     int rc = (int)hipGetLastError();
     if (rc) return rc;

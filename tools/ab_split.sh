@@ -1,0 +1,11 @@
+# A/B of split-K heuristics (fwd + dgrad) on ONE device
+set -e
+SHAPES=("40 512 16 32 512 3 1 1 zeros" "40 256 16 32 256 3 1 1 reflect" "40 128 32 64 128 3 1 1 reflect" "40 512 8 16 512 3 1 1 reflect" "40 128 32 64 256 4 2 1 reflect" "40 256 16 32 512 4 2 1 reflect" "40 64 64 128 128 4 2 1 reflect")
+for round in 1 2; do
+for v in "$@"; do
+  if [ "$v" = "default" ]; then unset C2M_AMD_LIB; else export C2M_AMD_LIB=$PWD/c2m_amd/lib/libc2m_hip_$v.so; fi
+  for s in "${SHAPES[@]}"; do
+    echo "[$v r$round] $s :: $(python tools/conv_microbench.py $s 8 all 2>/dev/null | grep -v wgrad | sed 's/(.igemm., //; s/, (1.*)//' | tr '\n' ' ')"
+  done
+done
+done
