@@ -50,6 +50,12 @@ struct ConvP {
     int reflect, is3d;
     int act;
     float slope;
+    // class batching (stride-s data gradient: the s^d parity classes share every dimension and differ only in
+    // weights, tap table and output origin): blockIdx.z = cls * splits + split
+    int ncls, splits, ktab_cls;       // ktab_cls: int4 entries per class table
+    long a_cls;                       // floats per class weight matrix
+    long out_off_c[8];
+    int po_c[8][3];
 };
 
 // spatial offset of one tap for this thread's pixel, or -1 when it falls in zero padding
@@ -94,7 +100,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kt_beg = blockIdx.z * p.ksteps_per_split;
+    const int cls = p.ncls > 1 ? (int)blockIdx.z / p.splits : 0;
+    const int split = p.ncls > 1 ? (int)blockIdx.z - cls * p.splits : (int)blockIdx.z;
+    const float* __restrict__ Acls = p.A + cls * p.a_cls;
+    const int4* __restrict__ ktab = p.ktab + cls * p.ktab_cls;
+    const int kt_beg = split * p.ksteps_per_split;
     int kt_end = kt_beg + p.ksteps_per_split; kt_end = kt_end < p.nk ? kt_end : p.nk;
 
     // ---- gather side: this thread owns one pixel column of the tile
@@ -128,13 +138,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
     for (int s = 0; s < APASS; ++s) {
         int row = m0 + arow + s * 64; row = row < p.M ? row : p.M - 1;
-        aptr[s] = p.A + (long)row * p.lda + akq;
+        aptr[s] = Acls + (long)row * p.lda + akq;
     }
     // gather table of the NEXT K-step to load, fetched one step ahead (scalar loads: their latency must not sit in
     // front of the address arithmetic)
     int4 t_hdr, t_tap[NS];
     auto fetch_table = [&](int kt) {
-        const int4* __restrict__ kd = p.ktab + (long)kt * (1 + NS);
+        const int4* __restrict__ kd = ktab + (long)kt * (1 + NS);
         t_hdr = kd[0];
 #pragma unroll
         for (int q = 0; q < NS; ++q) t_tap[q] = kd[1 + q];
@@ -230,20 +240,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 
     // ---- epilogue: acc[i][j][r] -> row m = ..(r&3)+8*(r>>2)+4*(lane>>5), col pix = ..(lane&31)
-    const bool direct = gridDim.z == 1;
-    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
+    const bool direct = p.splits == 1;
+    float* __restrict__ Yb = p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
+    const int po_t = p.po_c[cls][0], po_y = p.po_c[cls][1], po_x = p.po_c[cls][2];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int pix = n0 + wn * TN + j * 32 + (lane & 31);
         if (pix >= p.Npix) continue;
         int n, ot, oy, ox;
         decompose_pix(pix, p, n, ot, oy, ox);
-        float* __restrict__ yb = Yb + p.out_off + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
+        float* __restrict__ yb = Yb + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
                                  (long)ox * p.out_sw;
         long row_stride = p.out_sc;
         if (p.Y2) {
-            const int tp = ot * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
-                      xp = ox * p.ps_x + p.po_x - p.lo_x;
+            const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y,
+                      xp = ox * p.ps_x + po_x - p.lo_x;
             if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
                 yb = p.Y2 + (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
                 row_stride = p.y2_sc;
@@ -472,7 +483,7 @@ template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
 
 template <int BM, int BN, int WGM, int WGN>
 static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s) {
-    dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits);
+    dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits * p.ncls);
     constexpr int U = (BM == 128) ? C2M_IGEMM_U : 1;
     switch (ns) {
         case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1, U>), grid, dim3(256), 0, s, p); break;
@@ -538,6 +549,16 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;   // the two-target epilogue is a direct-store feature
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
     if (!g[52] && c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // empty split
+    p.splits = splits;
+    p.ncls = g[61] > 1 ? (int)g[61] : 1;
+    if (p.ncls > 8) return (int)hipErrorInvalidValue;
+    p.a_cls = g[62]; p.ktab_cls = (int)g[63];
+    p.out_off_c[0] = p.out_off; p.po_c[0][0] = p.po_t; p.po_c[0][1] = p.po_y; p.po_c[0][2] = p.po_x;
+    for (int c = 0; c < p.ncls && p.ncls > 1; ++c) {
+        p.out_off_c[c] = g[64 + c];
+        for (int d = 0; d < 3; ++d) p.po_c[c][d] = (int)g[72 + 3 * c + d];
+    }
+    if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;
     if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
         if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
@@ -551,7 +572,7 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, splits, s);
         else                return launch_patch<128, 128, 2, 2>(p, splits, s);
     }
-    if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2) {      // thin output: vector-ALU kernel
+    if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2 && p.ncls == 1) {      // thin output: vector-ALU kernel
         if (ns == 1) return launch_thin_fwd<1>(p, s);
         if (ns == 2) return launch_thin_fwd<2>(p, s);
         return launch_thin_fwd<4>(p, s);

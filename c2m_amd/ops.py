@@ -189,7 +189,7 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(64, dtype=np.int64)
+    g = np.zeros(96, dtype=np.int64)
     idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
                in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
                in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
@@ -318,6 +318,38 @@ class _ConvPlan:
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
+        # ---- class batching: the stride parity classes of a k % s == 0 conv share every dimension (same taps per
+        # class, same Q extents) and differ only in weights, tap table and output origin -> ONE launch
+        # (blockIdx.z = class), which fills the chip where a single class (1/s^d of the pixels) cannot
+        self.cls_batch = None
+        cl = self.classes
+        ncls = st * sh * sw
+        if 1 < ncls <= 8 and len(cl) == ncls and kt % st == 0 and kh % sh == 0 and kw % sw == 0 and \
+                not self.dgrad_needs_zero and not any(c["patch"] for c in cl) and \
+                len({(c["nk"], c["ck"], c["taps"]) for c in cl}) == 1:
+            key = lambda c: (c["npix"],) + tuple(int(v) for v in c["geom"][4:7])
+            runs, i = [], 0
+            while i < ncls:                       # maximal runs of consecutive classes with identical extents
+                j = i
+                while j + 1 < ncls and key(cl[j + 1]) == key(cl[i]):
+                    j += 1
+                runs.append((i, j + 1))
+                i = j + 1
+            nk0, ck0 = cl[0]["nk"], cl[0]["ck"]
+            SB = min(L.c2m_conv_igemm_splits(Cin, nk0, cl[a]["npix"] * (b - a)) for a, b in runs)
+            groups = []
+            for a, b in runs:
+                g = cl[a]["geom"].copy()
+                g[26] = SB
+                g[61], g[62], g[63] = b - a, Cin * nk0 * 16, nk0 * (1 + 16 // ck0)
+                for i in range(a, b):
+                    g[64 + i - a] = cl[i]["geom"][21]
+                    g[72 + 3 * (i - a):75 + 3 * (i - a)] = cl[i]["geom"][39:42]
+                groups.append(dict(geom=g, tab=torch.cat([c["tab"] for c in cl[a:b]]), ncls=b - a, first=a,
+                                   npix=cl[a]["npix"]))
+            if len(groups) < ncls:
+                self.cls_batch = dict(groups=groups, ncls=ncls, ck=ck0, taps=cl[0]["taps"], nk=nk0)
+                self.dgrad_splits = SB
 
 
 def _plan(x, w, stride, pad, reflect):
@@ -376,7 +408,20 @@ class _ConvFn(torch.autograd.Function):
             dst = tgt if S == 1 else alloc(S * tgt.numel(), device=x.device, dtype=torch.float32)
             st, sh, sw = pl.stride
             w5 = w if pl.is3d else w.unsqueeze(2)
-            for c in pl.classes:
+            cb = pl.cls_batch
+            if cb is not None:
+                kt, kh, kw = pl.dims[9:12]
+                wall = w5.reshape(Cout, Cin, kt // st, st, kh // sh, sh, kw // sw, sw).permute(3, 5, 7, 1, 0, 2, 4, 6)
+                A = _pack_rows(wall.reshape(cb["ncls"] * Cin, Cout, cb["taps"]), cb["ck"])
+                for grp in cb["groups"]:
+                    Ag = A[grp["first"] * Cin:]
+                    tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
+                           pl.reflect, S)
+                    _lib.check(_timed("igemm", 2.0 * Cin * Cout * cb["taps"] * grp["npix"] * grp["ncls"],
+                                      lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
+                                                               None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
+                                                               _stream()), tag), "conv_igemm dgrad (batched classes)")
+            for c in (pl.classes if cb is None else ()):
                 rt, ry, rx = c["r"]
                 wc = w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1)
                 A = _pack_rows(wc, c["ck"])

@@ -25,6 +25,7 @@ def g(t):
 CONV_CASES = [
     # (x shape, Cout, kernel, stride, pad, mode)
     ((2, 6, 12, 16), 8, (4, 4), 2, 1, "reflect"),
+    ((2, 6, 12, 16), 8, (4, 4), 2, 1, "zeros"),        # stride-2 dgrad: 4 parity classes batched into one launch
     ((2, 3, 10, 12), 4, (7, 7), 1, 3, "reflect"),
     ((1, 32, 9, 11), 3, (7, 7), 1, 3, "zeros"),
     ((2, 5, 9, 11), 7, (3, 3), 1, 1, "reflect"),
