@@ -1134,3 +1134,53 @@ C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int 
                        f);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// Native conv weights -> the kernels' K order in one pass (coalesced writes, gathered reads; weights sit in L2).
+//   out[r][((chunk * ntg + tg) * NS + slot) * CK + ch],  r = cls * M + m,  c = chunk*CK + ch,  tap = tg*NS + slot
+//   source element: w[m*s_m + c*s_c + ((at*st + rt)*KH + (ay*sh + ry))*KW + (ax*sw + rx)]
+//   with tap = (at, ay, ax) over (At, Ay, Ax) = (KT/st, KH/sh, KW/sw) and cls = (rt, ry, rx) over (st, sh, sw).
+// Forward: st = sh = sw = 1, s_m = C*taps, s_c = taps.  Data gradient (rows = input channels, K = output channels,
+// one class per stride parity): s_m = taps_full, s_c = M*taps_full.  Padding (c >= C or tap >= taps) is written as 0.
+struct PackP { int M, C, CK, NS, nch, ntg, At, Ay, Ax, st, sh, sw, KH, KW; long s_m, s_c, total; };
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, const PackP q) {
+    const int taps = q.At * q.Ay * q.Ax;
+    const int lda = q.nch * q.ntg * 16;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < q.total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % lda); const int r = (int)(i / lda);
+        const int ch = k % q.CK; int t = k / q.CK;
+        const int slot = t % q.NS; t /= q.NS;
+        const int tg = t % q.ntg; const int chunk = t / q.ntg;
+        const int c = chunk * q.CK + ch, tap = tg * q.NS + slot;
+        float v = 0.f;
+        if (c < q.C && tap < taps) {
+            const int m = r % q.M; int cls = r / q.M;
+            const int rx = cls % q.sw; cls /= q.sw;
+            const int ry = cls % q.sh; const int rt = cls / q.sh;
+            const int ax = tap % q.Ax; const int ay = (tap / q.Ax) % q.Ay; const int at = tap / (q.Ax * q.Ay);
+            v = w[m * q.s_m + c * q.s_c + ((long)(at * q.st + rt) * q.KH + (ay * q.sh + ry)) * q.KW + (ax * q.sw + rx)];
+        }
+        out[i] = v;
+    }
+}
+
+// g[]: 0 M, 1 C, 2 CK, 3 KT, 4 KH, 5 KW, 6 st, 7 sh, 8 sw, 9 s_m, 10 s_c;  out holds st*sh*sw * M rows of
+// ceil(C/CK) * ceil(taps/NS) * 16 floats (NS = 16/CK, taps = (KT/st)*(KH/sh)*(KW/sw)).
+C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void* stream) {
+    C2M_ENTER();
+    PackP q;
+    q.M = (int)g[0]; q.C = (int)g[1]; q.CK = (int)g[2];
+    const int KT = (int)g[3];
+    q.KH = (int)g[4]; q.KW = (int)g[5]; q.st = (int)g[6]; q.sh = (int)g[7]; q.sw = (int)g[8];
+    q.s_m = g[9]; q.s_c = g[10];
+    if (q.M <= 0 || q.C <= 0) return 0;
+    if ((q.CK != 4 && q.CK != 8 && q.CK != 16) || q.st < 1 || q.sh < 1 || q.sw < 1 || KT % q.st || q.KH % q.sh ||
+        q.KW % q.sw) return (int)hipErrorInvalidValue;
+    q.NS = 16 / q.CK;
+    q.At = KT / q.st; q.Ay = q.KH / q.sh; q.Ax = q.KW / q.sw;
+    q.nch = c2m_cdiv(q.C, q.CK); q.ntg = c2m_cdiv(q.At * q.Ay * q.Ax, q.NS);
+    q.total = (long)q.st * q.sh * q.sw * q.M * q.nch * q.ntg * 16;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(c2m_grid(q.total, 256)), dim3(256), 0, (hipStream_t)stream, w, out, q);
+    return (int)hipGetLastError();
+}

@@ -324,6 +324,9 @@ class _ConvPlan:
         self.cls_batch = None
         cl = self.classes
         ncls = st * sh * sw
+        self.classes_packable = len(cl) == ncls and kt % st == 0 and kh % sh == 0 and kw % sw == 0 and \
+            len({(c["ck"], c["taps"]) for c in cl}) == 1 and \
+            [c["r"] for c in cl] == [(a, b, c_) for a in range(st) for b in range(sh) for c_ in range(sw)]
         if 1 < ncls <= 8 and len(cl) == ncls and kt % st == 0 and kh % sh == 0 and kw % sw == 0 and \
                 not self.dgrad_needs_zero and not any(c["patch"] for c in cl) and \
                 len({(c["nk"], c["ck"], c["taps"]) for c in cl}) == 1:
@@ -364,6 +367,35 @@ def _gp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _pack_native(w, M, C, ck, kdims, stride, s_m, s_c):
+    """c2m_pack_weights: contiguous native weights -> [ncls*M, nk*16] packed rows (ncls = prod(stride))."""
+    kt, kh, kw = kdims
+    st, sh, sw = stride
+    ns = 16 // ck
+    taps = (kt // st) * (kh // sh) * (kw // sw)
+    out = torch.empty(st * sh * sw * M, _cdiv(C, ck) * _cdiv(taps, ns) * 16, device=w.device, dtype=torch.float32)
+    g = np.array([M, C, ck, kt, kh, kw, st, sh, sw, s_m, s_c], dtype=np.int64)
+    _lib.check(_lib.lib().c2m_pack_weights(_p(w), _p(out), _gp(g), _stream()), "pack_weights")
+    return out
+
+
+_frozen_pack_cache = {}
+
+
+def _packed(w, frozen, kind, build):
+    """Packed weight matrix; weights that take no gradient (the frozen VGG-19 of the perceptual loss) are packed once
+    and reused until the tensor is modified in place or replaced (data_ptr / _version are part of the key)."""
+    if not frozen:
+        return build()
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index, kind)
+    A = _frozen_pack_cache.get(key)
+    if A is None:
+        if len(_frozen_pack_cache) > 256:
+            _frozen_pack_cache.clear()
+        A = _frozen_pack_cache[key] = build()
+    return A
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, reflect, act):
@@ -372,7 +404,8 @@ class _ConvFn(torch.autograd.Function):
         pl = _plan(x, w, stride, pad, reflect)
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
-        A = _pack_rows(w.reshape(Cout, Cin, -1), pl.ck)
+        ctx.frozen_w = not ctx.needs_input_grad[1]
+        A = _packed(w, ctx.frozen_w, ("fwd", pl.ck), lambda: _pack_native(w, Cout, Cin, pl.ck, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
         S = pl.fwd_splits
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
@@ -411,8 +444,8 @@ class _ConvFn(torch.autograd.Function):
             cb = pl.cls_batch
             if cb is not None:
                 kt, kh, kw = pl.dims[9:12]
-                wall = w5.reshape(Cout, Cin, kt // st, st, kh // sh, sh, kw // sw, sw).permute(3, 5, 7, 1, 0, 2, 4, 6)
-                A = _pack_rows(wall.reshape(cb["ncls"] * Cin, Cout, cb["taps"]), cb["ck"])
+                A = _packed(w, ctx.frozen_w, ("dgrad-all", cb["ck"], pl.stride), lambda: _pack_native(
+                    w, Cin, Cout, cb["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
                 for grp in cb["groups"]:
                     Ag = A[grp["first"] * Cin:]
                     tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
@@ -421,10 +454,16 @@ class _ConvFn(torch.autograd.Function):
                                       lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
                                                                None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
                                                                _stream()), tag), "conv_igemm dgrad (batched classes)")
-            for c in (pl.classes if cb is None else ()):
+            kt, kh, kw = pl.dims[9:12]
+            Aall = None
+            if cb is None and pl.classes_packable:      # every parity class present, equal taps: one pack launch
+                Aall = _packed(w, ctx.frozen_w, ("dgrad-all", pl.classes[0]["ck"], pl.stride), lambda: _pack_native(
+                    w, Cin, Cout, pl.classes[0]["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
+            for ci, c in enumerate(pl.classes if cb is None else ()):
                 rt, ry, rx = c["r"]
-                wc = w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1)
-                A = _pack_rows(wc, c["ck"])
+                A = Aall[ci * Cin:] if Aall is not None else _packed(
+                    w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
+                        w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
                 _lib.check(_timed("igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,

@@ -57,6 +57,13 @@ int c2m_conv_wgrad_rows(int M, int ngroups);
 int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
                    const int64_t* geom, void* stream);
 
+/* Native conv weights ([Cout][Cin][kt][kh][kw]) -> the packed K order above, one launch; also the per-parity-class
+ * transposed matrices of the data gradient (rows = input channels), all classes stacked along the rows.
+ * g[]: 0 M rows per class, 1 C (K-side channels), 2 CK, 3 KT, 4 KH, 5 KW, 6 st, 7 sh, 8 sw (1,1,1 = forward),
+ *      9 row stride, 10 channel stride of the source (elements).  Replaces the reshape/permute/copy chain that
+ *      aten::convolution does internally on its weights (no reference line of its own).                          */
+int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stream);
+
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
 int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
