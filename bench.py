@@ -7,8 +7,9 @@ synthetic data + random-init weights, weak scaling over ranks with the mean-of-r
 A step = zero_grad + forward + backward (+ gradient all-reduce when N > 1); inputs are resident in HBM.
 
 One JSON line on rank 0.  Extra objects:
-  roofline     dominant kernel = conv_igemm_kernel (fp32 MFMA): algorithmic conv FLOPs / HIP-event time of those
-               launches, measured inside the timed steps on the launch stream; peak = 157.3 TFLOP/s fp32 matrix
+  roofline     dominant kernels = conv_igemm_kernel + conv_patch3x3_kernel (fp32 MFMA; forward and data-gradient
+               launches of c2m_conv_igemm): algorithmic conv FLOPs / HIP-event time of those launches, measured inside
+               the timed steps on the launch stream; peak = 157.3 TFLOP/s fp32 matrix
   cpu_baseline the CPU oracle (oracle/c2m_oracle.py, validated bit-exact against the reference) timed on this host
 """
 import argparse
@@ -141,13 +142,23 @@ def main():
     if rank == 0:
         if prof is not None:
             s = prof.summary()
-            ig = s.get("igemm", dict(launches=0, flops=0.0, ms=1e-9))
-            wg = s.get("wgrad", dict(launches=0, flops=0.0, ms=1e-9))
+            ig = s.get("igemm", dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
+            wg = s.get("wgrad", dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
+            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            # (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json); counters cannot be read from inside the process
+            traffic, traffic_src = None, None
+            tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tp) and (args.batch, args.height, args.width) == (8, 128, 256):
+                with open(tp) as f:
+                    traffic = json.load(f)["igemm"]["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
             ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad launches)",
+                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_patch3x3_kernel (c2m_conv_igemm fwd + dgrad launches)",
                 "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                 "launches_per_step": ig["launches"] // args.steps,
                 "avg_launch_us": round(1000.0 * ig["ms"] / max(ig["launches"], 1), 2),
                 "gflop_per_launch": round(ig["flops"] / max(ig["launches"], 1) / 1e9, 3),

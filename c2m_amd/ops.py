@@ -5,6 +5,7 @@ gfx950 kernels from libc2m_hip.so on torch's current HIP stream.  There is no CP
 not on a HIP device raises (the oracle in oracle/ is test infrastructure and is never imported from here).
 """
 import ctypes
+import weakref
 import math
 
 import numpy as np
@@ -46,7 +47,7 @@ class ConvProfiler:
     active = None
 
     def __init__(self):
-        self.records = []          # (kind, flops, start_event, end_event, tag)
+        self.records = []          # (kind, flops, start_event, end_event, tag, algorithmic bytes)
 
     def __enter__(self):
         ConvProfiler.active = self
@@ -58,10 +59,11 @@ class ConvProfiler:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1, _ in self.records:
-            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+        for kind, flops, e0, e1, _, nbytes in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -69,7 +71,7 @@ class ConvProfiler:
         """Per launch-shape totals: [(tag, launches, ms, TFLOP/s)] sorted by time."""
         torch.cuda.synchronize()
         agg = {}
-        for kind, flops, e0, e1, tag in self.records:
+        for kind, flops, e0, e1, tag, _ in self.records:
             d = agg.setdefault((kind,) + tuple(tag), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
@@ -78,7 +80,7 @@ class ConvProfiler:
         return sorted(rows, key=lambda r: -r[2])
 
 
-def _timed(kind, flops, fn, tag=()):
+def _timed(kind, flops, fn, tag=(), nbytes=0):
     prof = ConvProfiler.active
     if prof is None:
         return fn()
@@ -86,7 +88,7 @@ def _timed(kind, flops, fn, tag=()):
     e0.record()
     rc = fn()
     e1.record()
-    prof.records.append((kind, flops, e0, e1, tag))
+    prof.records.append((kind, flops, e0, e1, tag, nbytes))
     return rc
 
 
@@ -384,15 +386,18 @@ _frozen_pack_cache = {}
 
 def _packed(w, frozen, kind, build):
     """Packed weight matrix; weights that take no gradient (the frozen VGG-19 of the perceptual loss) are packed once
-    and reused until the tensor is modified in place or replaced (data_ptr / _version are part of the key)."""
+    and reused while the SAME tensor object is alive and unmodified (weak reference + _version: a new tensor that
+    happens to reuse a freed allocation never hits)."""
     if not frozen:
         return build()
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index, kind)
-    A = _frozen_pack_cache.get(key)
-    if A is None:
-        if len(_frozen_pack_cache) > 256:
-            _frozen_pack_cache.clear()
-        A = _frozen_pack_cache[key] = build()
+    key = (id(w), kind)
+    hit = _frozen_pack_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+        return hit[3]
+    if len(_frozen_pack_cache) > 512:
+        _frozen_pack_cache.clear()
+    A = build()
+    _frozen_pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), A)
     return A
 
 
@@ -412,7 +417,8 @@ class _ConvFn(torch.autograd.Function):
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                           lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
-                                                   ACT[act], LRELU_SLOPE, _stream()), tag), "conv_igemm fwd")
+                                                   ACT[act], LRELU_SLOPE, _stream()), tag,
+                          4 * (x.numel() + w.numel() + y.numel())), "conv_igemm fwd")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
                                            LRELU_SLOPE, _stream()), "splitk_reduce")
@@ -453,7 +459,10 @@ class _ConvFn(torch.autograd.Function):
                     _lib.check(_timed("igemm", 2.0 * Cin * Cout * cb["taps"] * grp["npix"] * grp["ncls"],
                                       lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
                                                                None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
-                                                               _stream()), tag), "conv_igemm dgrad (batched classes)")
+                                                               _stream()), tag,
+                                      4 * (gy.numel() * grp["ncls"] // cb["ncls"] + w.numel() +
+                                           x.numel() * grp["ncls"] // cb["ncls"])),
+                               "conv_igemm dgrad (batched classes)")
             kt, kh, kw = pl.dims[9:12]
             Aall = None
             if cb is None and pl.classes_packable:      # every parity class present, equal taps: one pack launch
@@ -467,8 +476,8 @@ class _ConvFn(torch.autograd.Function):
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
                 _lib.check(_timed("igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
-                                                           _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag),
-                           "conv_igemm dgrad")
+                                                           _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
+                                  4 * (gy.numel() + w.numel() + x.numel()) // len(pl.classes)), "conv_igemm dgrad")
             if S > 1:
                 _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
                            "splitk_reduce dgrad")
@@ -484,7 +493,8 @@ class _ConvFn(torch.autograd.Function):
             tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
             _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
-                                                       _gp(pl.wg_geom), _stream()), tag), "conv_wgrad")
+                                                       _gp(pl.wg_geom), _stream()), tag,
+                              4 * (gy.numel() + x.numel() + w.numel())), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
         return gx, gw, gb, None, None, None, None
 

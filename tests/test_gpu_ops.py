@@ -98,6 +98,58 @@ def test_conv_fwd_bwd(case, act):
     rel_close(bg.grad, br.grad, 1e-4, "conv bias grad")
 
 
+def test_conv_stride2_fuzz():
+    """Random small stride-2 layers (the tiny e2e fixtures live here): batched parity classes, split-K, thin rows."""
+    rs = np.random.RandomState(7)
+    for it in range(40):
+        three_d = it % 4 == 3
+        cin, cout = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+        h, w_ = int(rs.randint(2, 11)) * 2, int(rs.randint(2, 11)) * 2
+        n = int(rs.randint(1, 4))
+        mode = "reflect" if it % 2 == 0 else "zeros"
+        if three_d:
+            t = int(rs.randint(2, 6))
+            kt = int(rs.choice([3, 4]))
+            xs, k, stride, pad = (n, cin, t, h, w_), (kt, 4, 4), ((2 if kt == 4 else 1), 2, 2), (1, 1, 1)
+            if kt == 4 and t < 2:
+                continue
+        else:
+            xs, k, stride, pad = (n, cin, h, w_), (4, 4), 2, 1
+        x = rnd(1000 + it, *xs)
+        w = rnd(2000 + it, cout, cin, *k, scale=(1.0 / (cin * int(np.prod(k))) ** 0.5))
+        b = rnd(3000 + it, cout, scale=0.1)
+        xr, wr, br = (t_.clone().requires_grad_(True) for t_ in (x, w, b))
+        yr = _ref_conv(xr, wr, br, stride, pad, mode, None)
+        go = rnd(4000 + it, *yr.shape)
+        (yr * go).sum().backward()
+        xg, wg, bg = (g(t_).requires_grad_(True) for t_ in (x, w, b))
+        y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
+        (y * g(go)).sum().backward()
+        what = f"case {it}: x{xs} cout {cout} k{k} s{stride} {mode}"
+        rel_close(y, yr, 2e-5, what + " fwd")
+        rel_close(xg.grad, xr.grad, 5e-5, what + " dgrad")
+        rel_close(wg.grad, wr.grad, 1e-4, what + " wgrad")
+        rel_close(bg.grad, br.grad, 1e-4, what + " bias grad")
+
+
+def test_conv_frozen_weight_pack_cache():
+    """Frozen weights (VGG) are packed once; an in-place update or a new tensor in the same allocation must miss."""
+    x = g(rnd(1, 2, 16, 8, 32))
+    w = g(rnd(2, 16, 16, 3, 3, scale=0.1))
+    ops._frozen_pack_cache.clear()
+    y1 = ops.conv(x, w, None, stride=1, padding=1)
+    n1 = len(ops._frozen_pack_cache)
+    y2 = ops.conv(x, w, None, stride=1, padding=1)
+    assert n1 == 1 and len(ops._frozen_pack_cache) == 1 and torch.equal(y1, y2)
+    w.mul_(2.0)                                   # _version bump -> repack
+    close(ops.conv(x, w, None, stride=1, padding=1), 2.0 * y1, 1e-6, 1e-6, "in-place update")
+    ptr = w.data_ptr()
+    del w
+    w2 = g(rnd(3, 16, 16, 3, 3, scale=0.1))       # usually lands in the freed block
+    yr = F.conv2d(x, w2, padding=1)
+    rel_close(ops.conv(x, w2, None, stride=1, padding=1), yr, 2e-5, f"new tensor (same ptr: {w2.data_ptr() == ptr})")
+
+
 def test_conv_big_wgrad_splitk():
     """Many pixels, few channels: exercises the split-K slabs + fixed-order reduction."""
     x, w = rnd(1, 4, 8, 64, 128), rnd(2, 16, 8, 3, 3, scale=0.1)
