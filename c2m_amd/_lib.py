@@ -21,6 +21,8 @@ _SIGS = {
     "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
     "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
     "c2m_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "c2m_adam_chunk": (c_int, []),
+    "c2m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_double] * 5 + [c_void_p]),
     "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),
     "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_void_p]),
     "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .. import ops
+from ..optim import Adam
 from ..utils import utils as U
 from ..losses import losses
 from .appearance_encoder.appearance_encoder import AppearanceEncoder
@@ -52,7 +53,8 @@ class GeneratorFullModel(nn.Module):
         if is_inference:
             return
         self.objective_func = losses.TrainingLosses(tp, mp)
-        adam = functools.partial(optim.Adam, betas=(tp["beta1"], tp["beta2"]), eps=float(tp["eps"]))
+        # torch.optim.Adam state layout / schedulers, stepped by the HIP multi-tensor kernel (c2m_amd/optim.py)
+        adam = functools.partial(Adam, betas=(tp["beta1"], tp["beta2"]), eps=float(tp["eps"]))
         milestones = list(range(tp["milestone_start"], tp["milestone_end"], tp["milestone_every"]))
         sched = functools.partial(torch.optim.lr_scheduler.MultiStepLR, milestones=milestones)
         self.model_parameters = list(self.appearance_encoder.parameters()) + \

@@ -128,6 +128,16 @@ int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int
 int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,
                  void* stream);
 
+/* ---- optimizer (optim.hip): SURVEY §8f-1 --------------------------------------------------------------------
+ * The four torch.optim.Adam(betas=(0.5,0.999), eps=1e-7) of modules/model.py:54-99, stepped at trainer/trainer.py:155-165:
+ * one launch per parameter group.  table = device int64 [4][ntensors] {param, grad, exp_avg, exp_avg_sq} pointers,
+ * sizes = device int64 [ntensors], blockmap = device int32 [nblocks][2] (tensor, chunk of c2m_adam_chunk() elements).
+ * step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) are computed by the caller in double,
+ * exactly as ATen's single-tensor Adam does; the kernel mirrors its fp32 operation order.                         */
+int c2m_adam_chunk(void);
+int c2m_adam_step(const int64_t* table, const int64_t* sizes, const int32_t* blockmap, int ntensors, int nblocks,
+                  double beta1, double beta2, double eps, double step_size, double bias_correction2_sqrt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,153 @@
+"""GPU parity of the multi-tensor Adam kernel and of whole training steps WITH the optimizers.
+
+Oracle: oracle/adam.py (pinned against the live torch.optim.Adam on CPU in tests/test_oracle_golden.py).  Tolerance:
+fp32, every operation mirrored -> parameters and both moments within 2 ulp (rtol 3e-7) of the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from c2m_amd.optim import Adam
+from c2m_amd.config import default_config, normalize_config
+from c2m_amd.modules.model import GeneratorFullModel
+from c2m_amd.synthetic import make_batch, make_step_rng, batch_to
+from c2m_amd.train import TrainStep
+from oracle import c2m_oracle as O
+from oracle.adam import adam_step, AdamState, multistep_lr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SHAPES = [(1,), (3,), (7, 5), (4096,), (4097,), (64, 32, 3, 3), (8191,), (300000,), (512, 512, 3, 3)]
+
+
+def test_adam_kernel_vs_oracle_with_multistep_lr():
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in SHAPES]
+    opt = Adam(ps, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.1)
+    mine = [p.detach().cpu().numpy().copy() for p in ps]
+    sts = [AdamState() for _ in ps]
+    for it in range(6):
+        gs = [torch.randn(s) * 10.0 ** (-2 * it) for s in SHAPES]
+        for p, g in zip(ps, gs):
+            p.grad = g.to(DEV)
+        if it == 3:
+            ps[1].grad = None                      # a parameter that skips a step keeps its own step count
+        opt.step()
+        lr = multistep_lr(2e-4, 0.1, [2, 4], it)
+        for i, (a, g, st) in enumerate(zip(mine, gs, sts)):
+            if it == 3 and i == 1:
+                continue
+            adam_step(a, g.numpy(), st, lr, 0.5, 0.999, 1e-7)
+        sch.step()
+        torch.cuda.synchronize()
+        for a, p, st in zip(mine, ps, sts):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), a, rtol=3e-7, atol=0, err_msg=f"param step {it}")
+            np.testing.assert_allclose(opt.state[p]["exp_avg"].cpu().numpy(), st.exp_avg, rtol=3e-7, atol=1e-45)
+            np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), st.exp_avg_sq, rtol=3e-7, atol=1e-45)
+            assert float(opt.state[p]["step"]) == st.step
+
+
+def test_adam_state_dict_exchanges_with_torch_adam():
+    """Checkpoints: the state_dict written by our Adam loads into torch.optim.Adam and back (reference trainer.py:117-136)."""
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in SHAPES[:5]]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours = Adam(ps, lr=1e-3, betas=(0.5, 0.999), eps=1e-7)
+    theirs = torch.optim.Adam(qs, lr=1e-3, betas=(0.5, 0.999), eps=1e-7, foreach=False)
+    for it in range(3):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g, g.clone()
+        if it == 1:                                  # swap optimizers' states through state_dict mid-run
+            sd_o, sd_t = copy.deepcopy(ours.state_dict()), copy.deepcopy(theirs.state_dict())
+            ours.load_state_dict(sd_t)
+            theirs.load_state_dict(sd_o)
+        ours.step()
+        theirs.step()
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
+
+
+def _tiny_cfg():
+    cfg = normalize_config(default_config(num_input_frames=2, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
+                                          out_channel=16, ndf=4, use_spade=True, use_image_discriminator=True,
+                                          use_video_discriminator=True))
+    cfg["train_params"]["use_gt_training"] = True
+    return cfg
+
+
+def test_two_full_steps_with_optimizers_vs_oracle():
+    """Full adversarial step (G + both D, 4 Adam steps) twice: product vs oracle forward/backward + oracle Adam.
+    The first update is sign-like (Adam's m/sqrt(v) = g/|g| at t = 1), so parameters whose gradient is rounding noise
+    may move by up to 2*lr in either implementation: compared norm-wise per tensor, and through the step-2 losses."""
+    cfg = _tiny_cfg()
+    tp = cfg["train_params"]
+    torch.manual_seed(0)
+    model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
+                               dataset="cityscapes")
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    step = TrainStep(model, run_optimizers=True, distributed=False)
+    groups = {"g": (step.optimizers[0], tp["lr_rate_g"]), "gnn": (step.optimizers[1], tp["lr_rate_gnn"]),
+              "di": (step.optimizers[2], tp["lr_rate_d"]), "dv": (step.optimizers[3], tp["lr_rate_d"])}
+    names = {id(p): k for k, p in model.named_parameters()}
+    S = O.State(sd0)
+    ostate = {}
+    batches = [make_batch(2, 128, 256, 2, seed=s) for s in (11, 12)]
+    losses_p, losses_o = [], []
+    for it, batch in enumerate(batches):
+        rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=it)   # widths of the tiny config (z_dim 16)
+        gb = batch_to(batch, DEV)
+        gb["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+        _, lg, _ = step(gb)
+        losses_p.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in lg.items()})
+        ob = dict(batch)
+        ob["tracking_gnn"] = batch["tracking_gnn"].clone()
+        for v in S.t.values():
+            v.grad = None
+        _, olg, oldi, oldv = O.forward(S, cfg, ob, rng)
+        O.train_step_backward(cfg, olg, oldi, oldv)
+        losses_o.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in olg.items()})
+        with torch.no_grad():
+            for gname, (opt, lr) in groups.items():
+                for p in opt.param_groups[0]["params"]:
+                    k = names[id(p)]
+                    t = S.t[k]
+                    if t.grad is None:
+                        continue
+                    st = ostate.setdefault((gname, k), AdamState())
+                    arr = t.detach().numpy()
+                    adam_step(arr, t.grad.numpy(), st, lr, tp["beta1"], tp["beta2"], float(tp["eps"]))
+    torch.cuda.synchronize()
+    for k in losses_o[0]:
+        assert abs(losses_p[0][k] - losses_o[0][k]) <= 2e-4 * abs(losses_o[0][k]) + 1e-6, f"step 1 loss {k}"
+    for k in losses_o[1]:      # after one update of every parameter
+        assert abs(losses_p[1][k] - losses_o[1][k]) <= 5e-3 * abs(losses_o[1][k]) + 1e-5, \
+            f"step 2 loss {k}: {losses_p[1][k]} vs {losses_o[1][k]}"
+    # Adam's first update is lr * g / (|g| + eps'): its size does not depend on |g|, so an element whose gradient is
+    # within the fp32 noise of zero (conv biases in front of a norm: analytically zero) moves by +-lr in a direction
+    # that is pure rounding.  Those tensors are only required to stay within 2*lr of the start; the others are compared
+    # norm-wise (a few sign flips of near-zero elements per tensor remain: each contributes 2*lr).
+    grads = S.grads()
+    per_elem = sorted(float(g.abs().sum()) / g.numel() for g in grads.values())
+    noise = 1e-3 * per_elem[len(per_elem) // 2]
+    lr_max = max(lr for _, lr in groups.values())
+    worst = []
+    for k, p in model.named_parameters():
+        ref, start = S.t[k].detach(), sd0[k]
+        d_ref = (ref - start).double()
+        if float(d_ref.norm()) == 0.0:
+            assert torch.equal(p.detach().cpu(), start), f"{k} must not move (no gradient)"
+            continue
+        got = p.detach().cpu()
+        assert float((got - start).abs().max()) <= 2.0 * 2 * lr_max * 1.001, f"{k}: update larger than 2 Adam steps"
+        if float(grads[k].abs().sum()) / grads[k].numel() < noise:
+            continue
+        err = float((got.double() - ref.double()).norm() / d_ref.norm())
+        worst.append((err, k))
+    worst.sort(reverse=True)
+    med = worst[len(worst) // 2][0]
+    assert len(worst) > 250 and med < 0.1 and worst[len(worst) // 10][0] < 0.3, \
+        f"update mismatch: median {med:.2e}, p90 {worst[len(worst) // 10]}, worst {worst[:3]}"

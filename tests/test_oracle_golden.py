@@ -307,3 +307,36 @@ def test_c_oracle_fma_mode_is_pinned():
                              _ptr(np.zeros(4 * H * W, np.float32)), B, K, T, H, W, m)
         res[m] = int((binm != c.mask("sparse_motion_bin").numpy()).sum())
     assert res[7] == 0 and res[0] > 0, res
+
+
+def test_oracle_adam_matches_torch():
+    """oracle/adam.py against the live third-party implementation (torch.optim.Adam, single-tensor CPU path), with the
+    reference's hyper-parameters (model.py:54-99: betas (0.5, 0.999), eps 1e-7) and a MultiStepLR schedule."""
+    import numpy as np
+    from oracle.adam import adam_step, AdamState, multistep_lr
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (4097,), (64, 3, 3, 3), (1,)]
+    tp = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = torch.optim.Adam(tp, lr=2e-4, betas=(0.5, 0.999), eps=1e-7, foreach=False)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.1)
+    mine = [p.detach().numpy().copy() for p in tp]
+    sts = [AdamState() for _ in tp]
+    for it in range(6):
+        gs = [torch.randn(s) * 10.0 ** (-2 * it) for s in shapes]      # down to 1e-10: eps-dominated updates
+        for p, g in zip(tp, gs):
+            p.grad = g.clone()
+        opt.step()
+        lr = multistep_lr(2e-4, 0.1, [2, 4], it)
+        assert abs(lr - opt.param_groups[0]["lr"]) < 1e-18
+        for a, g, st in zip(mine, gs, sts):
+            adam_step(a, g.numpy(), st, lr, 0.5, 0.999, 1e-7)
+        sch.step()
+        bad = total = 0
+        for a, p, st in zip(mine, tp, sts):
+            ref = p.detach().numpy()
+            np.testing.assert_allclose(a, ref, rtol=2e-7, atol=0)
+            np.testing.assert_array_equal(st.exp_avg, opt.state[p]["exp_avg"].numpy())
+            np.testing.assert_array_equal(st.exp_avg_sq, opt.state[p]["exp_avg_sq"].numpy())
+            bad += int((a != ref).sum())
+            total += a.size
+        assert bad <= max(1, total // 2000), f"step {it}: {bad} of {total} parameters differ in the last bit"
