@@ -441,6 +441,34 @@ def dense_motion_network(S, cfg, app, mi, rng, training=True, p="motion_encoder"
     return out
 
 
+def dense_motion_inference(S, cfg, app, mi, training=False, p="motion_encoder"):
+    """motion_estimator/dense_motion.py:236-271 (inference, use_fw_of False): no VAE encoders, z_m and the click index come
+    from the caller, the GNN runs in eval mode (model.py:249), thetas are chosen by use_gt_eval."""
+    tp, cp = cfg["train_params"], cfg["model_params"]["common_params"]
+    t_in, T = tp["num_input_frames"], tp["num_predicted_frames"]
+    ap = cfg["model_params"]["appearance_encoder"]
+    sf = cp["scale_factor"]
+    h_app = int(tp["input_size"][0] / 2 ** ap["num_down_blocks"] * sf)
+    w_app = int(tp["input_size"][1] / 2 ** ap["num_down_blocks"] * sf)
+    thetas = sparse_motion_generator(S, cfg, mi["tracking_gnn"], app["objects_feature"], mi["latent"],
+                                     mi["click_index"], training=False)
+    out = dict(thetas)
+    sparse = generate_sparse_motion(cfg, mi["tracking_gnn"], thetas, mi["instance"][:, :, t_in - 1].float(),
+                                    tp["use_gt_eval"])
+    sparse_feats = sparse_feature_encoder(S, cfg, sparse["sparse_motion_bw"], training)
+    code = torch.cat([linear(S, p + ".fc", mi["z_m"]).view(-1, 64, h_app, w_app), app["app_encoded"]], 1)
+    code = same_block_two_conv2d(S, p + ".zconv", code, "reflect")
+    codex = app["app_encoded"].unsqueeze(2).repeat(1, 1, T, 1, 1)
+    code = torch.cat(torch.chunk(code.unsqueeze(2), T, 1), 2)
+    z = torch.cat([codex, code], 1)
+    flow, occ = dense_motion_decoder(S, p + ".dense_generator_bw", cfg, app, sparse_feats,
+                                     sparse["sparse_motion_bw"], sparse["sparse_occ_bw"], z, training)
+    out.update({k: v for k, v in sparse.items() if not k.startswith("_")})
+    out["dense_motion_bw"], out["occlusion_bw"] = flow, occ
+    out["index_user_guidance"] = mi["click_index"]
+    return out
+
+
 def flow_embedder(S, p, cfg, x, training=True):
     """generator/flowembedder.py:47-81 (use_decoder True)."""
     fp = cfg["model_params"]["flow_embedder"]
@@ -671,6 +699,35 @@ def forward(S, cfg, batch, rng, training=True):
         loss_g["g_gan_video"], loss_g["feature_matching_video"] = gg, fm
         loss_d_vid = {"d_real": dr, "d_fake": df}
     return out, loss_g, loss_d_img, loss_d_vid
+
+
+def inference(S, cfg, batch, rng, z_m, training=False):
+    """modules/model.py:241-324 GeneratorFullModel.inference: encoder input as in forward, dense_motion.inference, the
+    generator on the last input frame, and the two sparse-flow visualisation warps.  `training` is the module mode the
+    caller left the model in (trainer.py:201-208 calls it under c2m.eval() + no_grad)."""
+    tp = cfg["train_params"]
+    t_in, T = tp["num_input_frames"], tp["num_predicted_frames"]
+    frames, bg, fg = batch["video"], batch["bg_mask"], batch["fg_mask"]
+    instance = batch["instance_mask"].float().int()
+    input_of, input_occ = batch.get("input_of"), batch.get("input_occ")
+    gnn = batch["tracking_gnn"]
+    seg = torch.cat([bg[:, :, :t_in], fg[:, :, :t_in]], 1)
+    enc_in = torch.cat([stack_time_into_channels(frames[:, :, :t_in]), stack_time_into_channels(seg),
+                        stack_time_into_channels(instance[:, :, :t_in])], 1)
+    if input_of is not None:
+        enc_in = torch.cat([enc_in, stack_time_into_channels(input_of[:, :, :t_in]),
+                            stack_time_into_channels(input_occ[:, :, :t_in])], 1)
+    app = appearance_encoder(S, cfg, enc_in, gnn, training)
+    mi = dict(instance=instance, latent=rng["latent_traj"], z_m=z_m, click_index=rng["click_index"], tracking_gnn=gnn)
+    out = dense_motion_inference(S, cfg, app, mi, training)
+    last = frames[:, :, t_in - 1]
+    gen = generator(S, cfg, fold_time(last.unsqueeze(2).repeat(1, 1, T, 1, 1)),
+                    fold_time(out["dense_motion_bw"]), fold_time(out["occlusion_bw"]), training)
+    out["generated"] = unfold_time(gen, T)
+    out["generated_sparse"] = torch.stack([resample(last, out["sparse_motion_bw"][:, :, i]) for i in range(T)], 2)
+    out["generated_sparse_occ"] = torch.stack(
+        [resample(last, out["sparse_motion_bw"][:, :, i]) * out["sparse_occ_bw"][:, :, i] for i in range(T)], 2)
+    return out
 
 
 def train_step_backward(cfg, loss_g, loss_d_img, loss_d_vid):

@@ -308,15 +308,72 @@ def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed)
     save(name, meta, arrays)
 
 
+def capture_inference(name, t_in, use_spade, batch_size, use_gt_eval, eval_mode, seed):
+    """GeneratorFullModel.inference (model.py:241-324) under no_grad, in eval() (how trainer.py:201-208 calls it: norm
+    layers on running statistics) or left in train() mode; z_m and the click index are passed in, the trajectory latent is
+    drawn inside the reference from the torch CPU RNG and re-drawn here with the same seed."""
+    from modules.model import GeneratorFullModel
+    cfg = normalize_config(default_config(num_input_frames=t_in, block_expansion=4, max_expansion=32, h_dim=32,
+                                          z_dim=16, out_channel=16, ndf=4, use_spade=use_spade,
+                                          use_image_discriminator=False, use_video_discriminator=False))
+    cfg["train_params"]["use_gt_eval"] = use_gt_eval
+    ref_cfg = copy.deepcopy(cfg)
+    model = GeneratorFullModel(train_params=ref_cfg["train_params"], model_params=ref_cfg["model_params"],
+                               dataset="cityscapes")
+    spec = state_spec(model.state_dict())
+    model.load_state_dict(synth_state(spec, seed))
+    model.train(not eval_mode)
+    batch = make_batch(batch_size, 128, 256, t_in, seed=seed)
+    gnn = batch["tracking_gnn"]
+    N = gnn.x.shape[0]
+    z_m = rnd(seed + 50, batch_size, 32)
+    clicks, tot = [], 0
+    for i, n in enumerate(gnn.num_real_nodes):
+        clicks.append((seed + i) % int(n) + tot)
+        tot += int(n)
+    clicks = torch.tensor(clicks, dtype=torch.long)
+    torch.manual_seed(seed)
+    latent = torch.FloatTensor(N, 5, 16).normal_(0, 1)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        out = model.inference(batch["video"], batch["bg_mask"], batch["fg_mask"], batch["instance_mask"],
+                              batch.get("input_of"), batch.get("input_occ"), gnn.clone(), clicks, z_m)
+    arrays = {"rng.latent_traj": latent, "rng.click_index": clicks, "in.z_m": z_m}
+    for k, v in out.items():
+        if k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+            arrays["mask." + k], arrays["maskshape." + k] = pack_mask(v)
+        elif k == "index_user_guidance":
+            arrays["out." + k] = v
+        else:
+            arrays["sum.out." + k] = summarize(v)
+            if v.dim() == 5:
+                arrays["sub.out." + k] = v[:, :, :, ::8, ::8].detach()
+            else:
+                arrays["out." + k] = v.detach()
+    for k, b in model.named_buffers():
+        if k.endswith(("running_mean", "running_var")):
+            arrays["sum.buf." + k] = summarize(b)
+    meta = dict(t_in=t_in, use_spade=use_spade, batch_size=batch_size, use_gt_eval=use_gt_eval, eval_mode=eval_mode,
+                seed=seed, spec=spec, cfg=cfg)
+    save(name, meta, arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_utils = ref_shims.install()
     torch.set_num_threads(8)
+    if "--inference-only" in sys.argv:      # added after the other fixtures were frozen: does not rewrite them
+        capture_inference("inf_tin2_spade_eval", 2, True, 2, False, True, 5)
+        capture_inference("inf_tin1_nospade_train_gt", 1, False, 1, True, False, 6)
+        return
     print("ops");      capture_ops(ref_utils)
     print("blocks");   capture_blocks()
     print("e2e")
     capture_e2e("e2e_tin2_spade_full", 2, True, 2, True, True, 3)
     capture_e2e("e2e_tin1_nospade_pred", 1, False, 1, False, False, 4)
+    print("inference")
+    capture_inference("inf_tin2_spade_eval", 2, True, 2, False, True, 5)
+    capture_inference("inf_tin1_nospade_train_gt", 1, False, 1, True, False, 6)
 
 
 if __name__ == "__main__":

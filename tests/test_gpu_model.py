@@ -260,3 +260,47 @@ def test_step_is_deterministic():
     assert losses[0] == losses[1]
     # conv/norm/loss kernels are deterministic; only the warp image-gradient uses float atomics (upstream of this weight? no)
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("name", names("inf_"))
+def test_inference_vs_golden(name):
+    """GeneratorFullModel.inference (reference model.py:241-324): same signature, eval or train mode, the
+    trajectory latent drawn from the torch CPU RNG exactly like the reference (so seeding reproduces the fixture)."""
+    c = Case(name)
+    m = c.meta
+    cfg = normalize_config(m["cfg"])
+    model = GeneratorFullModel(train_params=cfg["train_params"], model_params=cfg["model_params"], dataset="cityscapes")
+    model.load_state_dict(synth_state(m["spec"], m["seed"]), strict=True)
+    model.to(DEV).train(not m["eval_mode"])
+    batch = batch_to(make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"]), DEV)
+    rng = c.group("rng")
+    torch.manual_seed(m["seed"])
+    with torch.no_grad():
+        out = model.inference(batch["video"], batch["bg_mask"], batch["fg_mask"], batch["instance_mask"],
+                              batch.get("input_of"), batch.get("input_occ"), batch["tracking_gnn"],
+                              rng["click_index"].long().to(DEV), c.group("in")["z_m"].to(DEV))
+    torch.cuda.synchronize()
+    exact = m["use_gt_eval"]
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+        mism = int((out[k].cpu() != c.mask(k)).sum())
+        if exact:
+            assert mism == 0, f"{k} must be bit-exact ({mism} pixels differ)"
+        else:
+            assert mism <= 0.06 * float(c.mask("sparse_motion_bin").sum()), f"{k}: {mism} pixels differ"
+    ref_out = c.group("out")
+    assert torch.equal(out["index_user_guidance"].cpu(), ref_out.pop("index_user_guidance"))
+    for k, ref in ref_out.items():
+        close(out[k], ref, 1e-3, 1e-4, f"out {k}")
+    if exact:
+        for k, ref in c.group("sub.out").items():
+            close(out[k][:, :, :, ::8, ::8], ref, 2e-3, 2e-4, f"out {k}")
+    tol = 1e-3 if exact else 3e-2
+    for k, ref in c.group("sum.out").items():
+        got = summarize(out[k].cpu())
+        assert abs(got[1] - ref[1].item()) <= tol * abs(ref[1].item()) + 1e-4, f"|{k}| sum {got[1]} vs {ref[1].item()}"
+    assert set(out) == set(c.group("sum.out")) | set(c.group("out")) | {"sparse_motion_bin", "sparse_occ_bw",
+                                                                       "sparse_occ_fw"}, "output key surface"
+    bufs = dict(model.named_buffers())
+    for k, ref in c.group("sum.buf").items():           # inference must not touch the running statistics
+        close(torch.from_numpy(summarize(bufs[k].cpu())), ref, 1e-6, 1e-7, f"buf {k}")
+    assert not model.motion_encoder.sparse_motion_estimator.training, "inference leaves the GNN in eval mode (model.py:249)"

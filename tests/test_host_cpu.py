@@ -67,3 +67,55 @@ def test_product_never_imports_the_oracle():
             "bad=[m for m in sys.modules if m.split('.')[0]=='oracle']; assert not bad, bad")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([sys.executable, "-c", code], cwd=root)
+
+
+def test_checkpoint_layout_round_trip_with_torch_adam_states(tmp_path):
+    """SURVEY §8f-2 / trainer.py:117-136,245-260: a checkpoint in the reference's layout -- reference state_dict keys (the
+    fixture's key spec) + plain torch.optim.Adam state dicts -- loads into the product model, and what the product saves
+    has the same layout and loads back (host logic only: no kernel runs)."""
+    import copy
+    from c2m_amd import checkpoint as ck
+    from oracle.golden_util import synth_state
+    c = Case("e2e_tin2_spade_full")
+    cfg = normalize_config(c.meta["cfg"])
+    mk = lambda: GeneratorFullModel(train_params=copy.deepcopy(cfg["train_params"]),
+                                    model_params=copy.deepcopy(cfg["model_params"]), dataset="cityscapes")
+    model = mk()
+    ref_sd = synth_state(c.meta["spec"], 77)                       # what the reference's c2m.state_dict() holds
+    # optimizer states as plain torch Adam writes them (the reference's optimizers), over the same parameter lists
+    ref_opt = {}
+    for key, opt in (("optimizer", model.optimizer), ("optimizer_gnn", model.optimizer_gnn),
+                     ("optimizer_d_image", model.d_optimizer_image), ("optimizer_d_video", model.d_optimizer_video)):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in opt.param_groups[0]["params"]]
+        t = torch.optim.Adam(ps, lr=opt.param_groups[0]["lr"], betas=opt.param_groups[0]["betas"],
+                             eps=opt.param_groups[0]["eps"])
+        for i, p in enumerate(ps[:5]):                             # a few parameters have state
+            p.grad = torch.full_like(p, 0.01 * (i + 1))
+        t.step()
+        ref_opt[key] = t.state_dict()
+    d = tmp_path / "samples"
+    d.mkdir()
+    torch.save(dict(c2m=ref_sd, **ref_opt), str(d / "latest_c2m_model.pth.tar"))
+    np.savetxt(str(d / "iter.txt"), (4, 120), delimiter=",", fmt="%d")
+    assert ck.load_checkpoint(model, str(d)) == (4, 120)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    for k, v in ref_sd.items():
+        assert torch.equal(sd[k].cpu(), v), k
+    st = model.optimizer.state_dict()["state"]
+    assert sorted(st.keys()) == [0, 1, 2, 3, 4] and float(st[0]["step"]) == 1.0
+    torch.testing.assert_close(st[2]["exp_avg"], ref_opt["optimizer"]["state"][2]["exp_avg"])
+    assert model.optimizer_gnn.state_dict()["state"] == {}, "the reference does not restore optimizer_gnn (trainer.py:124-129)"
+    # save from the product, load into a fresh product model and into plain torch optimizers
+    path = ck.save_checkpoint(model, str(d), current_epoch=7, epoch_iter=33)
+    saved = torch.load(path, weights_only=False)
+    assert set(saved) == {"c2m", "optimizer", "optimizer_gnn", "optimizer_d_image", "optimizer_d_video"}
+    assert list(saved["c2m"].keys()) == list(ref_sd.keys())
+    other = mk()
+    assert ck.load_checkpoint(other, str(d)) == (8, 33)
+    for k, v in other.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    ps = [torch.nn.Parameter(p.detach().clone()) for p in model.optimizer.param_groups[0]["params"]]
+    t = torch.optim.Adam(ps, lr=1e-4, betas=(0.5, 0.999), eps=1e-7)
+    t.load_state_dict(saved["optimizer"])                          # our optimizer state is a valid torch Adam state
+    assert float(t.state_dict()["state"][0]["step"]) == 1.0

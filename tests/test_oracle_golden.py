@@ -213,6 +213,38 @@ def test_end_to_end_step(name):
         close(summarize(S[k]), ref, rtol=1e-4, atol=1e-5, what=f"buf {k}")
 
 
+@pytest.mark.parametrize("name", names("inf_"))
+def test_inference_path(name):
+    """oracle.inference vs GeneratorFullModel.inference of the live reference (model.py:241-324), eval and train mode."""
+    c = Case(name)
+    m = c.meta
+    S = O.State(synth_state(m["spec"], m["seed"]), trainable=False)
+    batch = make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"])
+    rng = c.group("rng")
+    rng["click_index"] = rng["click_index"].long()
+    with torch.no_grad():
+        out = O.inference(S, m["cfg"], batch, rng, c.group("in")["z_m"], training=not m["eval_mode"])
+    exact = m["use_gt_eval"]          # predicted thetas: the float-equality raster mask may flip on a few pixels
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw"):
+        mism = int((out[k] != c.mask(k)).sum())
+        assert mism == 0 if exact else mism <= 0.06 * float(c.mask("sparse_motion_bin").sum()), f"{k}: {mism} pixels"
+    ref_out = c.group("out")
+    assert torch.equal(out["index_user_guidance"], ref_out.pop("index_user_guidance"))
+    for k, ref in ref_out.items():
+        close(out[k], ref, rtol=1e-4, atol=1e-5, what=f"out {k}")
+    tol = 1e-4 if exact else 3e-2
+    for k, ref in c.group("sub.out").items():
+        if exact:
+            close(out[k][:, :, :, ::8, ::8], ref, rtol=1e-4, atol=1e-5, what=f"out {k}")
+    for k, ref in c.group("sum.out").items():
+        got = summarize(out[k])
+        assert abs(got[1] - ref[1].item()) <= tol * abs(ref[1].item()) + 1e-4, f"|{k}| sum {got[1]} vs {ref[1].item()}"
+    assert set(out) == set(c.group("sum.out")) | set(c.group("out")) | {"sparse_motion_bin", "sparse_occ_bw",
+                                                                       "sparse_occ_fw"}, "output key surface"
+    for k, ref in c.group("sum.buf").items():       # inference never updates running statistics
+        close(summarize(S[k]), ref, rtol=1e-6, atol=1e-7, what=f"buf {k}")
+
+
 def test_state_dict_surface():
     """The full-model key surface (724 entries at t_in=2) is a compatibility contract."""
     c = Case("e2e_tin2_spade_full")
