@@ -129,7 +129,7 @@ def main():
         elapsed = float(t.item())
     frames = world * args.batch * 7 * args.steps
     result = {
-        "metric": "generator train-step frames/sec at 128x256x7", "value": round(frames / elapsed, 2),
+        "metric": f"generator train-step frames/sec at {args.height}x{args.width}x7", "value": round(frames / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -137,7 +137,9 @@ def main():
                                f"batch {args.batch}/GPU, fp32, generator fwd+bwd only (no D), VGG loss on, "
                                "random-init weights", "global_batch": world * args.batch,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * 1e-3 * world * args.batch * args.steps / elapsed, 2),
+        # conv FLOPs scale with the pixel count ("for 256x512 multiply conv FLOPs by 4")
+        "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * (args.height * args.width) / (128 * 256) * 1e-3 *
+                                             world * args.batch * args.steps / elapsed, 2),
     }
     if rank == 0:
         if prof is not None:
