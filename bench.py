@@ -31,12 +31,13 @@ from c2m_amd.synthetic import make_batch, make_step_rng, batch_to  # noqa: E402
 from c2m_amd.train import TrainStep, init_distributed  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (only used by the --dtype bf16 side measurement)
 ALGO_GFLOP_PER_CLIP = 1068.6      # 7-frame 128x256 G-only clip, fwd+bwd (FlopCounterMode on the reference)
 
 
-def bench_config(height, width):
+def bench_config(height, width, full_step=False):
     return normalize_config(default_config(height=height, width=width, num_input_frames=2,
-                                           use_image_discriminator=False, use_video_discriminator=False))
+                                           use_image_discriminator=full_step, use_video_discriminator=full_step))
 
 
 def cpu_baseline(cfg, seconds_budget=25.0):
@@ -83,6 +84,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="conv operand precision: f32 = BASELINE configs[1] (the bench line); bf16 = configs[2-4] mode")
+    ap.add_argument("--full-step", action="store_true",
+                    help="full adversarial step of BASELINE configs[2-4]: both discriminators on + the four Adam steps")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     args = ap.parse_args()
@@ -93,13 +98,14 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local_rank)
-    cfg = bench_config(args.height, args.width)
+    cfg = bench_config(args.height, args.width, args.full_step)
+    ops.set_conv_precision("bf16" if args.dtype == "bf16" else "fp32")
     import copy
     torch.manual_seed(0)                       # identical initial weights on every rank (== DDP's rank-0 broadcast)
     model = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
                                model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
     model.to(dev).train()
-    step = TrainStep(model, run_optimizers=False, distributed=world > 1 or args.force_reducer,
+    step = TrainStep(model, run_optimizers=args.full_step, distributed=world > 1 or args.force_reducer,
                      force_collectives=args.force_reducer)
     batch = batch_to(make_batch(args.batch, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)
@@ -132,10 +138,13 @@ def main():
         "metric": f"generator train-step frames/sec at {args.height}x{args.width}x7", "value": round(frames / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {args.height}x{args.width}, 7-frame clips (2 in + 5 predicted), "
-                               f"batch {args.batch}/GPU, fp32, generator fwd+bwd only (no D), VGG loss on, "
-                               "random-init weights", "global_batch": world * args.batch,
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE {'configs[1]' if (args.dtype, args.full_step) == ('f32', False) else 'configs[2-3] style (side measurement)'}: "
+                               f"{args.height}x{args.width}, 7-frame clips (2 in + 5 predicted), "
+                               f"batch {args.batch}/GPU, {'fp32' if args.dtype == 'f32' else 'bf16 conv operands (fp32 accumulate, fp32 tensors)'}, "
+                               + ("full adversarial step (G + D_image + D_video, 4 Adam steps), VGG loss on, "
+                                  if args.full_step else "generator fwd+bwd only (no D), VGG loss on, ")
+                               + "random-init weights", "global_batch": world * args.batch,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         # conv FLOPs scale with the pixel count ("for 256x512 multiply conv FLOPs by 4")
         "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * (args.height * args.width) / (128 * 256) * 1e-3 *
@@ -144,21 +153,24 @@ def main():
     if rank == 0:
         if prof is not None:
             s = prof.summary()
-            ig = s.get("igemm", dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
-            wg = s.get("wgrad", dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
+            sfx = "_bf16" if args.dtype == "bf16" else ""
+            peak = PEAK_BF16_MFMA_TFLOPS if sfx else PEAK_FP32_MFMA_TFLOPS
+            ig = s.get("igemm" + sfx, dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
+            wg = s.get("wgrad" + sfx, dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json); counters cannot be read from inside the process
             traffic, traffic_src = None, None
             tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tp) and (args.batch, args.height, args.width) == (8, 128, 256):
+            if os.path.exists(tp) and (args.batch, args.height, args.width, args.dtype, args.full_step) == \
+                    (8, 128, 256, "f32", False):
                 with open(tp) as f:
                     traffic = json.load(f)["igemm"]["traffic_bytes_per_launch"]
                 traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
             ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             result["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel + conv_patch3x3_kernel (c2m_conv_igemm fwd + dgrad launches)",
-                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                 "launches_per_step": ig["launches"] // args.steps,

@@ -83,7 +83,16 @@ __device__ __forceinline__ void decompose_pix(int pix, const P& p, int& n, int& 
     ot = r % p.To;   n = r / p.To;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, int U>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// BF = true: bf16 operands (activations and weights are rounded to bf16, RNE, while they are staged into LDS; fp32
+// accumulation, fp32 output) on v_mfma_f32_32x32x16_bf16 -- one instruction per 16-deep K-step and 32x32 tile.  LDS
+// image [k half h][row][8 bf16] (16 B per lane, conflict-free ds_read_b128).  The K slot order inside a step is
+// permuted identically for A and B so that each gathering thread's values are contiguous: slot(k) = (k % BROWS) *
+// BPASS + k / BROWS (a sum over k does not care about the order).
+template <int BM, int BN, int WGM, int WGN, int NS, int U, bool BF = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     // U = table K-steps (16 deep each) staged per barrier: U = 2 halves the barriers per MFMA at twice the LDS
     constexpr int BK = 16, CK = BK / NS, BKU = BK * U;
@@ -94,8 +103,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int A_F4 = BM * BK / 4;         // float4 loads per K-step (whole block)
     constexpr int APASS = (A_F4 + 255) / 256;
     static_assert(WGM * WGN == 4 && BN >= 64 && CK % BROWS == 0, "tile");
-    __shared__ float sA[2][BKU][LDA_S];
-    __shared__ float sB[2][BKU][LDB_S];
+    static_assert(!BF || BROWS <= 2, "bf16 slot packing is written for BN = 128 / 256");
+    __shared__ float sA[BF ? 1 : 2][BF ? 1 : BKU][BF ? 1 : LDA_S];
+    __shared__ float sB[BF ? 1 : 2][BF ? 1 : BKU][BF ? 1 : LDB_S];
+    __shared__ uint4 hA[BF ? 2 * U * 2 * BM : 1];      // [buf][u][h][row] x 8 bf16
+    __shared__ uint4 hB[BF ? 2 * U * 2 * BN : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -187,16 +199,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if constexpr (BF) {
+                __bf16* __restrict__ a8 = reinterpret_cast<__bf16*>(hA) + (long)((buf * U + u) * 2) * BM * 8;
 #pragma unroll
-            for (int s = 0; s < APASS; ++s) {
-                int r = arow + s * 64;
-                if (A_F4 >= 256 || r < BM) {
-                    sA[buf][u * BK + akq + 0][r] = ra[u][s].x; sA[buf][u * BK + akq + 1][r] = ra[u][s].y;
-                    sA[buf][u * BK + akq + 2][r] = ra[u][s].z; sA[buf][u * BK + akq + 3][r] = ra[u][s].w;
+                for (int s = 0; s < APASS; ++s) {
+                    const int r = arow + s * 64;
+                    if (A_F4 >= 256 || r < BM) {
+                        const float4 v = ra[u][s];
+                        if constexpr (BROWS == 1) {        // slot = k: 4 consecutive slots in half akq / 8
+                            bf16x4 q = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                            *reinterpret_cast<bf16x4*>(a8 + ((akq >> 3) * BM + r) * 8 + (akq & 7)) = q;
+                        } else {                            // slot = (k & 1) * 8 + k / 2: even k -> half 0, odd k -> half 1
+                            bf16x2 e = {(__bf16)v.x, (__bf16)v.z}, o = {(__bf16)v.y, (__bf16)v.w};
+                            *reinterpret_cast<bf16x2*>(a8 + (0 * BM + r) * 8 + (akq >> 1)) = e;
+                            *reinterpret_cast<bf16x2*>(a8 + (1 * BM + r) * 8 + (akq >> 1)) = o;
+                        }
+                    }
                 }
-            }
+                // this thread's BPASS values are slots brow0*BPASS .. +BPASS-1: whole 8-slot halves
+                uint4* __restrict__ b8 = hB + (long)((buf * U + u) * 2) * BN;
 #pragma unroll
-            for (int s = 0; s < BPASS; ++s) sB[buf][u * BK + brow0 + s * BROWS][bp] = rb[u][s];
+                for (int hh = 0; hh < BPASS / 8; ++hh) {
+                    bf16x8 q;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) q[e] = (__bf16)rb[u][hh * 8 + e];
+                    const int h = BROWS == 1 ? hh : brow0;
+                    b8[h * BN + bp] = __builtin_bit_cast(uint4, q);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < APASS; ++s) {
+                    int r = arow + s * 64;
+                    if (A_F4 >= 256 || r < BM) {
+                        sA[buf][u * BK + akq + 0][r] = ra[u][s].x; sA[buf][u * BK + akq + 1][r] = ra[u][s].y;
+                        sA[buf][u * BK + akq + 2][r] = ra[u][s].z; sA[buf][u * BK + akq + 3][r] = ra[u][s].w;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < BPASS; ++s) sB[buf][u * BK + brow0 + s * BROWS][bp] = rb[u][s];
+            }
         }
     };
 
@@ -212,6 +253,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if (more) load_tile(kt + U);
         // all fragment reads of a 16-deep step are issued first (own registers each), so the LDS latency of k-pair
         // kk+1.. hides behind the MFMAs of kk (the compiler otherwise recycles 4 VGPRs and serialises read -> mfma)
+        if constexpr (BF) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint4* __restrict__ a8 = hA + (long)((cur * U + u) * 2 + (lane >> 5)) * BM;
+                const uint4* __restrict__ b8 = hB + (long)((cur * U + u) * 2 + (lane >> 5)) * BN;
+                bf16x8 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = __builtin_bit_cast(bf16x8, a8[wm * TM + i * 32 + (lane & 31)]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = __builtin_bit_cast(bf16x8, b8[wn * TN + j * 32 + (lane & 31)]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float a[BK / 2][MI], b[BK / 2][NI];
@@ -480,11 +538,24 @@ template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
 #ifndef C2M_IGEMM_U
 #define C2M_IGEMM_U 1
 #endif
+#ifndef C2M_BF16_U
+#define C2M_BF16_U 2      // bf16: 4 MFMAs per 16-deep step and wave, so two steps per barrier
+#endif
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s) {
+static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s, bool bf16) {
     dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits * p.ncls);
     constexpr int U = (BM == 128) ? C2M_IGEMM_U : 1;
+    if (bf16) {
+        constexpr int UB = C2M_BF16_U;
+        switch (ns) {
+            case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1, UB, true>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 2, UB, true>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 4, UB, true>), grid, dim3(256), 0, s, p); break;
+            default: return (int)hipErrorInvalidValue;
+        }
+        return (int)hipGetLastError();
+    }
     switch (ns) {
         case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 1, U>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, 2, 1>), grid, dim3(256), 0, s, p); break;
@@ -561,6 +632,7 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;
     if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
+        if (g[34] == 1) return (int)hipErrorInvalidValue;  // fp32 only
         if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
         p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
         for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
@@ -577,9 +649,10 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         if (ns == 2) return launch_thin_fwd<2>(p, s);
         return launch_thin_fwd<4>(p, s);
     }
-    if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s);
-    else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s);
-    else                return launch_igemm<128, 128, 2, 2>(p, ns, splits, s);
+    const bool bf16 = g[34] == 1;                          // operand precision: 0 fp32 (exact), 1 bf16 (fp32 accumulate)
+    if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s, bf16);
+    else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s, bf16);
+    else                return launch_igemm<128, 128, 2, 2>(p, ns, splits, s, bf16);
 }
 
 C2M_API int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits,
@@ -608,7 +681,7 @@ struct WgradP {
     unsigned x_bytes, dy_bytes;
 };
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool BF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     constexpr int CK = 16 / NS;
     constexpr int BK = 64;                 // pixels per K-step (one wave-width: coalesced along pix)
@@ -617,8 +690,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     constexpr int AROWS = BM / 4, BROWSW = BN / 4;   // rows per wave
     constexpr int BGROUPS = BROWSW / 16;              // 16-row (one tap) groups per wave
     static_assert(BROWSW % 16 == 0, "wgrad rows per wave must be whole tap groups");
-    __shared__ float sA[BM][LDS_S];
-    __shared__ float sB[BN][LDS_S];
+    // BF: bf16 operands (dY and X rounded RNE while staged), v_mfma_f32_32x32x16_bf16 with 16 pixels per instruction;
+    // LDS rows of 64 + 8 bf16 (144 B: conflict-free 16-B fragment reads)
+    constexpr int LDH = BK + 8;
+    __shared__ float sA[BF ? 1 : BM][BF ? 1 : LDS_S];
+    __shared__ float sB[BF ? 1 : BN][BF ? 1 : LDS_S];
+    __shared__ __attribute__((aligned(16))) __bf16 hA[BF ? BM : 1][BF ? LDH : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[BF ? BN : 1][BF ? LDH : 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
@@ -688,12 +766,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     for (int pk = pbeg; pk < pend; pk += BK) {
         if (!PIPE && pk > pbeg) issue_loads(pk);
         __syncthreads();   // previous K-step's fragment reads are done
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < AROWS; ++s) sA[wave * AROWS + s][lane] = ra[s];
+            for (int s = 0; s < AROWS; ++s) hA[wave * AROWS + s][lane] = (__bf16)ra[s];
 #pragma unroll
-        for (int s = 0; s < BROWSW; ++s) sB[wave * BROWSW + s][lane] = rb[s];
+            for (int s = 0; s < BROWSW; ++s) hB[wave * BROWSW + s][lane] = (__bf16)rb[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < AROWS; ++s) sA[wave * AROWS + s][lane] = ra[s];
+#pragma unroll
+            for (int s = 0; s < BROWSW; ++s) sB[wave * BROWSW + s][lane] = rb[s];
+        }
         __syncthreads();
         if (PIPE && pk + BK < pend) issue_loads(pk + BK);
+        if constexpr (BF) {
+#pragma unroll
+            for (int kq = 0; kq < BK / 16; ++kq) {
+                const int kc = kq * 16 + 8 * (lane >> 5);
+                bf16x8 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&hA[wm * TM + i * 32 + (lane & 31)][kc]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&hB[wn * TN + j * 32 + (lane & 31)][kc]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else
         // fragment reads in groups of 8 k-pairs issued ahead of their MFMAs (see the igemm kernel)
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
@@ -984,19 +1085,23 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
                            taps, NS, ntg, ngroups, Sthin);
         return (int)hipGetLastError();
     }
-    if (p.M <= 32) {
-        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 1>), grid, dim3(256), 0, s, p);
-        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 2>), grid, dim3(256), 0, s, p);
-        else              hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, p);
-    } else if (p.M > 64) {
-        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, p);
-        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
-        else              hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, s, p);
-    } else {
-        if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 1>), grid, dim3(256), 0, s, p);
-        else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 2>), grid, dim3(256), 0, s, p);
-        else              hipLaunchKernelGGL((conv_wgrad_kernel<64, C2M_WG64_BN, 2, 2, 4>), grid, dim3(256), 0, s, p);
-    }
+    const bool bf16 = g[34] == 1;
+#define C2M_WG(BMv, BNv, WGMv, WGNv)                                                                                  \
+    do {                                                                                                              \
+        if (bf16) {                                                                                                   \
+            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1, true>), grid, dim3(256), 0, s, p); \
+            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2, true>), grid, dim3(256), 0, s, p); \
+            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4, true>), grid, dim3(256), 0, s, p); \
+        } else {                                                                                                      \
+            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1>), grid, dim3(256), 0, s, p); \
+            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2>), grid, dim3(256), 0, s, p); \
+            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4>), grid, dim3(256), 0, s, p); \
+        }                                                                                                             \
+    } while (0)
+    if (p.M <= 32)      C2M_WG(32, 128, 1, 4);
+    else if (p.M > 64)  C2M_WG(128, 128, 2, 2);
+    else                C2M_WG(64, C2M_WG64_BN, 2, 2);
+#undef C2M_WG
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long total = (long)p.M * (Cin * taps + 1);

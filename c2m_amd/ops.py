@@ -39,6 +39,32 @@ def _f(t):
 
 # =============================================================================================== convolution
 _geom_cache = {}
+_conv_bf16 = False
+
+
+def set_conv_precision(precision):
+    """"fp32" (default: exact fp32 MFMA) or "bf16": conv operands (activations, weights, output gradients) are rounded to
+    bf16 while staged into LDS and multiplied on the bf16 MFMA with fp32 accumulation; tensors in HBM, norms, warps and
+    losses stay fp32.  BASELINE configs[2-4] ("bf16") run in this mode.  Returns the previous setting."""
+    global _conv_bf16
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(f"unknown conv precision {precision!r}")
+    prev = "bf16" if _conv_bf16 else "fp32"
+    _conv_bf16 = precision == "bf16"
+    return prev
+
+
+class conv_precision:
+    """Context manager form of set_conv_precision (the backward of a conv uses the precision of its forward)."""
+
+    def __init__(self, precision):
+        self.precision = precision
+
+    def __enter__(self):
+        self.prev = set_conv_precision(self.precision)
+
+    def __exit__(self, *exc):
+        set_conv_precision(self.prev)
 
 
 class ConvProfiler:
@@ -203,8 +229,9 @@ def _geom(**kw):
 class _ConvPlan:
     """Everything shape-dependent for one conv layer geometry (cached): gather tables + geom arrays."""
 
-    def __init__(self, xs, ws, stride, pad, reflect, device):
+    def __init__(self, xs, ws, stride, pad, reflect, device, bf16=False):
         L = _lib.lib()
+        self.bf16 = bf16
         nd = len(xs) - 2
         self.is3d = is3d = 1 if nd == 3 else 0
         N, Cin = xs[0], xs[1]
@@ -229,7 +256,7 @@ class _ConvPlan:
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
-        if (kt, kh, kw) == (1, 3, 3) and _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout):
+        if not bf16 and (kt, kh, kw) == (1, 3, 3) and _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout):
             self.fwd_patch, self.ck = True, 16
             ck = 16
         ns = 16 // ck
@@ -290,7 +317,7 @@ class _ConvPlan:
                     ctaps = At * Ay * Ax
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
-                    if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
+                    if not bf16 and (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
                             _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, Cin):
                         cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
@@ -358,10 +385,16 @@ class _ConvPlan:
 
 
 def _plan(x, w, stride, pad, reflect):
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index)
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index, _conv_bf16)
     pl = _geom_cache.get(key)
     if pl is None:
-        pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device)
+        pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device, _conv_bf16)
+        if _conv_bf16:                     # geom[34] = operand precision, read by c2m_conv_igemm / c2m_conv_wgrad
+            pl.fwd_geom[34] = pl.wg_geom[34] = 1
+            for c in pl.classes:
+                c["geom"][34] = 1
+            for grp in (pl.cls_batch["groups"] if pl.cls_batch else ()):
+                grp["geom"][34] = 1
     return pl
 
 
@@ -415,7 +448,7 @@ class _ConvFn(torch.autograd.Function):
         S = pl.fwd_splits
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
-        _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+        _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                           lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
                                                    ACT[act], LRELU_SLOPE, _stream()), tag,
                           4 * (x.numel() + w.numel() + y.numel())), "conv_igemm fwd")
@@ -456,7 +489,8 @@ class _ConvFn(torch.autograd.Function):
                     Ag = A[grp["first"] * Cin:]
                     tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
                            pl.reflect, S)
-                    _lib.check(_timed("igemm", 2.0 * Cin * Cout * cb["taps"] * grp["npix"] * grp["ncls"],
+                    _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
+                                      2.0 * Cin * Cout * cb["taps"] * grp["npix"] * grp["ncls"],
                                       lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
                                                                None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
                                                                _stream()), tag,
@@ -474,7 +508,7 @@ class _ConvFn(torch.autograd.Function):
                     w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
                         w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
-                _lib.check(_timed("igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
+                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
                                                            _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
                                   4 * (gy.numel() + w.numel() + x.numel()) // len(pl.classes)), "conv_igemm dgrad")
@@ -491,7 +525,7 @@ class _ConvFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
-            _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            _lib.check(_timed("wgrad_bf16" if pl.bf16 else "wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
                                                        _gp(pl.wg_geom), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wgrad")

@@ -98,6 +98,41 @@ def test_conv_fwd_bwd(case, act):
     rel_close(bg.grad, br.grad, 1e-4, "conv bias grad")
 
 
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_k{c[2]}_s{c[3]}_{c[5]}")
+def test_conv_bf16_mode(case):
+    """bf16 operand mode (BASELINE configs[2-4]): with inputs that are exactly representable in bf16 every product is
+    exact in fp32, so the result must equal the fp32 convolution up to summation order -- this pins the bf16 LDS image,
+    the K-slot permutation and the 32x32x16 operand layout; arbitrary inputs then differ only by the operand rounding."""
+    xs, cout, k, stride, pad, mode = case
+    seed = abs(hash(str(case))) % 10000
+    x, w = _bf(rnd(seed, *xs)), _bf(rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * int(np.prod(k))) ** 0.5)))
+    b = rnd(seed + 2, cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = _ref_conv(xr, wr, br, stride, pad, mode, None)
+    go = _bf(rnd(seed + 3, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+    with ops.conv_precision("bf16"):
+        y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
+        (y * g(go)).sum().backward()
+    rel_close(y, yr, 2e-5, "bf16-mode conv fwd (representable inputs)")
+    rel_close(xg.grad, xr.grad, 5e-5, "bf16-mode dgrad")
+    rel_close(wg.grad, wr.grad, 1e-4, "bf16-mode wgrad")
+    rel_close(bg.grad, br.grad, 1e-4, "bf16-mode bias grad")
+    # arbitrary fp32 inputs: operands rounded to 8 mantissa bits -> relative error of a dot product ~ 2^-8 / sqrt(K)
+    x2, w2 = rnd(seed + 5, *xs), rnd(seed + 6, cout, xs[1], *k, scale=(1.0 / (xs[1] * int(np.prod(k))) ** 0.5))
+    with ops.conv_precision("bf16"):
+        y2 = ops.conv(g(x2), g(w2), None, stride=stride, padding=pad, padding_mode=mode)
+    rel_close(y2, _ref_conv(x2, w2, None, stride, pad, mode, None), 1e-2, "bf16-mode conv fwd (fp32 inputs)")
+    if cout > 4:       # <= 4 output channels run on the fp32 vector-ALU kernel in either mode (more precise, not less)
+        rel_close(y2, _ref_conv(_bf(x2), _bf(w2), None, stride, pad, mode, None), 2e-5,
+                  "bf16 rounding is RNE of both operands")
+
+
 def test_conv_stride2_fuzz():
     """Random small stride-2 layers (the tiny e2e fixtures live here): batched parity classes, split-K, thin rows."""
     rs = np.random.RandomState(7)
