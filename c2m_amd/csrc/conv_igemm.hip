@@ -533,6 +533,25 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
     }
 }
 
+// 16-byte form: 4 consecutive outputs share a channel when chan_stride % 4 == 0
+__global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, float4* __restrict__ out,
+                                         const float* __restrict__ bias, long total4, int S, long chan_stride4, int M,
+                                         int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < S; ++z) {
+            const float4 v = slab[(long)z * total4 + i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (bias) {
+            const float b = bias[(int)((i / chan_stride4) % M)];
+            acc.x += b; acc.y += b; acc.z += b; acc.w += b;
+        }
+        out[i] = make_float4(c2m_act(acc.x, act, slope), c2m_act(acc.y, act, slope), c2m_act(acc.z, act, slope),
+                             c2m_act(acc.w, act, slope));
+    }
+}
+
 template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
 
 #ifndef C2M_IGEMM_U
@@ -659,6 +678,12 @@ C2M_API int c2m_splitk_reduce(const float* slab, float* out, const float* bias, 
                               long chan_stride, int M, int act, float slope, void* stream) {
     C2M_ENTER();
     if (total <= 0) return 0;
+    if ((total & 3) == 0 && (!bias || (chan_stride & 3) == 0) && ((((uintptr_t)slab) | ((uintptr_t)out)) & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias, total / 4,
+                           splits, bias ? chan_stride / 4 : 1, M, act, slope);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, out,
                        bias, total, splits, chan_stride, M, act, slope);
     return (int)hipGetLastError();

@@ -31,12 +31,28 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     const long end = beg + NORM_CHUNK < S ? beg + NORM_CHUNK : S;
     const float* __restrict__ p = x + plane * S;
     const int cnt = (int)(end - beg);
+    const bool vec = (S & 3) == 0 && ((uintptr_t)x & 15) == 0;      // chunk bounds are multiples of 4 then
     float s = 0.f;
-    for (long i = beg + threadIdx.x; i < end; i += 256) s += p[i];
+    if (vec) {
+        for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += 256) s += p[i];
+    }
     s = block_sum_256(s, sm);
     const float mean = s / (float)cnt;
     float m2 = 0.f;
-    for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = p[i] - mean; m2 += d * d; }
+    if (vec) {
+        for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            m2 += (a * a + b * b) + (c * c + d * d);
+        }
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = p[i] - mean; m2 += d * d; }
+    }
     m2 = block_sum_256(m2, sm);
     if (threadIdx.x == 0) {
         partial[(long)blockIdx.x * 2 + 0] = mean;
@@ -124,6 +140,46 @@ __global__ void norm_apply_kernel(const ApplyP p) {
     }
 }
 
+// Large planes (S >= 1024, S % 4 == 0): one workgroup per (plane, 8192-element chunk), 16-byte accesses, the plane's
+// statistics and affine parameters in registers -- no per-element index arithmetic.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(256) void norm_apply_vec_kernel(const ApplyP p, int chunks) {
+    const long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const long beg = (long)chunk * NORM_CHUNK;
+    const long end = beg + NORM_CHUNK < p.S ? beg + NORM_CHUNK : p.S;
+    const int c = (int)(plane % p.C);
+    const int n = (int)(plane / p.C);
+    const int st = p.mode == 0 ? (int)plane : c;
+    const float mean = p.mean[st], invstd = p.invstd[st];
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    const float* __restrict__ x = p.x + plane * p.S;
+    float* __restrict__ y = p.y + plane * p.S;
+    const float* __restrict__ g0 = p.gb ? p.gb + ((long)n * 2 * p.C + c) * p.S : nullptr;
+    const float* __restrict__ g1 = p.gb ? g0 + (long)p.C * p.S : nullptr;
+    for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        const float4 v = ld4(x + i);
+        float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
+        if (p.gb) {
+            const float4 a = ld4(g0 + i);
+            sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+            sh = ld4(g1 + i);
+        }
+        float4 o;
+        o.x = c2m_act((v.x - mean) * invstd * sc.x + sh.x, p.act, p.slope);
+        o.y = c2m_act((v.y - mean) * invstd * sc.y + sh.y, p.act, p.slope);
+        o.z = c2m_act((v.z - mean) * invstd * sc.z + sh.z, p.act, p.slope);
+        o.w = c2m_act((v.w - mean) * invstd * sc.w + sh.w, p.act, p.slope);
+        *reinterpret_cast<float4*>(y + i) = o;
+    }
+}
+
+static inline bool norm_vec_ok(long S, const void* a, const void* b, const void* c, const void* d) {
+    return S >= 1024 && (S & 3) == 0 &&
+           ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 C2M_API int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, const float* gb, float* y, int N, int C, long S, int mode, int act,
                            float slope, void* stream) {
@@ -131,6 +187,12 @@ C2M_API int c2m_norm_apply(const float* x, const float* mean, const float* invst
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
     ApplyP p{x, mean, invstd, gamma, beta, gb, y, N, C, S, mode, act, slope};
+    if (norm_vec_ok(S, x, y, gb, nullptr)) {
+        const int chunks = norm_chunks(S);
+        hipLaunchKernelGGL(norm_apply_vec_kernel, dim3((unsigned)((long)N * C * chunks)), dim3(256), 0,
+                           (hipStream_t)stream, p, chunks);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(norm_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
@@ -167,6 +229,35 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
     const float mean = p.mean[st], invstd = p.invstd[st];
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    const bool vec = (p.S & 3) == 0 && (((uintptr_t)p.x | (uintptr_t)p.gy | (uintptr_t)p.gb | (uintptr_t)p.ggb) & 15) == 0;
+    if (vec) {                       // 16-byte accesses; element order inside a thread is fixed -> deterministic sums
+        const float* __restrict__ xp = p.x + plane * p.S;
+        const float* __restrict__ gp = p.gy + plane * p.S;
+        const long gplane = ((long)n * 2 * p.C + c) * p.S, goff = (long)p.C * p.S;
+        for (long s = beg + threadIdx.x * 4; s < end; s += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + s);
+            const float4 gv = *reinterpret_cast<const float4*>(gp + s);
+            float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
+            if (p.gb) {
+                const float4 a = *reinterpret_cast<const float4*>(p.gb + gplane + s);
+                sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+                sh = *reinterpret_cast<const float4*>(p.gb + gplane + goff + s);
+            }
+            const float xh[4] = {(xv.x - mean) * invstd, (xv.y - mean) * invstd, (xv.z - mean) * invstd, (xv.w - mean) * invstd};
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, gyv[4] = {gv.x, gv.y, gv.z, gv.w};
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[e] = gyv[e] * act_grad(xh[e] * scv[e] + shv[e], p.act, p.slope);
+                if (p.gb) { s1 += g[e] * scv[e]; s2 += g[e] * scv[e] * xh[e]; }
+                else { s1 += g[e]; s2 += g[e] * xh[e]; }
+            }
+            if (p.gb) {
+                *reinterpret_cast<float4*>(p.ggb + gplane + s) = make_float4(g[0] * xh[0], g[1] * xh[1], g[2] * xh[2], g[3] * xh[3]);
+                *reinterpret_cast<float4*>(p.ggb + gplane + goff + s) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        }
+    } else
     for (long s = beg + threadIdx.x; s < end; s += 256) {
         const long i = plane * p.S + s;
         const float xhat = (p.x[i] - mean) * invstd;
@@ -255,6 +346,41 @@ __global__ void norm_bwd_apply_kernel(const BwdP p) {
     }
 }
 
+__global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP p) {
+    const long plane = blockIdx.x / p.chunks;
+    const int chunk = blockIdx.x % p.chunks;
+    const long beg = (long)chunk * NORM_CHUNK;
+    const long end = beg + NORM_CHUNK < p.S ? beg + NORM_CHUNK : p.S;
+    const int c = (int)(plane % p.C);
+    const int n = (int)(plane / p.C);
+    const int st = p.mode == 0 ? (int)plane : c;
+    const float mean = p.mean[st], invstd = p.invstd[st], c1 = p.coef[st * 2 + 0], c2 = p.coef[st * 2 + 1];
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    const float* __restrict__ xp = p.x + plane * p.S;
+    const float* __restrict__ gp = p.gy + plane * p.S;
+    float* __restrict__ dp = p.dx + plane * p.S;
+    const long gplane = ((long)n * 2 * p.C + c) * p.S, goff = (long)p.C * p.S;
+    for (long s = beg + threadIdx.x * 4; s < end; s += 1024) {
+        const float4 xv = *reinterpret_cast<const float4*>(xp + s);
+        const float4 gv = *reinterpret_cast<const float4*>(gp + s);
+        float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
+        if (p.gb) {
+            const float4 a = *reinterpret_cast<const float4*>(p.gb + gplane + s);
+            sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+            sh = *reinterpret_cast<const float4*>(p.gb + gplane + goff + s);
+        }
+        const float xh[4] = {(xv.x - mean) * invstd, (xv.y - mean) * invstd, (xv.z - mean) * invstd, (xv.w - mean) * invstd};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, gyv[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = gyv[e] * act_grad(xh[e] * scv[e] + shv[e], p.act, p.slope);
+            o[e] = invstd * (g * scv[e] - c1 - xh[e] * c2);
+        }
+        *reinterpret_cast<float4*>(dp + s) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
 C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
@@ -273,7 +399,10 @@ C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, con
     hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
     const int nthreads = mode == 0 ? N * C : C;
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p);
+    if (norm_vec_ok(S, x, gy, gb, dx))
+        hipLaunchKernelGGL(norm_bwd_apply_vec_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -294,9 +423,33 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
     }
 }
 
+__device__ __forceinline__ float act_bwd_elem(float v, float g, int act, float slope) {
+    switch (act) {
+        case C2M_ACT_RELU: return v > 0.f ? g : 0.f * g;
+        case C2M_ACT_LRELU: return g * (v > 0.f ? 1.f : slope);
+        case C2M_ACT_SIGMOID: return g * (v * (1.f - v));
+        default: return g;
+    }
+}
+
+__global__ void act_bwd_vec_kernel(const float4* __restrict__ y, const float4* __restrict__ gy, float4* __restrict__ gx,
+                                   long total4, int act, float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = y[i], g = gy[i];
+        gx[i] = make_float4(act_bwd_elem(v.x, g.x, act, slope), act_bwd_elem(v.y, g.y, act, slope),
+                            act_bwd_elem(v.z, g.z, act, slope), act_bwd_elem(v.w, g.w, act, slope));
+    }
+}
+
 C2M_API int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream) {
     C2M_ENTER();
     if (total <= 0) return 0;
+    if ((total & 3) == 0 && ((((uintptr_t)y) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0) {
+        hipLaunchKernelGGL(act_bwd_vec_kernel, dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(gy),
+                           reinterpret_cast<float4*>(gx), total / 4, act, slope);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(act_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, gy, gx, total,
                        act, slope);
     return (int)hipGetLastError();

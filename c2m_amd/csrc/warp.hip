@@ -184,16 +184,25 @@ __device__ __forceinline__ Lerp lerp_src(int o, int in, float scale, bool align)
     return l;
 }
 
+// Index type of the element-parallel kernels below: 32-bit when the tensor allows (a 64-bit division per element costs
+// more than the memory access it addresses).
+#define C2M_IDX_DISPATCH(total, KERNEL, grid, stream, ...)                                                   \
+    do {                                                                                                     \
+        if ((total) < (1L << 31)) hipLaunchKernelGGL((KERNEL<unsigned>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<long>), grid, dim3(256), 0, stream, __VA_ARGS__);                  \
+    } while (0)
+
+template <typename I>
 __global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi,
                                        int Ho, int Wo, float sh, float sw, int align, float mul) {
-    const long total = NC * Ho * Wo;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % Wo); const long r = i / Wo;
-        const int oy = (int)(r % Ho); const long nc = r / Ho;
+    const I total = (I)(NC * Ho * Wo);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
+        const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
         const Lerp ly = lerp_src(oy, Hi, sh, align), lx = lerp_src(ox, Wi, sw, align);
-        const float* __restrict__ p = in + nc * (long)Hi * Wi;
-        const float v = ly.l0 * (lx.l0 * p[(long)ly.i0 * Wi + lx.i0] + lx.l1 * p[(long)ly.i0 * Wi + lx.i1]) +
-                        ly.l1 * (lx.l0 * p[(long)ly.i1 * Wi + lx.i0] + lx.l1 * p[(long)ly.i1 * Wi + lx.i1]);
+        const float* __restrict__ p = in + (long)nc * Hi * Wi;
+        const float v = ly.l0 * (lx.l0 * p[ly.i0 * Wi + lx.i0] + lx.l1 * p[ly.i0 * Wi + lx.i1]) +
+                        ly.l1 * (lx.l0 * p[ly.i1 * Wi + lx.i0] + lx.l1 * p[ly.i1 * Wi + lx.i1]);
         out[i] = v * mul;
     }
 }
@@ -209,20 +218,45 @@ C2M_API int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, in
     C2M_ENTER();
     const long total = NC * Ho * Wo;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
-                       NC, Hi, Wi, Ho, Wo, area_scale(Hi, Ho, align, scale_factor),
-                       area_scale(Wi, Wo, align, scale_factor), align, 1.0f);
+    C2M_IDX_DISPATCH(total, resize_bilinear_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi,
+                     Ho, Wo, area_scale(Hi, Ho, align, scale_factor), area_scale(Wi, Wo, align, scale_factor), align, 1.0f);
     return (int)hipGetLastError();
 }
 
+// x2 upsample (align_corners=False; up_block.py:10): one thread per INPUT pixel writes its 2x2 outputs as two 8-byte
+// stores; the arithmetic is the generic kernel's expression with the same lerp_src weights -> bit-identical results.
+template <typename I>
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi) {
+    const int Wo = 2 * Wi;
+    const I total = (I)(NC * Hi * Wi);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
+        const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
+        const float* __restrict__ p = in + (long)nc * Hi * Wi;
+        float* __restrict__ o = out + (long)nc * 4 * Hi * Wi + (long)(2 * y) * Wo + 2 * x;
+        const Lerp lx0 = lerp_src(2 * x, Wi, 0.5f, false), lx1 = lerp_src(2 * x + 1, Wi, 0.5f, false);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const Lerp ly = lerp_src(2 * y + a, Hi, 0.5f, false);
+            const float* __restrict__ r0 = p + ly.i0 * Wi;
+            const float* __restrict__ r1 = p + ly.i1 * Wi;
+            float2 v;
+            v.x = ly.l0 * (lx0.l0 * r0[lx0.i0] + lx0.l1 * r0[lx0.i1]) + ly.l1 * (lx0.l0 * r1[lx0.i0] + lx0.l1 * r1[lx0.i1]);
+            v.y = ly.l0 * (lx1.l0 * r0[lx1.i0] + lx1.l1 * r0[lx1.i1]) + ly.l1 * (lx1.l0 * r1[lx1.i0] + lx1.l1 * r1[lx1.i1]);
+            *reinterpret_cast<float2*>(o + (long)a * Wo) = v;
+        }
+    }
+}
+
 // adjoint of the x2 (align_corners=False, scale 0.5) upsample, gather form (deterministic, no atomics)
+template <typename I>
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long NC, int Hi, int Wi) {
     const int Ho = 2 * Hi, Wo = 2 * Wi;
-    const long total = NC * Hi * Wi;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % Wi); const long r = i / Wi;
-        const int y = (int)(r % Hi); const long nc = r / Hi;
-        const float* __restrict__ g = gout + nc * (long)Ho * Wo;
+    const I total = (I)(NC * Hi * Wi);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
+        const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
+        const float* __restrict__ g = gout + (long)nc * Ho * Wo;
         float wy[4], wx[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -240,7 +274,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __r
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int ox = 2 * x - 1 + b;
-                if (wx[b] != 0.0f) row += wx[b] * g[(long)oy * Wo + ox];
+                if (wx[b] != 0.0f) row += wx[b] * g[oy * Wo + ox];
             }
             acc += wy[a] * row;
         }
@@ -250,47 +284,52 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __r
 
 C2M_API int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
     C2M_ENTER();
-    return c2m_resize_bilinear(in, out, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, stream);
+    const long total = NC * Hi * Wi;
+    if (total <= 0) return 0;
+    if ((((uintptr_t)out) & 7) != 0) return c2m_resize_bilinear(in, out, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, stream);
+    C2M_IDX_DISPATCH(total * 4, upsample2x_fwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi);
+    return (int)hipGetLastError();
 }
 
 C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gout, gin,
-                       NC, Hi, Wi);
+    C2M_IDX_DISPATCH(total * 4, upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, gout, gin, NC, Hi, Wi);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------- maxpool 2x2 / 2
+template <typename I>
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi) {
     const int Ho = Hi / 2, Wo = Wi / 2;
-    const long total = NC * Ho * Wo;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % Wo); const long r = i / Wo;
-        const int oy = (int)(r % Ho); const long nc = r / Ho;
-        const float* __restrict__ p = in + nc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+    const I total = (I)(NC * Ho * Wo);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
+        const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
+        const float* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
         out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Wi], p[Wi + 1]));
     }
 }
 
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
+template <typename I>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                     float* __restrict__ gin, long NC, int Hi, int Wi) {
     const int Ho = Hi / 2, Wo = Wi / 2;
-    const long total = NC * Hi * Wi;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % Wi); const long r = i / Wi;
-        const int y = (int)(r % Hi); const long nc = r / Hi;
+    const I total = (I)(NC * Hi * Wi);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
+        const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
         const int oy = y / 2, ox = x / 2;
         float g = 0.0f;
         if (oy < Ho && ox < Wo) {
-            const float* __restrict__ p = in + nc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+            const float* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
             const float v[4] = {p[0], p[1], p[Wi], p[Wi + 1]};
             int arg = 0; float m = v[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
-            if (arg == (y & 1) * 2 + (x & 1)) g = gout[nc * (long)Ho * Wo + (long)oy * Wo + ox];
+            if (arg == (y & 1) * 2 + (x & 1)) g = gout[(long)nc * Ho * Wo + oy * Wo + ox];
         }
         gin[i] = g;
     }
@@ -300,8 +339,7 @@ C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int
     C2M_ENTER();
     const long total = NC * (Hi / 2) * (Wi / 2);
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, NC,
-                       Hi, Wi);
+    C2M_IDX_DISPATCH(NC * Hi * Wi, maxpool2_fwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi);
     return (int)hipGetLastError();
 }
 
@@ -309,8 +347,7 @@ C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, l
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, gout, gin,
-                       NC, Hi, Wi);
+    C2M_IDX_DISPATCH(total, maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
     return (int)hipGetLastError();
 }
 

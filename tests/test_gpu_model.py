@@ -239,14 +239,19 @@ def test_full_width_step_vs_oracle():
     assert set(og) == set(gg)
     rms = sorted((og[k].double().norm().item() / og[k].numel() ** 0.5) for k in og)
     noise = 1e-3 * rms[len(rms) // 2]               # analytically-zero gradients are rounding noise below this rms
-    worst = 0.0
+    rel = []
     for k in og:
         a, b = gg[k].cpu().double(), og[k].double()
         err = (a - b).norm().item()
-        allowed = 5e-3 * b.norm().item() + noise * b.numel() ** 0.5
-        worst = max(worst, err / max(b.norm().item(), noise * b.numel() ** 0.5))
-        assert err <= allowed, f"grad {k}: L2 err {err:.3e} > allowed {allowed:.3e} (ref norm {b.norm().item():.3e})"
-    print(f"worst relative gradient error: {worst:.2e}")
+        # 1e-2: the fp32 oracle itself differs from the same graph evaluated in fp64 by 2e-3..4e-3 on the keys deepest in
+        # the backward pass (flowembedder.conv_first, generator.middle.3; median 6.6e-4) -- tests/diag_fp64_sensitivity.py
+        rel.append((err / (1e-2 * b.norm().item() + noise * b.numel() ** 0.5), k, err / max(b.norm().item(), 1e-30)))
+    rel.sort(reverse=True)
+    real = sorted(r for _, k, r in rel if og[k].double().norm().item() > 10 * noise * og[k].numel() ** 0.5)
+    assert len(real) > 200 and real[len(real) // 2] < 2e-3, f"median relative gradient error {real[len(real) // 2]:.2e}"
+    print("gradient error / allowance (1e-2 * |ref| + noise floor):", [(f"{e:.2f}", k, f"{r:.1e}") for e, k, r in rel[:8]],
+          "median", f"{rel[len(rel) // 2][0]:.2f}")
+    assert rel[0][0] <= 1.0, f"worst gradients (error / allowance, key, relative error): {rel[:5]}"
 
 
 def test_step_is_deterministic():
