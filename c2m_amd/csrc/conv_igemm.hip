@@ -862,24 +862,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 // db[m] = sum_s slab[s][m][ones_col]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, float* __restrict__ db,
                                     int M, int J, int Cin, int taps, int NS, int ntg, int ngroups, int S) {
+    // threads run over the slab's own (m, column) order, so the S reads per output are coalesced; the (single) write
+    // per output is the scattered one
     const int CK = 16 / NS;
-    const int per_m = Cin * taps + 1;
-    const long total = (long)M * per_m;
+    const int used = (ngroups + 1) * 16;                  // real groups + the ones group; pad columns are skipped
+    const long total = (long)M * used;
     const long per = (long)M * J;
-    const int ones_col = ngroups * 16;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / per_m);
-        const int q = (int)(i % per_m);
-        int col;
-        if (q == Cin * taps) col = ones_col;
-        else {
-            const int c = q / taps, tap = q % taps;
-            col = ((c / CK) * ntg + tap / NS) * 16 + (tap % NS) * CK + c % CK;
+        const int m = (int)(i / used);
+        const int col = (int)(i - (long)m * used);
+        const int g = col >> 4, within = col & 15;
+        long dst = -1;                                     // -1: padding, -2: bias gradient
+        if (g == ngroups) {
+            if (within == 0) dst = -2;
+        } else {
+            const int c = (g / ntg) * CK + within % CK, tap = (g % ntg) * NS + within / CK;
+            if (c < Cin && tap < taps) dst = ((long)m * Cin + c) * taps + tap;
         }
+        if (dst == -1) continue;
         float acc = 0.f;
         for (int s = 0; s < S; ++s) acc += slab[(long)s * per + (long)m * J + col];
-        if (q == Cin * taps) { if (db) db[m] = acc; }
-        else dW[(long)m * Cin * taps + q] = acc;
+        if (dst == -2) { if (db) db[m] = acc; }
+        else dW[dst] = acc;
     }
 }
 
@@ -1105,7 +1109,7 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
 #undef C2M_THIN_W
         int rc2 = (int)hipGetLastError();
         if (rc2) return rc2;
-        const long total2 = (long)p.M * (Cin * taps + 1);
+        const long total2 = (long)p.M * (ngroups + 1) * 16;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total2, 256)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
                            taps, NS, ntg, ngroups, Sthin);
         return (int)hipGetLastError();
@@ -1129,7 +1133,7 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
 #undef C2M_WG
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    const long total = (long)p.M * (Cin * taps + 1);
+    const long total = (long)p.M * (ngroups + 1) * 16;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
                        taps, NS, ntg, ngroups, Seff);
     return (int)hipGetLastError();
@@ -1272,26 +1276,34 @@ C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int 
 //   with tap = (at, ay, ax) over (At, Ay, Ax) = (KT/st, KH/sh, KW/sw) and cls = (rt, ry, rx) over (st, sh, sw).
 // Forward: st = sh = sw = 1, s_m = C*taps, s_c = taps.  Data gradient (rows = input channels, K = output channels,
 // one class per stride parity): s_m = taps_full, s_c = M*taps_full.  Padding (c >= C or tap >= taps) is written as 0.
-struct PackP { int M, C, CK, NS, nch, ntg, At, Ay, Ax, st, sh, sw, KH, KW; long s_m, s_c, total; };
+struct PackP { int M, C, CK, NS, nch, ntg, At, Ay, Ax, st, sh, sw, KH, KW; long s_m, s_c; };
 
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, const PackP q) {
+// one workgroup row per packed row r = cls*M + m (blockIdx.y); the per-tap source offsets of the row's parity class are
+// computed once into LDS, CK / NS are powers of two: one integer division (by ntg) per element remains
+template <int CK>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                            const PackP q) {
+    constexpr int NS = 16 / CK, LCK = CK == 16 ? 4 : (CK == 8 ? 3 : 2), LNS = 4 - LCK;
+    __shared__ int toff[128];
     const int taps = q.At * q.Ay * q.Ax;
     const int lda = q.nch * q.ntg * 16;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < q.total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % lda); const int r = (int)(i / lda);
-        const int ch = k % q.CK; int t = k / q.CK;
-        const int slot = t % q.NS; t /= q.NS;
-        const int tg = t % q.ntg; const int chunk = t / q.ntg;
-        const int c = chunk * q.CK + ch, tap = tg * q.NS + slot;
-        float v = 0.f;
-        if (c < q.C && tap < taps) {
-            const int m = r % q.M; int cls = r / q.M;
-            const int rx = cls % q.sw; cls /= q.sw;
-            const int ry = cls % q.sh; const int rt = cls / q.sh;
-            const int ax = tap % q.Ax; const int ay = (tap / q.Ax) % q.Ay; const int at = tap / (q.Ax * q.Ay);
-            v = w[m * q.s_m + c * q.s_c + ((long)(at * q.st + rt) * q.KH + (ay * q.sh + ry)) * q.KW + (ax * q.sw + rx)];
-        }
-        out[i] = v;
+    const int r = blockIdx.y;
+    const int m = r % q.M; int cls = r / q.M;
+    const int rx = cls % q.sw; cls /= q.sw;
+    const int ry = cls % q.sh; const int rt = cls / q.sh;
+    for (int tap = threadIdx.x; tap < taps; tap += 256) {
+        const int ax = tap % q.Ax; const int ay = (tap / q.Ax) % q.Ay; const int at = tap / (q.Ax * q.Ay);
+        toff[tap] = ((at * q.st + rt) * q.KH + (ay * q.sh + ry)) * q.KW + (ax * q.sw + rx);
+    }
+    __syncthreads();
+    const float* __restrict__ wr = w + m * q.s_m;
+    float* __restrict__ orow = out + (long)r * lda;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < lda; k += gridDim.x * 256) {
+        const int ch = k & (CK - 1); int t = k >> LCK;
+        const int slot = t & (NS - 1); t >>= LNS;
+        const int chunk = t / q.ntg, tg = t - chunk * q.ntg;
+        const int c = chunk * CK + ch, tap = tg * NS + slot;
+        orow[k] = (c < q.C && tap < taps) ? wr[c * q.s_c + toff[tap]] : 0.f;
     }
 }
 
@@ -1310,7 +1322,12 @@ C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void*
     q.NS = 16 / q.CK;
     q.At = KT / q.st; q.Ay = q.KH / q.sh; q.Ax = q.KW / q.sw;
     q.nch = c2m_cdiv(q.C, q.CK); q.ntg = c2m_cdiv(q.At * q.Ay * q.Ax, q.NS);
-    q.total = (long)q.st * q.sh * q.sw * q.M * q.nch * q.ntg * 16;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(c2m_grid(q.total, 256)), dim3(256), 0, (hipStream_t)stream, w, out, q);
+    const long rows = (long)q.st * q.sh * q.sw * q.M;
+    const int lda = q.nch * q.ntg * 16;
+    if (q.At * q.Ay * q.Ax > 128 || rows > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid(c2m_cdiv(lda, 1024) < 1 ? 1 : c2m_cdiv(lda, 1024), (unsigned)rows);
+    if (q.CK == 16)     hipLaunchKernelGGL((pack_weights_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
+    else if (q.CK == 8) hipLaunchKernelGGL((pack_weights_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
+    else                hipLaunchKernelGGL((pack_weights_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
     return (int)hipGetLastError();
 }
