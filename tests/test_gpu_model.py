@@ -309,3 +309,20 @@ def test_inference_vs_golden(name):
     for k, ref in c.group("sum.buf").items():           # inference must not touch the running statistics
         close(torch.from_numpy(summarize(bufs[k].cpu())), ref, 1e-6, 1e-7, f"buf {k}")
     assert not model.motion_encoder.sparse_motion_estimator.training, "inference leaves the GNN in eval mode (model.py:249)"
+
+
+def test_nan_in_theta_losses_raises_value_error():
+    """Error behaviour kept (reference utils.py:375-379 via losses.py:244-250): a NaN theta loss raises ValueError out of
+    the forward, before any backward / optimizer step."""
+    c = Case("e2e_tin1_nospade_pred")
+    cfg, model, batch = _model_and_batch(c)
+    batch["tracking_gnn"].targets_theta[0, 0, 2] = float("nan")
+    with pytest.raises(ValueError):
+        model(batch)
+    step = TrainStep(model, run_optimizers=True, distributed=False)
+    before = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith(
+        ("running_mean", "running_var", "num_batches_tracked", "weight_u", "weight_v"))}
+    with pytest.raises(ValueError):
+        step(batch)
+    for k, v in before.items():                   # the optimizers must not have stepped on a NaN loss
+        assert torch.equal(model.state_dict()[k], v), k
