@@ -50,7 +50,11 @@ def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_pred
     instance = torch.zeros(B, 1, T, H, W, dtype=torch.int32)
     xs, thetas, rois, ids, batch_vec, edges = [], [], [], [], [], []
     node0 = 0
+    per_sample = [int(num_objects)] * B if isinstance(num_objects, int) else [int(n) for n in num_objects]
+    if len(per_sample) != B or min(per_sample) < 1:
+        raise ValueError("num_objects: an int or one count >= 1 per sample (ragged graphs are allowed)")
     for b in range(B):
+        num_objects = per_sample[b]
         for n in range(num_objects):
             x0 = int(round((20 + 60 * n) * sx))
             y0 = int(round((40 + 10 * n) * sy))
@@ -82,8 +86,8 @@ def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_pred
         x=torch.stack(xs, 0), targets_theta=torch.stack(thetas, 0),
         edge_index=torch.tensor(edges, dtype=torch.long).t().contiguous(),
         batch=torch.tensor(batch_vec, dtype=torch.long),
-        num_real_nodes=torch.full((B,), num_objects, dtype=torch.int32),
-        num_nodes=B * num_objects,
+        num_real_nodes=torch.tensor(per_sample, dtype=torch.int32),
+        num_nodes=sum(per_sample),
         source_frames_nodes_roi_padded=torch.stack(rois, 0),
         source_frames_nodes_instance_ids=torch.stack(ids, 0))
 

@@ -326,3 +326,31 @@ def test_nan_in_theta_losses_raises_value_error():
         step(batch)
     for k, v in before.items():                   # the optimizers must not have stepped on a NaN loss
         assert torch.equal(model.state_dict()[k], v), k
+
+
+def test_ragged_graph_batch_step_vs_oracle():
+    """Samples with different object counts (1, 3 and 2 nodes; the 1-node sample has no edges at all): whole tiny-config
+    step, product vs oracle -- exercises the per-node batch index in roi_align / raster / GNN softmax."""
+    cfg = normalize_config(default_config(num_input_frames=2, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
+                                          out_channel=16, ndf=4, use_spade=True, use_image_discriminator=False,
+                                          use_video_discriminator=False))
+    torch.manual_seed(3)
+    model = GeneratorFullModel(train_params=copy.deepcopy(cfg["train_params"]),
+                               model_params=copy.deepcopy(cfg["model_params"]), dataset="cityscapes")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = make_batch(3, 128, 256, 2, num_objects=[1, 3, 2], seed=9)
+    rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=1)
+    S = O.State(sd)
+    ob = dict(batch)
+    ob["tracking_gnn"] = batch["tracking_gnn"].clone()
+    oo, olg, _, _ = O.forward(S, cfg, ob, rng)
+    model.to(DEV).train()
+    gb = batch_to(batch, DEV)
+    gb["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+    out, lg, _ = TrainStep(model, run_optimizers=False, distributed=False)(gb)
+    for k, v in olg.items():
+        close(lg[k], v, 2e-4, 1e-6, f"loss {k}")
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw", "sparse_motion_bw"):
+        assert torch.equal(out[k].cpu(), oo[k]), k
+    for t in range(5):
+        close(out[f"theta_{t}"], oo[f"theta_{t}"], 1e-4, 1e-5, f"theta_{t}")

@@ -435,3 +435,60 @@ def test_roi_align_vs_oracle():
     (y * g(go)).sum().backward()
     close(y, yr, 1e-4, 1e-5, "roi_align fwd")
     close(fg.grad, fr.grad, 1e-4, 1e-5, "roi_align bwd")
+
+
+# ----------------------------------------------------------------------------------------------- edge cases
+def test_sparse_raster_without_objects_and_with_background_id():
+    """No nodes at all, and nodes whose instance id is 0 (the reference skips id 0: dense_motion.py:103-106)."""
+    inst = torch.zeros(2, 16, 32)
+    inst[1, 4:9, 5:20] = 26001.0
+    bw, fw, binm = ops.sparse_raster(g(inst), torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long),
+                                     g(torch.zeros(0, 5, 6)))
+    assert bw.shape == (2, 2, 5, 16, 32) and not bw.any() and not fw.any() and not binm.any()
+    theta = torch.tensor([1.0, 0.0, 0.1, 0.0, 1.0, 0.05]).repeat(2, 5, 1)
+    ids, batch = torch.tensor([0, 26001]), torch.tensor([0, 1])
+    bw, fw, binm = ops.sparse_raster(g(inst), ids, batch, g(theta))
+    assert not binm[0].any() and binm[1].any(), "id 0 must be skipped, the real object rasterised"
+    lib = oracle_build.load()
+    ref = [np.zeros(s, np.float32) for s in ((2, 2, 5, 16, 32), (2, 2, 5, 16, 32), (2, 1, 5, 16, 32))]
+    i64 = lambda t: np.ascontiguousarray(t.numpy().astype(np.int64))
+    a_inst, a_ids, a_b, a_th = inst.numpy(), i64(ids), i64(batch), np.ascontiguousarray(theta.numpy())
+    scratch = np.zeros(4 * 16 * 32, np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.oc_sparse_raster(vp(a_inst), vp(a_ids), vp(a_b), vp(a_th), vp(ref[0]), vp(ref[1]), vp(ref[2]), vp(scratch),
+                         2, 2, 5, 16, 32, oracle_build.FMA_MODE)
+    assert np.array_equal(bw.cpu().numpy(), ref[0]) and np.array_equal(fw.cpu().numpy(), ref[1])
+    assert np.array_equal(binm.cpu().numpy(), ref[2])
+
+
+def test_occlusion_splat_everything_leaves_the_frame():
+    flow = torch.full((2, 2, 8, 16), 1000.0)
+    occ, clip = ops.occlusion_splat(g(flow), want_map=True, want_clip=True)
+    assert not occ.any() and not clip.any()
+    occ0, _ = ops.occlusion_splat(g(torch.zeros(1, 2, 8, 16)))       # zero flow: every pixel lands on itself
+    assert torch.equal(occ0.cpu(), torch.ones(1, 1, 8, 16))
+
+
+def test_roi_align_without_boxes():
+    feat = g(rnd(1, 2, 4, 8, 8)).requires_grad_(True)
+    y = ops.roi_align(feat, g(torch.zeros(0, 5)), 7, spatial_scale=0.25)
+    assert y.shape == (0, 4, 7, 7)
+    y.sum().backward()
+    assert feat.grad is not None and not feat.grad.any()
+
+
+@pytest.mark.parametrize("xs,cout,k,pad", [((2, 8, 1, 1), 5, 1, 0), ((3, 4, 1, 1), 6, 3, 1), ((1, 1, 2, 2), 1, 3, 1),
+                                            ((1, 3, 1, 40), 2, 3, 1)])
+def test_conv_degenerate_extents(xs, cout, k, pad):
+    x, w, b = rnd(1, *xs), rnd(2, cout, xs[1], k, k, scale=0.3), rnd(3, cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, padding=pad)
+    go = rnd(4, *yr.shape)
+    (yr * go).sum().backward()
+    xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv(xg, wg, bg, stride=1, padding=pad)
+    (y * g(go)).sum().backward()
+    rel_close(y, yr, 2e-5, "fwd")
+    rel_close(xg.grad, xr.grad, 5e-5, "dgrad")
+    rel_close(wg.grad, wr.grad, 1e-4, "wgrad")
+    rel_close(bg.grad, br.grad, 1e-4, "bias grad")
