@@ -31,15 +31,22 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  * K order: (channel chunk, tap group, tap slot, channel in chunk); one 16-deep K-step = NS taps x CK channels.
  * ktab: nk groups of (1 + NS) int4: header {channel_offset, nvalid_channels (-2: ones row), 0, 0} then NS taps
  *       {dt, dy, dx, valid}; A is the weight matrix packed by the host into the same order ([M][nk*16]).
- * geom[] (int64, 32 entries):
+ * geom[] (int64; 64 entries, 96 when parity classes are batched):
  *   0 M   1 nk (K-steps; for wgrad: J rows)   2 lda   3 Npix = N*To*Ho*Wo   4 To 5 Ho 6 Wo   7 Ti 8 Hi 9 Wi
  *   10 st 11 sh 12 sw (input coord = o*stride + tap offset)   13 in_sn 14 in_st 15 in_sh (elements; w stride 1)
  *   16 out_sn 17 out_sc 18 out_st 19 out_sh 20 out_sw 21 out_off   22 reflect (0 zeros / 1 reflect) 23 is3d
  *   24 NS (1, 2 or 4)   25 in_sc (channel stride)   26 splits (from c2m_conv_igemm_splits, or 1)
  *   27 slab_stride (elements between split-K slabs)   28 Cin 29 taps 30 tap groups per chunk 31 real groups (wgrad)
- *   32 x_bytes 33 dy_bytes (wgrad)   36..51 two-target epilogue (reflect-pad dgrad, Y_interior != NULL): padded
- *   coordinate = o*ps + po per dim (36-38 ps, 39-41 po); outputs inside [lo, lo+ext) (42-44 lo, 45-47 ext) are stored
- *   to Y_interior with strides 48 sn 49 sc 50 st 51 sh, the pad ring to Y; c2m_reflect_border_add then folds the ring.
+ *   32 x_bytes 33 dy_bytes (wgrad; buffer-load bounds, < 2 GiB)
+ *   34 operand precision: 0 = fp32 (exact v_mfma_f32_32x32x2_f32), 1 = bf16 operands rounded RNE while staged, fp32
+ *      accumulation (v_mfma_f32_32x32x16_bf16); tensors in memory are fp32 in both modes
+ *   36..51 two-target epilogue (reflect-pad dgrad, Y_interior != NULL): padded coordinate = o*ps + po per dim
+ *      (36-38 ps, 39-41 po); outputs inside [lo, lo+ext) (42-44 lo, 45-47 ext) are stored to Y_interior with strides
+ *      48 sn 49 sc 50 st 51 sh, the pad ring to Y; c2m_reflect_border_add then folds the ring.
+ *   52 LDS-patch kernel (3x3, stride 1, fp32): 1 = on; 53 iy0 54 ix0 input origin of an output tile relative to its
+ *      first output; 55-57 / 58-60 patch row / column of tap row / column 0,1,2 ((0,1,2) forward, (2,1,0) dgrad)
+ *   61 ncls: stride parity classes batched into this launch (blockIdx.z = class*splits + split); 62 floats per class
+ *      weight matrix, 63 int4 entries per class tap table, 64+c out_off of class c, 72+3c.. its (po_t, po_y, po_x)
  * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
  * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
 int c2m_conv_igemm_splits(int M, int nk, int Npix);
