@@ -135,6 +135,15 @@ int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int
 int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,
                  void* stream);
 
+/* ---- input pipeline stage upstream of the path (data_prep.hip): SURVEY §8f-3 -------------------------------------
+ * src/datasets/cityscapes.py:30-70 (ToTensor of frames, label-id one-hot split 0..10 / 11..19), :212-265 (occlusion
+ * PNG -> clip_mask, .flo HWC -> CHW): decoded uint8 / float arrays in, the batch-dict tensors of model.py:124 out.  */
+int c2m_prep_video(const uint8_t* frames_bthwc, float* video_bcthw, int B, int T, int H, int W, void* stream);
+int c2m_prep_seg_onehot(const uint8_t* labels_bthw, float* bg_mask, float* fg_mask, int B, int T, int H, int W,
+                        void* stream);
+int c2m_prep_flow_occ(const uint8_t* occ_bthw, const float* flow_bthwc, float* occ_out, float* flow_out, int B, int T,
+                      int H, int W, void* stream);
+
 /* ---- optimizer (optim.hip): SURVEY §8f-1 --------------------------------------------------------------------
  * The four torch.optim.Adam(betas=(0.5,0.999), eps=1e-7) of modules/model.py:54-99, stepped at trainer/trainer.py:155-165:
  * one launch per parameter group.  table = device int64 [4][ntensors] {param, grad, exp_avg, exp_avg_sq} pointers,

@@ -1,0 +1,72 @@
+"""Device-side batch assembly vs the CPU restatement of the reference's dataset arithmetic: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from c2m_amd import data
+from c2m_amd.config import default_config, normalize_config
+from c2m_amd.modules.model import GeneratorFullModel
+from c2m_amd.synthetic import make_batch
+from oracle import data_prep as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _arrays(B, T, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    frames = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 34, (B, T, H, W), generator=g, dtype=torch.uint8)       # ids >= 20 belong to no channel
+    n = min(20, W)
+    labels[0, 0, 0, :n] = torch.arange(n, dtype=torch.uint8)
+    occ = (torch.randint(0, 2, (B, T, H, W), generator=g) * 255).to(torch.uint8)
+    occ[0, 0, 0, :4] = torch.tensor([127, 128, 0, 255], dtype=torch.uint8)            # around the 0.5 threshold (W >= 4)
+    flow = torch.randn(B, T, H, W, 2, generator=g) * 3.0
+    return frames, labels, occ, flow
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 16, 32), (1, 1, 5, 7), (3, 5, 33, 17)])
+def test_prep_kernels_bitexact_vs_oracle(shape):
+    B, T, H, W = shape
+    frames, labels, occ, flow = _arrays(B, T, H, W, 5)
+    video = data.prep_video(frames.to(DEV)).cpu()
+    bg, fg = (t.cpu() for t in data.prep_seg_onehot(labels.to(DEV)))
+    o, f = (t.cpu() for t in data.prep_flow_occ(occ.to(DEV), flow.to(DEV)))
+    for b in range(B):
+        assert torch.equal(video[b], D.read_video(frames[b].numpy()))
+        rbg, rfg = D.read_seg_masks(labels[b].numpy())
+        assert torch.equal(bg[b], rbg) and torch.equal(fg[b], rfg)
+        ro, rf = D.load_flow_occ(occ[b].numpy(), flow[b].numpy())
+        assert torch.equal(o[b], ro) and torch.equal(f[b], rf)
+    assert float(bg.sum() + fg.sum()) == float((labels < 20).sum()), "exactly one channel per pixel with an id < 20"
+
+
+def test_prep_rejects_wrong_inputs_and_empty_batch():
+    with pytest.raises(TypeError):
+        data.prep_video(torch.zeros(1, 1, 4, 4, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        data.prep_video(torch.zeros(1, 1, 4, 4, 3, dtype=torch.uint8))          # not on the device: no CPU path
+    assert data.prep_video(torch.zeros(0, 7, 4, 4, 3, dtype=torch.uint8, device=DEV)).shape == (0, 3, 7, 4, 4)
+
+
+def test_assembled_batch_drives_the_model():
+    """A batch assembled on the device from uint8 arrays feeds GeneratorFullModel.forward like the synthetic one."""
+    B, T, H, W = 1, 7, 128, 256
+    frames, labels, occ, flow = _arrays(B, T, H, W, 11)
+    labels = labels % 20
+    ref = make_batch(B, H, W, 2, seed=2)
+    gnn = ref["tracking_gnn"]
+    inst = ref["instance_mask"][:, 0]
+    batch = data.assemble_batch(frames.to(DEV), labels.to(DEV), inst.to(DEV), occ[:, 2:].to(DEV), flow[:, 2:].to(DEV),
+                                gnn.to(DEV) if hasattr(gnn, "to") else gnn, occ[:, 1:2].to(DEV), flow[:, 1:2].to(DEV))
+    for k in ("video", "bg_mask", "fg_mask", "instance_mask", "target_bw_of", "target_bw_occ", "input_of", "input_occ"):
+        assert tuple(batch[k].shape) == tuple(ref[k].shape) and batch[k].dtype == ref[k].dtype, k
+    cfg = normalize_config(default_config(num_input_frames=2, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
+                                          out_channel=16, ndf=4, use_image_discriminator=False,
+                                          use_video_discriminator=False))
+    torch.manual_seed(0)
+    model = GeneratorFullModel(train_params=cfg["train_params"], model_params=cfg["model_params"], dataset="cityscapes")
+    model.to(DEV).train()
+    out, lg, _, _ = model(batch)
+    assert all(np.isfinite(float(v.detach()) if torch.is_tensor(v) else float(v)) for v in lg.values())
+    assert out["generated"].shape == (B, 3, 5, H, W)
