@@ -18,7 +18,16 @@ LRELU_SLOPE = 0.2
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream of the current device as a raw handle (torch.cuda.current_stream() costs ~9 us of
+    Python per call -- 500 calls per step; the private raw getter is the same lookup without the Stream object)."""
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+if _raw_stream is None or _cur_device is None:          # older / newer torch without the private getters
+    _raw_stream = lambda idx: torch.cuda.current_stream(idx).cuda_stream
+    _cur_device = torch.cuda.current_device
 
 
 def _p(t):
