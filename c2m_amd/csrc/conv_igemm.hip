@@ -553,6 +553,7 @@ __global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, float4
 }
 
 template <int NS> static int launch_thin_fwd(const ConvP& p, hipStream_t s);
+template <int KW> static int launch_thin_rows(const ConvP& p, int ns, int ntg, int Cin, int xdesc, hipStream_t s);
 
 #ifndef C2M_IGEMM_U
 #define C2M_IGEMM_U 1
@@ -664,6 +665,13 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         else                return launch_patch<128, 128, 2, 2>(p, splits, s);
     }
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2 && p.ncls == 1) {      // thin output: vector-ALU kernel
+        // g[35] = +-KW: 2-D stride-1 square KW x KW tap set in row-major order (dx ascending / descending)
+        const int kw = (int)(g[35] < 0 ? -g[35] : g[35]);
+        if ((kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
+            g[29] == kw * kw && g[28] > 0 && g[28] * kw * kw * 16 <= 48 * 1024) {
+            if (kw == 3) return launch_thin_rows<3>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
+            return launch_thin_rows<7>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
+        }
         if (ns == 1) return launch_thin_fwd<1>(p, s);
         if (ns == 2) return launch_thin_fwd<2>(p, s);
         return launch_thin_fwd<4>(p, s);
@@ -937,6 +945,117 @@ __global__ __launch_bounds__(256) void conv_thin_fwd_kernel(const ConvP p) {
             }
         }
     }
+}
+
+// Row-blocked form for 2-D stride-1 square kernels (the 7x7 RGB head, the 3x3 flow / occlusion heads, the data gradient
+// of the first VGG conv): each lane computes PX = 4 horizontally adjacent outputs, so one gathered input row segment of
+// PX + KW - 1 values feeds PX * KW taps -- 2.8x (7x7) / 2x (3x3) fewer loads per FMA than the per-pixel kernel above,
+// which is bound by load issue.  Tap geometry comes from the same K-step table (row-major taps, dx ascending for the
+// forward pass, descending for a data gradient), weights from the same packed matrix through scalar loads.
+template <int MT, int KW>
+__global__ __launch_bounds__(256) void conv_thin_rows_kernel(const ConvP p, int lns, int ntg, int Cin, int xdesc) {
+    constexpr int PX = 4, NV = PX + KW - 1;
+    extern __shared__ float4 sW[];                        // [c][i][j] -> weights of the (<= 4) output rows
+    const int NS = 1 << lns, CK = 16 >> lns, lck = 4 - lns;
+    auto tap_entry = [&](int t) { return p.ktab[(t >> lns) * (1 + NS) + 1 + (t & (NS - 1))]; };   // chunk 0's taps
+    for (int e = threadIdx.x; e < Cin * KW * KW; e += 256) {
+        const int c = e / (KW * KW), t = e - c * (KW * KW);
+        const int k = (((c >> lck) * ntg + (t >> lns)) << 4) + ((t & (NS - 1)) << lck) + (c & (CK - 1));
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) w[m] = p.A[(long)m * p.lda + k];
+        sW[e] = make_float4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const int groups_x = p.Wo / PX;
+    const int total = p.Npix / PX;
+    const int dx_first = tap_entry(0).z, dx_last = tap_entry(KW - 1).z;
+    const int lo = dx_first < dx_last ? dx_first : dx_last;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+        const int xg = g % groups_x; int r = g / groups_x;
+        const int oy = r % p.Ho; const int n = r / p.Ho;
+        const int ox0 = xg * PX;
+        const unsigned img_byte = (unsigned)(n * (int)p.in_sn) * 4u;
+        float acc[MT][PX];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) acc[m][q] = 0.f;
+        unsigned cvo[NV];                                  // column byte offsets of this lane's NV inputs
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            int ix = ox0 + lo + e;
+            bool ok = true;
+            if (p.reflect) { ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix; }
+            else ok = (unsigned)ix < (unsigned)p.Wi;
+            cvo[e] = ok ? (unsigned)ix * 4u : C2M_OOB;
+        }
+        for (int i = 0; i < KW; ++i) {                    // tap rows (square kernel)
+            int iy = oy + tap_entry(i * KW).y;
+            bool rok = true;
+            if (p.reflect) { iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy; }
+            else rok = (unsigned)iy < (unsigned)p.Hi;
+            const unsigned rbase = img_byte + (unsigned)(iy * (int)p.in_sh) * 4u;
+            unsigned vo[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) vo[e] = (rok && cvo[e] != C2M_OOB) ? rbase + cvo[e] : C2M_OOB;
+            const float4* __restrict__ wrow = sW + i * KW;
+            for (int c = 0; c < Cin; ++c) {
+                float v[NV];
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[e], c * p.in_sc * 4, 0));
+#pragma unroll
+                for (int j = 0; j < KW; ++j) {
+                    const float4 w4 = wrow[c * (KW * KW) + j];          // same address in every lane: LDS broadcast
+                    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+                    const int pos = xdesc ? KW - 1 - j : j;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < PX; ++q) acc[m][q] = fmaf(v[q + pos], wv[m], acc[m][q]);
+                }
+            }
+        }
+        float* __restrict__ yb = p.Y + p.out_off + (long)n * p.out_sn + (long)oy * p.out_sh + (long)ox0 * p.out_sw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < p.M) {
+                float o[PX];
+#pragma unroll
+                for (int q = 0; q < PX; ++q) {
+                    float v = acc[m][q];
+                    if (p.bias) v += p.bias[m];
+                    o[q] = c2m_act(v, p.act, p.slope);
+                }
+                float* dst = yb + (long)m * p.out_sc;
+                if (p.out_sw == 1 && (((uintptr_t)dst) & 15) == 0) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PX; ++q) dst[(long)q * p.out_sw] = o[q];
+                }
+            }
+        }
+    }
+}
+
+template <int KW>
+static int launch_thin_rows(const ConvP& p, int ns, int ntg, int Cin, int xdesc, hipStream_t s) {
+    // few, fat blocks: every block first copies the layer's weights into LDS (Cin * KW * KW float4)
+    long blocks = (p.Npix / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks);
+    const int lns = ns == 1 ? 0 : (ns == 2 ? 1 : 2);
+    const size_t lds = (size_t)Cin * KW * KW * sizeof(float4);
+    switch (p.M) {
+        case 1: hipLaunchKernelGGL((conv_thin_rows_kernel<1, KW>), grid, dim3(256), lds, s, p, lns, ntg, Cin, xdesc); break;
+        case 2: hipLaunchKernelGGL((conv_thin_rows_kernel<2, KW>), grid, dim3(256), lds, s, p, lns, ntg, Cin, xdesc); break;
+        case 3: hipLaunchKernelGGL((conv_thin_rows_kernel<3, KW>), grid, dim3(256), lds, s, p, lns, ntg, Cin, xdesc); break;
+        default: hipLaunchKernelGGL((conv_thin_rows_kernel<4, KW>), grid, dim3(256), lds, s, p, lns, ntg, Cin, xdesc); break;
+    }
+    return (int)hipGetLastError();
 }
 
 template <int NS>

@@ -164,7 +164,7 @@ def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
     """LDS-patch kernel eligibility: 3x3 (kt = 1) stride-1, whole 16-channel chunks without much padding, a grid big
     enough not to need split-K, output rows/cols that fill the (rows x 32) tile reasonably."""
     kt, kh, kw = taps3
-    if (kt, kh, kw) != (1, 3, 3) or tuple(stride) != (1, 1, 1):
+    if (kt, kh, kw) != (1, 3, 3) or tuple(stride) != (1, 1, 1) or M <= 4:      # <= 4 rows: vector-ALU kernels
         return False
     best = _ceil(C, _choose_ck(C, 9))
     if _ceil(C, 16) > 1.10 * best:
@@ -281,6 +281,9 @@ class _ConvPlan:
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
                               in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp,
                               x_bytes=4 * N * Cin * in_sc)
+        self.fwd_geom[[28, 29, 30]] = (Cin, taps, ntg)
+        if kt == 1 and kh == kw and (st, sh, sw) == (1, 1, 1):
+            self.fwd_geom[35] = kw                # row-major square tap set, dx ascending (thin row-blocked kernel)
         if self.fwd_patch:
             _set_patch(self.fwd_geom, -ph, -pw, (0, 1, 2), (0, 1, 2))
         # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
@@ -340,6 +343,9 @@ class _ConvPlan:
                                  in_sc=osp, splits=1, slab_stride=tgt_numel, x_bytes=4 * N * Cout * osp)
                     # two-target epilogue (reflect): padded coord = q*stride + r per dim; interior = [pad, pad + extent)
                     geom[36:52] = (st, sh, sw, offt, offy, offx, pt, ph, pw, Ti, Hi, Wi, Cin * in_sc, in_sc, Hi * Wi, Wi)
+                    geom[[28, 29, 30]] = (Cout, ctaps, cntg)
+                    if At == 1 and Ay == Ax and (st, sh, sw) == (1, 1, 1):
+                        geom[35] = -Ax            # data gradient: tap offsets run q - arange(A): dx descending
                     if cpatch:
                         _set_patch(geom, qy - 2, qx - 2, (2, 1, 0), (2, 1, 0))
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
