@@ -88,6 +88,8 @@ def main():
                     help="conv operand precision: f32 = BASELINE configs[1] (the bench line); bf16 = configs[2-4] mode")
     ap.add_argument("--full-step", action="store_true",
                     help="full adversarial step of BASELINE configs[2-4]: both discriminators on + the four Adam steps")
+    ap.add_argument("--check-grads", action="store_true",
+                    help="after the run, verify that every rank holds bit-identical (all-reduced) gradients")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     args = ap.parse_args()
@@ -150,6 +152,19 @@ def main():
         "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * (args.height * args.width) / (128 * 256) * 1e-3 *
                                              world * args.batch * args.steps / elapsed, 2),
     }
+    if args.check_grads:
+        # all-reduced gradients must be bit-identical on every rank although each rank saw different data
+        gsum = torch.stack([p.grad.double().abs().sum() for p in model.parameters() if p.grad is not None])
+        local = torch.stack([gsum.sum(), (gsum * torch.arange(1, gsum.numel() + 1, device=dev)).sum()]).cpu()
+        if dist.is_initialized() and world > 1:
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            same = all(torch.equal(g, gathered[0]) for g in gathered)
+        else:
+            same = True
+        if not same:
+            raise SystemExit(f"rank {rank}: gradients differ across ranks after the all-reduce")
+        result["grad_sync"] = "identical on all ranks"
     if rank == 0:
         if prof is not None:
             s = prof.summary()

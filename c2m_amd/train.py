@@ -14,11 +14,16 @@ def init_distributed():
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); backend nccl == RCCL on ROCm."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: every rank on device 0, collectives over gloo (RCCL refuses two ranks on one device);
+    # exercises the multi-rank reducer logic on HIP tensors -- never used by the real launch
+    shared = bool(os.environ.get("C2M_REHEARSAL_SHARED_GPU"))
+    if shared:
+        local_rank = 0
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     if (world > 1 or os.environ.get("C2M_FORCE_PROCESS_GROUP")) and "MASTER_ADDR" in os.environ \
             and not dist.is_initialized():
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() and not shared else "gloo")
     return int(os.environ.get("RANK", "0")), local_rank, world
 
 
