@@ -21,6 +21,9 @@ _SIGS = {
     "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
     "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
     "c2m_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "c2m_wino_upack_floats": (c_long, [c_int, c_int]),
+    "c2m_wino_filter_transform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "c2m_conv_wino": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "c2m_prep_video": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_seg_onehot": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_flow_occ": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),

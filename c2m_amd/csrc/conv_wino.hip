@@ -1,0 +1,328 @@
+// conv_wino.hip -- Winograd F(2x2, 3x3) convolution for the 3x3 stride-1 layers (VGG-19, SPADE MLPs, generator and
+// decoder blocks: layers/vgg.py:92-137, spade_block.py:47-49, residual_block.py:13-31,42-71, up_block.py:9-13 and their
+// data gradients), fp32 on v_mfma_f32_32x32x2_f32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input tile, g: 3x3 filter, Y: 2x2 outputs
+// 16 multiplies per 4 outputs instead of 36: the contraction over input channels becomes 16 independent GEMMs
+// M_xi[cout][tile] = sum_c U_xi[cout][c] * V_xi[c][tile] with 2.25x fewer MFMA FLOPs than the direct form.  The input
+// transform uses only +-1 coefficients, the filter transform 1/2 and 1/4 (exact scalings), so the result differs from
+// the direct fp32 convolution by a few ulp of the partial sums (tests: 2e-5 of the tensor scale, like the direct kernels).
+//
+// One workgroup = 64 output channels x an 8x16 output region (32 Winograd tiles) of one image; 4 waves, wave w owns the
+// transformed row i = w (xi = 4w .. 4w+3) for all 64 x 32 outputs: 4 xi x 2 row-tiles x 16 = 128 accumulator registers.
+// Per 8-channel chunk: the (8 x 10 x 18) input patch arrives by LDS-DMA (double buffered), 256 threads transform one
+// (channel, tile) each into V[xi][k][tile] in LDS, the U fragments come straight from global memory in a pre-packed,
+// per-lane-contiguous order (c2m_wino_filter_transform), 32 MFMAs per wave.  The inverse transform is split: the column
+// combination (over j) happens in registers, the row combination (over i = waves) through LDS in the epilogue, which also
+// applies bias + activation and writes coalesced NCHW rows.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define WINO_OOB 0x80000000u
+
+struct WinoP {
+    const float* U;      // packed filter transform (see wino_filter_kernel)
+    const float* X;
+    float* Y;
+    const float* bias;
+    int M, K, nimg;      // output channels (rows), input channels, images
+    int Hi, Wi, Ho, Wo;
+    int iy0, ix0;        // input row/col of output (0,0)'s first tap (= -pad forward; see host for the data gradient)
+    int reflect;
+    long in_sn, out_sn, out_sc, out_sh, out_off;
+    int in_sc, in_sh;
+    unsigned x_bytes;
+    int nchunks, mtiles;
+    int act;
+    float slope;
+};
+
+constexpr int WR = 8, WC = 16;               // output region rows / cols
+constexpr int PH = WR + 2, PW = WC + 2;      // input patch
+constexpr int CKW = 8;                       // channels per chunk
+constexpr int PELEMS = CKW * PH * PW;        // 1440
+constexpr int PLOADS = (PELEMS + 255) / 256; // 6
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
+    __shared__ float sP[3][PLOADS * 256];           // input patch [k][PH][PW], filled by LDS-DMA two chunks ahead
+    __shared__ float sV[2 * 16 * CKW * 32];         // V[buf][xi][k][tile] (double buffered); reused by the epilogue
+#ifdef WINO_OCC1
+    __shared__ float sDummy[20000];
+    if (threadIdx.x == 999) sDummy[p.M] = 1.f;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int regions_x = (p.Wo + WC - 1) / WC, regions_y = (p.Ho + WR - 1) / WR;
+    int rb = blockIdx.x;
+    const int rx = rb % regions_x; rb /= regions_x;
+    const int ry = rb % regions_y; const int img = rb / regions_y;
+    const int oy0 = ry * WR, ox0 = rx * WC;
+    const int mt = blockIdx.y;
+
+    // ---- patch addresses of this thread (fixed over the K loop)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const unsigned img_byte = (unsigned)(img * (int)p.in_sn) * 4u;
+    unsigned pvo[PLOADS];
+#pragma unroll
+    for (int i = 0; i < PLOADS; ++i) {
+        const int e = tid + i * 256;
+        const int k = e / (PH * PW), r = (e % (PH * PW)) / PW, c = e % PW;
+        int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + c;
+        if (p.reflect) {
+            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+        }
+        const bool ok = e < PELEMS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        pvo[i] = ok ? img_byte + (unsigned)(k * p.in_sc + iy * p.in_sh + ix) * 4u : WINO_OOB;
+    }
+    // The LDS-DMA is issued through inline asm and TWO chunks ahead (three patch buffers).  hipcc makes the first MFMA
+    // after an LDS-DMA wait until every VMEM operation older than the U-fragment loads has completed; with the builtin and
+    // a one-chunk-ahead prefetch that put the whole DMA latency in front of the MFMAs (40 % MFMA utilisation).  Issued
+    // after the U loads and a full iteration before its data is needed, the DMA is never waited for while it is young;
+    // the counted s_waitcnt at the top of each iteration (vmcnt(6): only the youngest DMA may still be in flight)
+    // guarantees the patch of the current chunk has landed before the barrier.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long xaddr = (unsigned long)p.X;
+    const u32x4 rs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const unsigned sp_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&sP[0][0];
+    auto load_patch = [&](int chunk, int buf) {
+        // channels beyond K only meet zero filter coefficients; beyond the tensor they read 0
+        const int soff = chunk * CKW * p.in_sc * 4;
+#pragma unroll
+        for (int i = 0; i < PLOADS; ++i) {
+            const unsigned dst = sp_lds + (unsigned)((buf * PLOADS * 256 + wave * 64 + i * 256) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(pvo[i]), "s"(rs), "s"(soff) : "memory");
+        }
+    };
+    // ---- U fragments: 8 float4 per lane and chunk, [i = j*2 + mi][lane][kk 0..3]: every load instruction of a wave reads
+    // 1 KB contiguous (per-lane-contiguous 128-byte records made the texture addresser the bottleneck: 64 lines per load)
+    const float* __restrict__ ubase = p.U + (((long)mt * 4 + wave) * 8 * 64 + lane) * 4;
+    const long ustride = (long)p.mtiles * 4 * 64 * 32;      // floats per chunk
+    f32x4 ua[8];
+    auto load_u = [&](int chunk) {
+        const f32x4* __restrict__ q = reinterpret_cast<const f32x4*>(ubase + chunk * ustride);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ua[i] = q[i * 64];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
+
+    // input-transform role of this thread: tile n (ty, tx), channel k of the chunk
+    const int tn = tid & 31, tk = tid >> 5;
+    const int ty = tn >> 3, tx = tn & 7;
+    const int pbase = tk * (PH * PW) + (2 * ty) * PW + 2 * tx;
+    // V = B^T d B of this thread's (channel, tile) from patch buffer `pb` into V buffer `vb`
+    auto read_d = [&](int pb, float (&d)[4][4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[a][b] = sP[pb][pbase + a * PW + b];
+    };
+    auto transform_store = [&](const float (&d)[4][4], int vb) {
+        float x[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            x[0][b] = d[0][b] - d[2][b];
+            x[1][b] = d[1][b] + d[2][b];
+            x[2][b] = d[2][b] - d[1][b];
+            x[3][b] = d[1][b] - d[3][b];
+        }
+        float* __restrict__ v = sV + vb * (16 * CKW * 32) + tk * 32 + tn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[(4 * i + 0) * CKW * 32] = x[i][0] - x[i][2];
+            v[(4 * i + 1) * CKW * 32] = x[i][1] + x[i][2];
+            v[(4 * i + 2) * CKW * 32] = x[i][2] - x[i][1];
+            v[(4 * i + 3) * CKW * 32] = x[i][1] - x[i][3];
+        }
+    };
+
+    // ---- prologue: patches 0 and 1 by DMA, U(0), V(0)
+    load_patch(0, 0);
+    if (p.nchunks > 1) load_patch(1, 1);
+    load_u(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(ua[i]));   // retire these loads HERE: a load pending at loop entry
+                                                       // costs a vmcnt(0) in front of the first MFMA of EVERY iteration
+    if (p.nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        float d0[4][4];
+        read_d(0, d0);
+        transform_store(d0, 0);
+    }
+    int pnext = 1;                                     // patch buffer of chunk + 1 = (chunk + 1) % 3
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < p.nchunks;
+        // patch(chunk + 1) (this wave's part) has landed: nothing younger is in flight at this point
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();       // V(chunk) complete; patch(chunk+1) complete; everyone is done with V(chunk-1) = buffer cur^1
+        // ---- this wave's V fragments, then the requests for later chunks (all through asm: the compiler inserts no vmcnt)
+        float b[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                b[j][kk] = sV[cur * (16 * CKW * 32) + ((4 * wave + j) * CKW + 2 * kk + (lane >> 5)) * 32 + (lane & 31)];
+        f32x4 un[8];
+        {
+            const float* q = ubase + (more ? chunk + 1 : chunk) * ustride;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(un[i]) : "v"(q + i * 256) : "memory");
+        }
+        if (chunk + 2 < p.nchunks) load_patch(chunk + 2, pnext == 2 ? 0 : pnext + 1);
+        // ---- the input transform of the NEXT chunk is interleaved with this chunk's MFMAs (same wave): LDS reads first,
+        // then the scheduler mixes the 32 MFMAs with the ~48 VALU and 16 LDS writes of the transform
+        float d[4][4];
+        read_d(pnext, d);                               // (last chunk: stale but in-bounds data, result unused)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const f32x4 v = ua[j * 2 + mi];
+                    const float av = kk == 0 ? v.x : (kk == 1 ? v.y : (kk == 2 ? v.z : v.w));
+                    acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][kk], acc[j][mi], 0, 0, 0);
+                }
+        transform_store(d, cur ^ 1);                    // unconditional: one basic block, so it can interleave
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {                 // 2 MFMA : 3 VALU : 1 LDS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        // the 8 U loads are older than the (up to 6) DMA loads issued after them
+        if (chunk + 2 < p.nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            asm volatile("" : "+v"(un[i]));            // the copies must stay behind the wait
+            ua[i] = un[i];
+        }
+        pnext = pnext == 2 ? 0 : pnext + 1;
+    }
+    __syncthreads();
+
+    // ---- inverse transform.  Column part in registers: R_i[q] = sum_j M[i][j] A[j][q], A = [[1,0],[1,1],[1,-1],[0,-1]]
+    // Row part through LDS: Y[0][q] = R_0 + R_1 + R_2, Y[1][q] = R_1 - R_2 - R_3 (i = wave)
+    float* __restrict__ sR = sV;                     // [q][w][16 cout][32 tiles] = 16 KB per pass (16 of the 64 couts)
+    const int m0 = mt * 64;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {               // accumulator registers r in [8hf, 8hf + 8) = tile rows 16hf .. 16hf+15
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = hf * 8 + rr;
+                const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);        // 0..15 within the half
+                sR[((0 * 4 + wave) * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
+                sR[((1 * 4 + wave) * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
+            }
+            __syncthreads();
+            // 16 couts x 8 rows x 16 columns; consecutive threads -> consecutive x (64-byte row segments)
+            for (int e = tid; e < 16 * WR * WC; e += 256) {
+                const int x = e & 15, y = (e >> 4) & 7, co = e >> 7;
+                const int n = (y >> 1) * 8 + (x >> 1), q = x & 1;
+                const float* __restrict__ rq = sR + (q * 4 * 16 + co) * 32 + n;
+                const float r0 = rq[0 * 16 * 32], r1 = rq[1 * 16 * 32], r2 = rq[2 * 16 * 32], r3 = rq[3 * 16 * 32];
+                float v = (y & 1) == 0 ? (r0 + r1) + r2 : (r1 - r2) - r3;
+                const int cout = m0 + mi * 32 + hf * 16 + co, oy = oy0 + y, ox = ox0 + x;
+                if (cout < p.M && oy < p.Ho && ox < p.Wo) {
+                    if (p.bias) v += p.bias[cout];
+                    p.Y[p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + ox] =
+                        c2m_act(v, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+// Filter transform U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written in the fragment order the conv
+// kernel reads: Upack[chunk][mt][w][j][mi][lane][kk] = U[xi = 4w + j][m = mt*64 + mi*32 + (lane & 31)][c = chunk*8 + 2kk + (lane >> 5)].
+// dgrad = 0: m = output channel, c = input channel, g = w[m][c];  dgrad = 1 (data gradient of a stride-1 conv): m = input
+// channel, c = output channel, g = w[c][m] rotated by 180 degrees.
+__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int K, int Cin_native,
+                                   int dgrad, int mtiles, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i & 3); long r = i >> 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int ji = (int)(r & 7); r >>= 3;
+        const int mi = ji & 1, j = ji >> 1;
+        const int wv = (int)(r & 3); r >>= 2;
+        const int mt = (int)(r % mtiles); const int chunk = (int)(r / mtiles);
+        const int m = mt * 64 + mi * 32 + (lane & 31), c = chunk * CKW + 2 * kk + (lane >> 5);
+        float v = 0.f;
+        if (m < M && c < K) {
+            const float* __restrict__ g = dgrad ? w + ((long)c * Cin_native + m) * 9 : w + ((long)m * Cin_native + c) * 9;
+            float gg[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) gg[a][b] = dgrad ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+            // row i = wv of G g: coefficients over a
+            float row[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float g0 = gg[0][b], g1 = gg[1][b], g2 = gg[2][b];
+                row[b] = wv == 0 ? g0 : (wv == 1 ? 0.5f * ((g0 + g1) + g2) : (wv == 2 ? 0.5f * ((g0 - g1) + g2) : g2));
+            }
+            v = j == 0 ? row[0] : (j == 1 ? 0.5f * ((row[0] + row[1]) + row[2])
+                                          : (j == 2 ? 0.5f * ((row[0] - row[1]) + row[2]) : row[2]));
+        }
+        up[i] = v;
+    }
+}
+
+C2M_API long c2m_wino_upack_floats(int M, int K) {
+    return 16L * (c2m_cdiv(M, 64) * 64L) * (c2m_cdiv(K, CKW) * (long)CKW);
+}
+
+// w: native [Cout][Cin][3][3].  dgrad = 0: M = Cout, K = Cin;  dgrad = 1: M = Cin, K = Cout.
+C2M_API int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream) {
+    C2M_ENTER();
+    const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    if (M <= 0 || K <= 0) return 0;
+    const long total = c2m_wino_upack_floats(M, K);
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, upack, M, K,
+                       Cin, dgrad, c2m_cdiv(M, 64), total);
+    return (int)hipGetLastError();
+}
+
+// geom[] (int64): 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0, 9 reflect, 10 in_sn, 11 in_sc, 12 in_sh,
+//                 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes
+C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, const float* bias, const int64_t* g, int act,
+                          float slope, void* stream) {
+    C2M_ENTER();
+    WinoP p;
+    p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
+    p.M = (int)g[0]; p.K = (int)g[1]; p.nimg = (int)g[2];
+    p.Hi = (int)g[3]; p.Wi = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
+    p.iy0 = (int)g[7]; p.ix0 = (int)g[8]; p.reflect = (int)g[9];
+    p.in_sn = g[10]; p.in_sc = (int)g[11]; p.in_sh = (int)g[12];
+    p.out_sn = g[13]; p.out_sc = g[14]; p.out_sh = g[15]; p.out_off = g[16];
+    if (g[17] <= 0 || g[17] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[17];
+    p.act = act; p.slope = slope;
+    if (p.M <= 0 || p.K <= 0 || p.nimg <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
+    if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;
+    p.nchunks = c2m_cdiv(p.K, CKW);
+    p.mtiles = c2m_cdiv(p.M, 64);
+    const long regions = (long)p.nimg * c2m_cdiv(p.Ho, WR) * c2m_cdiv(p.Wo, WC);
+    if (regions > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)regions, (unsigned)p.mtiles);
+    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

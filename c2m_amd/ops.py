@@ -5,6 +5,7 @@ gfx950 kernels from libc2m_hip.so on torch's current HIP stream.  There is no CP
 not on a HIP device raises (the oracle in oracle/ is test infrastructure and is never imported from here).
 """
 import ctypes
+import os
 import weakref
 import math
 
@@ -49,6 +50,7 @@ def _f(t):
 # =============================================================================================== convolution
 _geom_cache = {}
 _conv_bf16 = False
+_WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 
 
 def set_conv_precision(precision):
@@ -262,6 +264,22 @@ class _ConvPlan:
         taps = kt * kh * kw
         self.K = Cin * taps
         in_sc, osp = Ti * Hi * Wi, To * Ho * Wo
+        # ---- Winograd F(2x2,3x3) for the 3x3 stride-1 2-D layers (fp32 mode): forward, and the data gradient when the
+        # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
+        self.wino_fwd = self.wino_dgrad = False
+        if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
+            regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
+            fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
+            if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and Cout >= 48 and
+                                    regions * _cdiv(Cout, 64) >= 256):
+                self.wino_fwd = True
+                self.wino_fwd_geom = np.array([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
+                                               Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc], dtype=np.int64)
+            if not reflect and (_WINO == "force" or (_WINO == "auto" and fit and Cout >= 32 and Cin >= 48 and
+                                                     regions * _cdiv(Cin, 64) >= 256)):
+                self.wino_dgrad = True
+                self.wino_dgrad_geom = np.array([Cin, Cout, N, Ho, Wo, Hi, Wi, -1, -1, 0, Cout * osp, osp, Wo,
+                                                 Cin * in_sc, in_sc, Wi, 0, 4 * N * Cout * osp], dtype=np.int64)
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
@@ -417,6 +435,15 @@ def _gp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _wino_filter(w, Cout, Cin, dgrad):
+    """c2m_wino_filter_transform: native [Cout][Cin][3][3] -> packed U = G g G^T fragments (dgrad: transposed, rotated)."""
+    L = _lib.lib()
+    M, K = (Cin, Cout) if dgrad else (Cout, Cin)
+    U = torch.empty(L.c2m_wino_upack_floats(M, K), device=w.device, dtype=torch.float32)
+    _lib.check(L.c2m_wino_filter_transform(_p(w), _p(U), Cout, Cin, dgrad, _stream()), "wino_filter_transform")
+    return U
+
+
 def _pack_native(w, M, C, ck, kdims, stride, s_m, s_c):
     """c2m_pack_weights: contiguous native weights -> [ncls*M, nk*16] packed rows (ncls = prod(stride))."""
     kt, kh, kw = kdims
@@ -458,6 +485,17 @@ class _ConvFn(torch.autograd.Function):
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
         ctx.frozen_w = not ctx.needs_input_grad[1]
+        if pl.wino_fwd:
+            U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
+            y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+                              lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), _p(b), _gp(pl.wino_fwd_geom), ACT[act],
+                                                      LRELU_SLOPE, _stream()), tag,
+                              4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
+            ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
+            ctx.save_for_backward(x, w, y if ACT[act] else None)
+            return y
         A = _packed(w, ctx.frozen_w, ("fwd", pl.ck), lambda: _pack_native(w, Cout, Cin, pl.ck, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
         S = pl.fwd_splits
@@ -485,7 +523,15 @@ class _ConvFn(torch.autograd.Function):
             gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and pl.wino_dgrad:
+            U = _packed(w, ctx.frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
+            gx = torch.empty_like(x)
+            tag = ("dgrad", Cin, Cout * 9, x.numel() // Cin, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("igemm", 2.0 * Cin * Cout * 9 * (x.numel() // Cin),
+                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(gx), None, _gp(pl.wino_dgrad_geom), 0, 0.0,
+                                                      _stream()), tag, 4 * (gy.numel() + w.numel() + x.numel())),
+                       "conv_wino dgrad")
+        elif ctx.needs_input_grad[0]:
             S = pl.dgrad_splits
             folded = pl.reflect and any(pl.pad)
             two_target = folded and S == 1 and not pl.dgrad_needs_zero

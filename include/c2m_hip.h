@@ -71,6 +71,17 @@ int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, floa
  *      aten::convolution does internally on its weights (no reference line of its own).                          */
 int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stream);
 
+/* Winograd F(2x2,3x3) form of the 3x3 stride-1 layers (conv_wino.hip; same reference call sites as above: vgg.py:92-137,
+ * spade_block.py:47-49, residual_block.py:13-71, up_block.py:9-13): 2.25x fewer MFMA FLOPs, fp32, bias/activation fused.
+ * c2m_wino_filter_transform packs U = G g G^T in the kernel's fragment order (dgrad = 1: transposed + rotated filter of
+ * the data gradient); upack holds c2m_wino_upack_floats(M, K) floats.
+ * geom[]: 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0 (input origin of output (0,0): -pad forward),
+ *         9 reflect, 10 in_sn, 11 in_sc, 12 in_sh, 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes          */
+long c2m_wino_upack_floats(int M, int K);
+int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
+int c2m_conv_wino(const float* upack, const float* X, float* Y, const float* bias, const int64_t* geom, int act,
+                  float slope, void* stream);
+
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
 int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,

@@ -2,6 +2,8 @@
 golden vectors.  Index/mask paths bit-exact; fp32 elementwise rtol 1e-5; conv / norm reductions 1e-4 (stated per test)."""
 import ctypes
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -82,22 +84,34 @@ def _ref_conv(x, w, b, stride, pad, mode, act):
 @pytest.mark.parametrize("act", [None, "lrelu"])
 def test_conv_fwd_bwd(case, act):
     xs, cout, k, stride, pad, mode = case
-    seed = abs(hash(str(case))) % 10000
+    seed = zlib.crc32(str(case).encode()) % 10000            # (hash() of a str changes from process to process)
     x = rnd(seed, *xs)
     w = rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * int(np.prod(k))) ** 0.5))
     b = rnd(seed + 2, cout, scale=0.1)
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
-    yr = _ref_conv(xr, wr, br, stride, pad, mode, act)
-    go = rnd(seed + 3, *yr.shape)
-    (yr * go).sum().backward()
     xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
     y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode, act=act)
+    ypre = _ref_conv(xr, wr, br, stride, pad, mode, None)
+    go = rnd(seed + 3, *ypre.shape)
+    if act == "lrelu":
+        # LeakyReLU's derivative is a step: where the reference pre-activation is within rounding of 0 the product's own
+        # sign decides (either is a valid fp32 answer); everywhere else the reference's sign is required
+        amb = ypre.detach().abs() < 1e-5 * float(ypre.detach().abs().max())
+        pos = torch.where(amb, y.detach().cpu() > 0, ypre.detach() > 0)
+        slope = torch.where(pos, torch.ones_like(go), torch.full_like(go, 0.2))
+        yr = F.leaky_relu(ypre, 0.2)
+        (ypre * (go * slope)).sum().backward()
+    else:
+        yr = ypre
+        (yr * go).sum().backward()
     (y * g(go)).sum().backward()
     torch.cuda.synchronize()
     rel_close(y, yr, 2e-5, "conv fwd")                 # fp32 MFMA = fmaf chain; only the summation order differs
     rel_close(xg.grad, xr.grad, 5e-5, "conv dgrad")
     rel_close(wg.grad, wr.grad, 1e-4, "conv wgrad")
-    rel_close(bg.grad, br.grad, 1e-4, "conv bias grad")
+    # a bias gradient is a plain sum over N*H*W values of either sign: its rounding error scales with sum |go|, not with
+    # the (cancelled) result
+    rel_close(bg.grad, br.grad, 1e-4, "conv bias grad", floor=1e-3 * float(go.abs().sum()) / cout)
 
 
 def _bf(t):
@@ -110,7 +124,7 @@ def test_conv_bf16_mode(case):
     exact in fp32, so the result must equal the fp32 convolution up to summation order -- this pins the bf16 LDS image,
     the K-slot permutation and the 32x32x16 operand layout; arbitrary inputs then differ only by the operand rounding."""
     xs, cout, k, stride, pad, mode = case
-    seed = abs(hash(str(case))) % 10000
+    seed = zlib.crc32(str(case).encode()) % 10000            # (hash() of a str changes from process to process)
     x, w = _bf(rnd(seed, *xs)), _bf(rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * int(np.prod(k))) ** 0.5)))
     b = rnd(seed + 2, cout, scale=0.1)
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
