@@ -36,6 +36,12 @@ struct WinoP {
     int nchunks, mtiles;
     int act;
     float slope;
+    // optional second target (data gradient of a reflect-padded conv, computed over the padded domain): outputs inside
+    // [lo, lo + ext) go straight to the unpadded gradient Y2, only the pad ring is written to Y (c2m_reflect_border_add
+    // then folds the ring)
+    float* Y2;
+    long y2_sn, y2_sc, y2_sh;
+    int lo_y, lo_x, ext_y, ext_x;
 };
 
 constexpr int WR = 8, WC = 16;               // output region rows / cols
@@ -242,8 +248,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
                 const int cout = m0 + mi * 32 + hf * 16 + co, oy = oy0 + y, ox = ox0 + x;
                 if (cout < p.M && oy < p.Ho && ox < p.Wo) {
                     if (p.bias) v += p.bias[cout];
-                    p.Y[p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + ox] =
-                        c2m_act(v, p.act, p.slope);
+                    v = c2m_act(v, p.act, p.slope);
+                    const int yi = oy - p.lo_y, xi = ox - p.lo_x;
+                    if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y && (unsigned)xi < (unsigned)p.ext_x)
+                        p.Y2[(long)img * p.y2_sn + (long)cout * p.y2_sc + (long)yi * p.y2_sh + xi] = v;
+                    else
+                        p.Y[p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + ox] = v;
                 }
             }
         }
@@ -302,12 +312,18 @@ C2M_API int c2m_wino_filter_transform(const float* w, float* upack, int Cout, in
 }
 
 // geom[] (int64): 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0, 9 reflect, 10 in_sn, 11 in_sc, 12 in_sh,
-//                 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes
-C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, const float* bias, const int64_t* g, int act,
-                          float slope, void* stream) {
+//                 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes; with Y_interior: 18 y2_sn, 19 y2_sc, 20 y2_sh,
+//                 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x
+C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
+                          const int64_t* g, int act, float slope, void* stream) {
     C2M_ENTER();
     WinoP p;
     p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
+    p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
+    if (Y_interior) {
+        p.y2_sn = g[18]; p.y2_sc = g[19]; p.y2_sh = g[20];
+        p.lo_y = (int)g[21]; p.lo_x = (int)g[22]; p.ext_y = (int)g[23]; p.ext_x = (int)g[24];
+    }
     p.M = (int)g[0]; p.K = (int)g[1]; p.nimg = (int)g[2];
     p.Hi = (int)g[3]; p.Wi = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
     p.iy0 = (int)g[7]; p.ix0 = (int)g[8]; p.reflect = (int)g[9];

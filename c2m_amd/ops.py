@@ -275,11 +275,18 @@ class _ConvPlan:
                 self.wino_fwd = True
                 self.wino_fwd_geom = np.array([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
                                                Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc], dtype=np.int64)
-            if not reflect and (_WINO == "force" or (_WINO == "auto" and fit and Cout >= 32 and Cin >= 48 and
-                                                     regions * _cdiv(Cin, 64) >= 256)):
+            # data gradient: zero padding -> the unpadded domain; reflect padding -> the padded (H+2)x(W+2) domain with
+            # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
+            Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
+            dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
+            dfit = Hd * Wd >= 0.8 * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
+            if _WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and Cin >= 48 and
+                                    dregions * _cdiv(Cin, 64) >= 256):
                 self.wino_dgrad = True
-                self.wino_dgrad_geom = np.array([Cin, Cout, N, Ho, Wo, Hi, Wi, -1, -1, 0, Cout * osp, osp, Wo,
-                                                 Cin * in_sc, in_sc, Wi, 0, 4 * N * Cout * osp], dtype=np.int64)
+                o = -2 if reflect else -1
+                self.wino_dgrad_geom = np.array(
+                    [Cin, Cout, N, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Hd * Wd, Hd * Wd, Wd, 0,
+                     4 * N * Cout * osp, Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi], dtype=np.int64)
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
@@ -490,7 +497,7 @@ class _ConvFn(torch.autograd.Function):
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
             _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                              lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), _p(b), _gp(pl.wino_fwd_geom), ACT[act],
+                              lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
                                                       LRELU_SLOPE, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
@@ -526,11 +533,18 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and pl.wino_dgrad:
             U = _packed(w, ctx.frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
             gx = torch.empty_like(x)
-            tag = ("dgrad", Cin, Cout * 9, x.numel() // Cin, pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("igemm", 2.0 * Cin * Cout * 9 * (x.numel() // Cin),
-                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(gx), None, _gp(pl.wino_dgrad_geom), 0, 0.0,
-                                                      _stream()), tag, 4 * (gy.numel() + w.numel() + x.numel())),
-                       "conv_wino dgrad")
+            npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
+            tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
+            tgt = torch.empty(pl.dgrad_target, device=x.device, dtype=torch.float32) if pl.reflect else gx
+            _lib.check(_timed("igemm", 2.0 * Cin * Cout * 9 * npix,
+                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
+                                                      _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
+                              4 * (gy.numel() + w.numel() + x.numel())), "conv_wino dgrad")
+            if pl.reflect:
+                Ti, Hi, Wi = pl.dims[3:6]
+                _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, _stream()),
+                           "reflect border add")
         elif ctx.needs_input_grad[0]:
             S = pl.dgrad_splits
             folded = pl.reflect and any(pl.pad)

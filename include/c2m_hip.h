@@ -76,11 +76,13 @@ int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stre
  * c2m_wino_filter_transform packs U = G g G^T in the kernel's fragment order (dgrad = 1: transposed + rotated filter of
  * the data gradient); upack holds c2m_wino_upack_floats(M, K) floats.
  * geom[]: 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0 (input origin of output (0,0): -pad forward),
- *         9 reflect, 10 in_sn, 11 in_sc, 12 in_sh, 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes          */
+ *         9 reflect, 10 in_sn, 11 in_sc, 12 in_sh, 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes;
+ *         with Y_interior (two-target data gradient of a reflect-padded conv, as in c2m_conv_igemm): 18 y2_sn, 19 y2_sc,
+ *         20 y2_sh, 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x                                                              */
 long c2m_wino_upack_floats(int M, int K);
 int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
-int c2m_conv_wino(const float* upack, const float* X, float* Y, const float* bias, const int64_t* geom, int act,
-                  float slope, void* stream);
+int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
+                  const int64_t* geom, int act, float slope, void* stream);
 
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */

@@ -114,6 +114,40 @@ def test_conv_fwd_bwd(case, act):
     rel_close(bg.grad, br.grad, 1e-4, "conv bias grad", floor=1e-3 * float(go.abs().sum()) / cout)
 
 
+WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3] == 1 and c[4] == 1] + [
+    ((3, 40, 24, 48), 70, (3, 3), 1, 1, "reflect"),      # channels not multiples of 8 / 64: zero-padded U, partial M tile
+    ((2, 16, 10, 20), 8, (3, 3), 1, 1, "zeros"),         # partial 8x16 regions on both axes
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_{c[5]}")
+def test_conv_winograd_forced(case, monkeypatch):
+    """Winograd F(2x2,3x3) kernel on EVERY 3x3 stride-1 pad-1 shape of the suite, whatever the auto heuristic would
+    pick: forward, zero-pad data gradient, reflect data gradient over the padded domain (two-target epilogue)."""
+    monkeypatch.setattr(ops, "_WINO", "force")
+    ops._geom_cache.clear()
+    try:
+        xs, cout, k, stride, pad, mode = case
+        seed = zlib.crc32(("wino" + str(case)).encode()) % 10000
+        x = rnd(seed, *xs)
+        w = rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * 9) ** 0.5))
+        b = rnd(seed + 2, cout, scale=0.1)
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        yr = _ref_conv(xr, wr, br, stride, pad, mode, None)
+        go = rnd(seed + 3, *yr.shape)
+        (yr * go).sum().backward()
+        xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+        y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
+        pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
+        assert pl.wino_fwd and pl.wino_dgrad
+        (y * g(go)).sum().backward()
+        rel_close(y, yr, 2e-5, "winograd fwd")
+        rel_close(xg.grad, xr.grad, 5e-5, "winograd dgrad")
+        rel_close(wg.grad, wr.grad, 1e-4, "wgrad (direct kernel)")
+    finally:
+        ops._geom_cache.clear()
+
+
 def _bf(t):
     return t.bfloat16().float()
 
