@@ -7,9 +7,10 @@ synthetic data + random-init weights, weak scaling over ranks with the mean-of-r
 A step = zero_grad + forward + backward (+ gradient all-reduce when N > 1); inputs are resident in HBM.
 
 One JSON line on rank 0.  Extra objects:
-  roofline     dominant kernels = conv_igemm_kernel + conv_patch3x3_kernel (fp32 MFMA; forward and data-gradient
-               launches of c2m_conv_igemm): algorithmic conv FLOPs / HIP-event time of those launches, measured inside
-               the timed steps on the launch stream; peak = 157.3 TFLOP/s fp32 matrix
+  roofline     dominant kernels = conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (fp32 MFMA; forward and
+               data-gradient launches): algorithmic (direct-convolution) FLOPs / HIP-event time of those launches,
+               measured inside the timed steps on the launch stream; peak = 157.3 TFLOP/s fp32 matrix.  The Winograd
+               kernel executes 2.25x fewer MFMA FLOPs than the algorithmic count on the layers it covers.
   cpu_baseline the CPU oracle (oracle/c2m_oracle.py, validated bit-exact against the reference) timed on this host
 """
 import argparse
@@ -183,9 +184,10 @@ def main():
                 traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
             ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_patch3x3_kernel (c2m_conv_igemm fwd + dgrad launches)",
+                "bound": "mfma", "kernel": "conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (conv forward + data-gradient launches)",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                "frac": round(ach / peak, 4), "flops_counted": "algorithmic direct-convolution FLOPs (2*M*K*Npix)",
+                "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
                 "launches_per_step": ig["launches"] // args.steps,

@@ -17,7 +17,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != C:
             continue
         n = r["Kernel_Name"]
-        key = "igemm" if ("conv_igemm_kernel" in n or "conv_patch3x3_kernel" in n) else \
+        key = "igemm" if ("conv_igemm_kernel" in n or "conv_patch3x3_kernel" in n or "conv_wino_kernel" in n) else \
               "wgrad" if "conv_wgrad_kernel" in n else None
         if key:
             agg[key][0] += 1
