@@ -342,3 +342,304 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
+
+// ================================================================================================ weight gradient
+// Winograd form of the 3x3 stride-1 weight gradient (same layers as above):
+//   dg[co][ci] = G^T [ sum_tiles (A dY A^T)[co][tile] (.) (B^T d B)[ci][tile] ] G
+// i.e. 16 independent GEMMs dU_xi[co][ci] = dM_xi[co][:] . V_xi[ci][:] contracted over the 2x2-output tiles (N*H/2*W/2 of
+// them) -- again 16 multiplies where the direct form needs 36.  One workgroup = 64 output channels x 32 input channels
+// over a range of 2x16-output regions (8 tiles each = one chunk, K = 8): both patches arrive by LDS-DMA one chunk ahead
+// of their transform, the two transforms of chunk c+1 are interleaved with the MFMAs of chunk c (double-buffered
+// operand images in LDS: dM [xi][tile][co], V [xi][tile][ci] -- lanes along the channel, conflict-free on both sides).
+// Pixel ranges are split over workgroups into slabs [split][xi][Cout][Cin] (+ a bias-gradient slab from the plain sum of
+// dY); wino_wgrad_reduce_kernel sums the splits in a fixed order, applies G^T (.) G and writes dW in its native layout.
+struct WinoWgP {
+    const float* dY; const float* X; float* slab; float* dbslab;
+    int M, K, nimg, H, W;            // Cout, Cin, images, spatial size (dY and X have the same: stride 1, pad 1)
+    int reflect;
+    long dy_sn, x_sn;                // image strides (elements); channel stride = H*W for both
+    unsigned dy_bytes, x_bytes;
+    int regions, per_split;          // 2x16-output regions in total / per workgroup
+};
+
+constexpr int GR = 2, GC = 16, GT = 8;               // region rows, cols, tiles
+constexpr int GY_STRIDE = GR * GC + 1;               // 33: dY patch [co][2][16] + 1 pad (odd stride: conflict-free)
+constexpr int GX_STRIDE = (GR + 2) * (GC + 2) + 1;   // 73: X patch [ci][4][18] + 1 pad
+constexpr int GY_LOADS = (64 * GY_STRIDE + 255) / 256;   // 9
+constexpr int GX_LOADS = (32 * GX_STRIDE + 255) / 256;   // 10
+
+__global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
+    __shared__ float pY[2][GY_LOADS * 256];
+    __shared__ float pX[2][GX_LOADS * 256];
+    __shared__ float sDM[2][16 * GT * 64];
+    __shared__ float sVV[2][16 * GT * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
+    const int m0 = mt * 64, c0 = nt * 32;
+    const int HW = p.H * p.W;
+    const int rbeg = split * p.per_split;
+    int rend = rbeg + p.per_split; rend = rend < p.regions ? rend : p.regions;
+    const int nchunks = rend - rbeg;
+    const int regions_x = p.W / GC, regions_y = p.H / GR;
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long ya = (unsigned long)p.dY, xa = (unsigned long)p.X;
+    const u32x4 rsy = {(unsigned)ya, (unsigned)(ya >> 32) & 0xffffu, p.dy_bytes, 0x00020000u};
+    const u32x4 rsx = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const unsigned py_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pY[0][0];
+    const unsigned px_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pX[0][0];
+
+    // dY patch slots of this thread: slot -> (co, y, x); fixed part of the byte offset (region origin is added per chunk)
+    unsigned yvo[GY_LOADS];
+#pragma unroll
+    for (int i = 0; i < GY_LOADS; ++i) {
+        const int s = tid + i * 256;
+        const int co = s / GY_STRIDE, rem = s % GY_STRIDE;
+        const bool ok = co < 64 && rem < GR * GC && m0 + co < p.M;
+        yvo[i] = ok ? (unsigned)((m0 + co) * HW + (rem / GC) * p.W + rem % GC) * 4u : WINO_OOB;
+    }
+    // X patch slots: (ci, r, c) with r in 0..3, c in 0..17; the boundary handling depends on the region -> per chunk
+    int xci[GX_LOADS], xr[GX_LOADS], xc[GX_LOADS];
+#pragma unroll
+    for (int i = 0; i < GX_LOADS; ++i) {
+        const int s = tid + i * 256;
+        const int ci = s / GX_STRIDE, rem = s % GX_STRIDE;
+        const bool ok = ci < 32 && rem < (GR + 2) * (GC + 2) && c0 + ci < p.K;
+        xci[i] = ok ? (c0 + ci) * HW : -1;
+        xr[i] = rem / (GC + 2); xc[i] = rem % (GC + 2);
+    }
+    auto issue_dma = [&](int region, int buf) {
+        const int rx = region % regions_x; int t = region / regions_x;
+        const int ry = t % regions_y; const int img = t / regions_y;
+        const int oy0 = ry * GR, ox0 = rx * GC;
+        const int ysoff = (int)(((long)img * p.dy_sn + (long)oy0 * p.W + ox0) * 4);
+#pragma unroll
+        for (int i = 0; i < GY_LOADS; ++i) {
+            const unsigned dst = py_lds + (unsigned)((buf * GY_LOADS * 256 + wave * 64 + i * 256) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(yvo[i]), "s"(rsy), "s"(ysoff) : "memory");
+        }
+        const unsigned ximg = (unsigned)((long)img * p.x_sn * 4);
+#pragma unroll
+        for (int i = 0; i < GX_LOADS; ++i) {
+            int iy = oy0 - 1 + xr[i], ix = ox0 - 1 + xc[i];
+            bool ok = xci[i] >= 0;
+            if (p.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+            } else {
+                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            }
+            const unsigned vo = ok ? ximg + (unsigned)(xci[i] + iy * p.W + ix) * 4u : WINO_OOB;
+            const unsigned dst = px_lds + (unsigned)((buf * GX_LOADS * 256 + wave * 64 + i * 256) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(vo), "s"(rsx), "s"(0) : "memory");
+        }
+    };
+
+    // transform roles
+    const int yco = tid & 63, ytg = tid >> 6;          // dM: channel yco, tiles 2*ytg and 2*ytg + 1
+    const int vci = tid & 31, vt = tid >> 5;           // V : channel vci, tile vt
+    float dbacc = 0.f;
+    float yv[2][4], xv[4][4];
+    auto read_patches = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                yv[t][e] = pY[buf][yco * GY_STRIDE + (e >> 1) * GC + 2 * (2 * ytg + t) + (e & 1)];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xv[a][b] = pX[buf][vci * GX_STRIDE + a * (GC + 2) + 2 * vt + b];
+    };
+    auto transform_store = [&](int ob) {
+        // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float y00 = yv[t][0], y01 = yv[t][1], y10 = yv[t][2], y11 = yv[t][3];
+            dbacc += (y00 + y01) + (y10 + y11);
+            const float T[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+            float* __restrict__ d = &sDM[ob][(2 * ytg + t) * 64 + yco];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[(4 * i + 0) * GT * 64] = T[i][0];
+                d[(4 * i + 1) * GT * 64] = T[i][0] + T[i][1];
+                d[(4 * i + 2) * GT * 64] = T[i][0] - T[i][1];
+                d[(4 * i + 3) * GT * 64] = -T[i][1];
+            }
+        }
+        // V = B^T d B
+        float x[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            x[0][b] = xv[0][b] - xv[2][b];
+            x[1][b] = xv[1][b] + xv[2][b];
+            x[2][b] = xv[2][b] - xv[1][b];
+            x[3][b] = xv[1][b] - xv[3][b];
+        }
+        float* __restrict__ v = &sVV[ob][vt * 32 + vci];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[(4 * i + 0) * GT * 32] = x[i][0] - x[i][2];
+            v[(4 * i + 1) * GT * 32] = x[i][1] + x[i][2];
+            v[(4 * i + 2) * GT * 32] = x[i][2] - x[i][1];
+            v[(4 * i + 3) * GT * 32] = x[i][1] - x[i][3];
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
+
+    if (nchunks > 0) {
+        // prologue: patches of chunk 0 (and 1), operands of chunk 0
+        issue_dma(rbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_patches(0);
+        if (nchunks > 1) issue_dma(rbeg + 1, 1);
+        transform_store(0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int cur = chunk & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // patches(chunk + 1) of this wave have landed
+            __syncthreads();   // operands(chunk) + patches(chunk+1) complete; everyone is done with operand buffer cur ^ 1
+            float a[4][2][4], b[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int row = ((4 * wave + j) * GT + 2 * kk + (lane >> 5));
+                    b[j][kk] = sVV[cur][row * 32 + (lane & 31)];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) a[j][mi][kk] = sDM[cur][row * 64 + mi * 32 + (lane & 31)];
+                }
+            const bool more = chunk + 1 < nchunks;
+            read_patches(cur ^ 1);                       // chunk + 1 (last chunk: stale data, result unused)
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk + 2 < nchunks) issue_dma(rbeg + chunk + 2, cur);   // patch buffer `cur` was consumed one iteration ago
+            const float dbkeep = dbacc;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][kk], b[j][kk], acc[j][mi], 0, 0, 0);
+            transform_store(cur ^ 1);
+            if (!more) dbacc = dbkeep;                   // the stale transform of the last iteration must not count
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- slab: dU_xi[co][ci] partials of this workgroup's region range
+    float* __restrict__ out = p.slab + (long)split * 16 * p.M * p.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xi = 4 * wave + j;
+        const int ci = c0 + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.M && ci < p.K) out[((long)xi * p.M + co) * p.K + ci] = acc[j][mi][r];
+            }
+    }
+    // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0 only)
+    if (nt == 0) {
+        float* __restrict__ red = &sDM[0][0];
+        red[ytg * 64 + yco] = dbacc;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M)
+            p.dbslab[(long)split * p.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    }
+}
+
+// dW[co][ci][3][3] = G^T (sum_splits dU) G;  db[co] = sum_splits dbslab
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
+                                         float* __restrict__ dW, float* __restrict__ db, int M, int K, int S) {
+    const long total = (long)M * K;
+    const long per = 16 * total;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float u[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) acc += slab[(long)s * per + (long)xi * total + i];
+            u[xi >> 2][xi & 3] = acc;
+        }
+        // G^T u: rows a = 0..2 from i = 0..3 with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+            t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+            t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+        }
+        float* __restrict__ o = dW + i * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+            o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+            o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        }
+    }
+    if (db) {
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) acc += dbslab[(long)s * M + m];
+            db[m] = acc;
+        }
+    }
+}
+
+// Number of region splits (= slabs) the launch will use: slab = S*16*M*K floats, dbslab = S*M floats.
+C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
+    const long regions = (long)nimg * (H / GR) * (W / GC);
+    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 32);
+    long S = 256 / tiles;                       // one workgroup per CU (134 KB of LDS): one resident round
+    if (S < 1) S = 1;
+    const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    const long per = (regions + S - 1) / S;
+    return (int)((regions + per - 1) / per);
+}
+
+// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 16 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
+C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
+                                int M, int K, int nimg, int H, int W, int reflect, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || K <= 0 || nimg <= 0) return 0;
+    if (H % GR || W % GC) return (int)hipErrorInvalidValue;
+    const long ybytes = 4L * nimg * M * H * W, xbytes = 4L * nimg * K * H * W;
+    if (ybytes >= 0x80000000LL || xbytes >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    WinoWgP p;
+    p.dY = dY; p.X = X; p.slab = slab; p.dbslab = dbslab;
+    p.M = M; p.K = K; p.nimg = nimg; p.H = H; p.W = W; p.reflect = reflect;
+    p.dy_sn = (long)M * H * W; p.x_sn = (long)K * H * W;
+    p.dy_bytes = (unsigned)ybytes; p.x_bytes = (unsigned)xbytes;
+    p.regions = nimg * (H / GR) * (W / GC);
+    const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
+    p.per_split = c2m_cdiv(p.regions, S);
+    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 32));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(256), 0, s, p);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(c2m_grid((long)M * K, 256)), dim3(256), 0, s, slab, dbslab, dW, db,
+                       M, K, S);
+    return (int)hipGetLastError();
+}

@@ -51,6 +51,9 @@ def _f(t):
 _geom_cache = {}
 _conv_bf16 = False
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
+# The Winograd WEIGHT gradient is parity-green but not yet faster than the direct wgrad kernel (both operands go through an
+# LDS transform: ~3.7 LDS instructions per MFMA; 67-106 vs 85-101 TF/s), so it only runs when forced (tests) or asked for.
+_WINO_WGRAD = os.environ.get("C2M_WINOGRAD_WGRAD", "off")      # "off" | "on" | "force"
 
 
 def set_conv_precision(precision):
@@ -266,8 +269,12 @@ class _ConvPlan:
         in_sc, osp = Ti * Hi * Wi, To * Ho * Wo
         # ---- Winograd F(2x2,3x3) for the 3x3 stride-1 2-D layers (fp32 mode): forward, and the data gradient when the
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
-        self.wino_fwd = self.wino_dgrad = False
+        self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
+            if Hi % 2 == 0 and Wi % 16 == 0 and (_WINO_WGRAD == "force" or (
+                    _WINO_WGRAD == "on" and Cin >= 32 and Cout >= 32 and N * (Hi // 2) * (Wi // 16) >= 2048)):
+                self.wino_wgrad = True
+                self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
             fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
             if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and Cout >= 48 and
@@ -595,7 +602,20 @@ class _ConvFn(torch.autograd.Function):
                 fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
                 _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
                            "reflect fold")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad:
+            S = pl.wino_wg_splits
+            slab = torch.empty(S * 16 * Cout * Cin, device=x.device, dtype=torch.float32)
+            dbslab = torch.empty(S * Cout, device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            Hi, Wi = pl.dims[4:6]
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+                              lambda: L.c2m_conv_wino_wgrad(_p(gy), _p(x), _p(slab), _p(dbslab), _p(gw), _p(gb_t), Cout,
+                                                            Cin, N, Hi, Wi, int(pl.reflect), _stream()), tag,
+                              4 * (gy.numel() + x.numel() + w.numel())), "conv_wino_wgrad")
+            gb = gb_t if ctx.has_bias else None
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)

@@ -84,6 +84,13 @@ int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, i
 int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
                   const int64_t* geom, int act, float slope, void* stream);
 
+/* Winograd weight gradient of the same layers: dg = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G (3x3, stride 1, pad 1,
+ * H % 2 == 0, W % 16 == 0).  slab: c2m_wino_wgrad_splits(...) * 16 * M * K floats, dbslab: splits * M floats; dW in the
+ * native [Cout][Cin][3][3] layout, db [Cout] (may be NULL).  Deterministic (fixed-order slab reduction).           */
+int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W);
+int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db, int M, int K,
+                        int nimg, int H, int W, int reflect, void* stream);
+
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
 int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
