@@ -362,21 +362,25 @@ struct WinoWgP {
     int regions, per_split;          // 2x16-output regions in total / per workgroup
 };
 
-constexpr int GR = 2, GC = 16, GT = 8;               // region rows, cols, tiles
-constexpr int GY_STRIDE = GR * GC + 1;               // 33: dY patch [co][2][16] + 1 pad (odd stride: conflict-free)
-constexpr int GX_STRIDE = (GR + 2) * (GC + 2) + 1;   // 73: X patch [ci][4][18] + 1 pad
-constexpr int GY_LOADS = (64 * GY_STRIDE + 255) / 256;   // 9
-constexpr int GX_LOADS = (32 * GX_STRIDE + 255) / 256;   // 10
+constexpr int GR = 2, GC = 8, GT = 4;                // region rows, cols, tiles (one chunk: K = 4 tiles)
+constexpr int GY_STRIDE = GR * GC + 1;               // 17: dY patch [co][2][8] + 1 pad (odd stride: conflict-free)
+constexpr int GX_STRIDE = (GR + 2) * (GC + 2) + 1;   // 41: X patch [ci][4][10] + 1 pad
+constexpr int GY_LOADS = (64 * GY_STRIDE + 255) / 256;   // 5
+constexpr int GX_LOADS = (64 * GX_STRIDE + 255) / 256;   // 11
 
+// Workgroup = 64 output channels x 64 input channels x 16 frequencies = 256 accumulator registers per lane (AGPRs; one
+// workgroup per CU).  Issue-slot budget: the 32 MFMAs of a chunk occupy 32 x 16 issue quads; everything else of the
+// chunk (patch DMA, both transforms, fragment reads, address arithmetic) must stay well below that and be spread
+// between the MFMAs (one MFMA : ~6 other instructions), because instructions behind a stalled MFMA cannot overtake it.
 __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     __shared__ float pY[2][GY_LOADS * 256];
     __shared__ float pX[2][GX_LOADS * 256];
-    __shared__ float sDM[2][16 * GT * 64];
-    __shared__ float sVV[2][16 * GT * 32];
+    __shared__ float sDM[2][16 * GT * 64];             // [xi][tile][co]
+    __shared__ float sVV[2][16 * GT * 64];             // [xi][tile][ci]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
-    const int m0 = mt * 64, c0 = nt * 32;
+    const int m0 = mt * 64, c0 = nt * 64;
     const int HW = p.H * p.W;
     const int rbeg = split * p.per_split;
     int rend = rbeg + p.per_split; rend = rend < p.regions ? rend : p.regions;
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     const unsigned py_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pY[0][0];
     const unsigned px_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pX[0][0];
 
-    // dY patch slots of this thread: slot -> (co, y, x); fixed part of the byte offset (region origin is added per chunk)
+    // patch slots of this thread; byte offsets relative to the region origin (the origin is the scalar offset per chunk)
     unsigned yvo[GY_LOADS];
 #pragma unroll
     for (int i = 0; i < GY_LOADS; ++i) {
@@ -399,15 +403,19 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
         const bool ok = co < 64 && rem < GR * GC && m0 + co < p.M;
         yvo[i] = ok ? (unsigned)((m0 + co) * HW + (rem / GC) * p.W + rem % GC) * 4u : WINO_OOB;
     }
-    // X patch slots: (ci, r, c) with r in 0..3, c in 0..17; the boundary handling depends on the region -> per chunk
-    int xci[GX_LOADS], xr[GX_LOADS], xc[GX_LOADS];
+    // X patch: (ci, r, c), r in 0..3 (input rows oy0-1 ..), c in 0..9.  Interior regions use the precomputed offsets;
+    // regions touching the image border recompute theirs (zero / reflect padding)
+    unsigned xvo[GX_LOADS];
+    int xci[GX_LOADS], xrc[GX_LOADS];
 #pragma unroll
     for (int i = 0; i < GX_LOADS; ++i) {
         const int s = tid + i * 256;
         const int ci = s / GX_STRIDE, rem = s % GX_STRIDE;
-        const bool ok = ci < 32 && rem < (GR + 2) * (GC + 2) && c0 + ci < p.K;
+        const bool ok = ci < 64 && rem < (GR + 2) * (GC + 2) && c0 + ci < p.K;
+        const int r = rem / (GC + 2), c = rem % (GC + 2);
         xci[i] = ok ? (c0 + ci) * HW : -1;
-        xr[i] = rem / (GC + 2); xc[i] = rem % (GC + 2);
+        xrc[i] = r * 16 + c;
+        xvo[i] = ok ? (unsigned)((c0 + ci) * HW + (r - 1) * p.W + (c - 1)) * 4u : WINO_OOB;     // may wrap: added to soff
     }
     auto issue_dma = [&](int region, int buf) {
         const int rx = region % regions_x; int t = region / regions_x;
@@ -420,55 +428,55 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                          :: "s"(dst), "v"(yvo[i]), "s"(rsy), "s"(ysoff) : "memory");
         }
+        const bool interior = ry > 0 && ry + 1 < regions_y && rx > 0 && rx + 1 < regions_x;    // wave-uniform
         const unsigned ximg = (unsigned)((long)img * p.x_sn * 4);
+        const unsigned xorg = ximg + (unsigned)(oy0 * p.W + ox0) * 4u;
 #pragma unroll
         for (int i = 0; i < GX_LOADS; ++i) {
-            int iy = oy0 - 1 + xr[i], ix = ox0 - 1 + xc[i];
-            bool ok = xci[i] >= 0;
-            if (p.reflect) {
-                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
-                ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+            unsigned vo;
+            if (interior) {
+                vo = xvo[i] == WINO_OOB ? WINO_OOB : xvo[i] + xorg;
             } else {
-                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                int iy = oy0 - 1 + (xrc[i] >> 4), ix = ox0 - 1 + (xrc[i] & 15);
+                bool ok = xci[i] >= 0;
+                if (p.reflect) {
+                    iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+                    ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                }
+                vo = ok ? ximg + (unsigned)(xci[i] + iy * p.W + ix) * 4u : WINO_OOB;
             }
-            const unsigned vo = ok ? ximg + (unsigned)(xci[i] + iy * p.W + ix) * 4u : WINO_OOB;
             const unsigned dst = px_lds + (unsigned)((buf * GX_LOADS * 256 + wave * 64 + i * 256) * 4);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                          :: "s"(dst), "v"(vo), "s"(rsx), "s"(0) : "memory");
         }
     };
 
-    // transform roles
-    const int yco = tid & 63, ytg = tid >> 6;          // dM: channel yco, tiles 2*ytg and 2*ytg + 1
-    const int vci = tid & 31, vt = tid >> 5;           // V : channel vci, tile vt
+    // transform role of a thread: channel ch = tid & 63 (as output channel AND as input channel), tile tq = tid >> 6
+    const int ch = tid & 63, tq = tid >> 6;
     float dbacc = 0.f;
-    float yv[2][4], xv[4][4];
+    float yv[4], xv[4][4];
     auto read_patches = [&](int buf) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                yv[t][e] = pY[buf][yco * GY_STRIDE + (e >> 1) * GC + 2 * (2 * ytg + t) + (e & 1)];
+        for (int e = 0; e < 4; ++e) yv[e] = pY[buf][ch * GY_STRIDE + (e >> 1) * GC + 2 * tq + (e & 1)];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xv[a][b] = pX[buf][vci * GX_STRIDE + a * (GC + 2) + 2 * vt + b];
+            for (int b = 0; b < 4; ++b) xv[a][b] = pX[buf][ch * GX_STRIDE + a * (GC + 2) + 2 * tq + b];
     };
     auto transform_store = [&](int ob) {
         // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+        const float y00 = yv[0], y01 = yv[1], y10 = yv[2], y11 = yv[3];
+        dbacc += (y00 + y01) + (y10 + y11);
+        const float T[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+        float* __restrict__ d = &sDM[ob][tq * 64 + ch];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float y00 = yv[t][0], y01 = yv[t][1], y10 = yv[t][2], y11 = yv[t][3];
-            dbacc += (y00 + y01) + (y10 + y11);
-            const float T[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
-            float* __restrict__ d = &sDM[ob][(2 * ytg + t) * 64 + yco];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[(4 * i + 0) * GT * 64] = T[i][0];
-                d[(4 * i + 1) * GT * 64] = T[i][0] + T[i][1];
-                d[(4 * i + 2) * GT * 64] = T[i][0] - T[i][1];
-                d[(4 * i + 3) * GT * 64] = -T[i][1];
-            }
+        for (int i = 0; i < 4; ++i) {
+            d[(4 * i + 0) * GT * 64] = T[i][0];
+            d[(4 * i + 1) * GT * 64] = T[i][0] + T[i][1];
+            d[(4 * i + 2) * GT * 64] = T[i][0] - T[i][1];
+            d[(4 * i + 3) * GT * 64] = -T[i][1];
         }
         // V = B^T d B
         float x[4][4];
@@ -479,26 +487,27 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             x[2][b] = xv[2][b] - xv[1][b];
             x[3][b] = xv[1][b] - xv[3][b];
         }
-        float* __restrict__ v = &sVV[ob][vt * 32 + vci];
+        float* __restrict__ v = &sVV[ob][tq * 64 + ch];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[(4 * i + 0) * GT * 32] = x[i][0] - x[i][2];
-            v[(4 * i + 1) * GT * 32] = x[i][1] + x[i][2];
-            v[(4 * i + 2) * GT * 32] = x[i][2] - x[i][1];
-            v[(4 * i + 3) * GT * 32] = x[i][1] - x[i][3];
+            v[(4 * i + 0) * GT * 64] = x[i][0] - x[i][2];
+            v[(4 * i + 1) * GT * 64] = x[i][1] + x[i][2];
+            v[(4 * i + 2) * GT * 64] = x[i][2] - x[i][1];
+            v[(4 * i + 3) * GT * 64] = x[i][1] - x[i][3];
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][2][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][mi][ni][r] = 0.f;
 
     if (nchunks > 0) {
-        // prologue: patches of chunk 0 (and 1), operands of chunk 0
         issue_dma(rbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -509,15 +518,17 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             const int cur = chunk & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // patches(chunk + 1) of this wave have landed
             __syncthreads();   // operands(chunk) + patches(chunk+1) complete; everyone is done with operand buffer cur ^ 1
-            float a[4][2][4], b[4][4];
+            float a[4][2][2], b[4][2][2];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int row = ((4 * wave + j) * GT + 2 * kk + (lane >> 5));
-                    b[j][kk] = sVV[cur][row * 32 + (lane & 31)];
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int row = ((4 * wave + j) * GT + 2 * kk + (lane >> 5)) * 64 + (lane & 31);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) a[j][mi][kk] = sDM[cur][row * 64 + mi * 32 + (lane & 31)];
+                    for (int q = 0; q < 2; ++q) {
+                        a[j][q][kk] = sDM[cur][row + q * 32];
+                        b[j][q][kk] = sVV[cur][row + q * 32];
+                    }
                 }
             const bool more = chunk + 1 < nchunks;
             read_patches(cur ^ 1);                       // chunk + 1 (last chunk: stale data, result unused)
@@ -525,19 +536,22 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             if (chunk + 2 < nchunks) issue_dma(rbeg + chunk + 2, cur);   // patch buffer `cur` was consumed one iteration ago
             const float dbkeep = dbacc;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
-                        acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][kk], b[j][kk], acc[j][mi], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][kk], b[j][ni][kk],
+                                                                                  acc[j][mi][ni], 0, 0, 0);
             transform_store(cur ^ 1);
             if (!more) dbacc = dbkeep;                   // the stale transform of the last iteration must not count
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            for (int g = 0; g < 32; ++g) {               // one MFMA : ~3 other instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
     }
@@ -548,19 +562,22 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xi = 4 * wave + j;
-        const int ci = c0 + (lane & 31);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni) {
+            const int ci = c0 + ni * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < p.M && ci < p.K) out[((long)xi * p.M + co) * p.K + ci] = acc[j][mi][r];
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < p.M && ci < p.K) out[((long)xi * p.M + co) * p.K + ci] = acc[j][mi][ni][r];
+                }
+        }
     }
     // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0 only)
     if (nt == 0) {
         float* __restrict__ red = &sDM[0][0];
-        red[ytg * 64 + yco] = dbacc;
+        red[tq * 64 + ch] = dbacc;
         __syncthreads();
         if (tid < 64 && m0 + tid < p.M)
             p.dbslab[(long)split * p.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
@@ -608,17 +625,17 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const f
 // Number of region splits (= slabs) the launch will use: slab = S*16*M*K floats, dbslab = S*M floats.
 C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long regions = (long)nimg * (H / GR) * (W / GC);
-    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 32);
-    long S = 256 / tiles;                       // one workgroup per CU (134 KB of LDS): one resident round
+    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 64);
+    long S = 256 / tiles;                       // one workgroup per CU (256 accumulator registers): one resident round
     if (S < 1) S = 1;
-    const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
+    const long maxS = (regions + 31) / 32;      // >= 32 regions (128 tiles) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     const long per = (regions + S - 1) / S;
     return (int)((regions + per - 1) / per);
 }
 
-// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 16 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
+// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 8 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
 C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
                                 int M, int K, int nimg, int H, int W, int reflect, void* stream) {
     C2M_ENTER();
@@ -634,7 +651,7 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     p.regions = nimg * (H / GR) * (W / GC);
     const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
     p.per_split = c2m_cdiv(p.regions, S);
-    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 32));
+    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 64));
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();

@@ -52,7 +52,7 @@ _geom_cache = {}
 _conv_bf16 = False
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # The Winograd WEIGHT gradient is parity-green but not yet faster than the direct wgrad kernel (both operands go through an
-# LDS transform: ~3.7 LDS instructions per MFMA; 67-106 vs 85-101 TF/s), so it only runs when forced (tests) or asked for.
+# LDS transform and it is instruction-issue bound; 52-115 vs 67-95 TF/s), so it only runs when forced (tests) or asked for.
 _WINO_WGRAD = os.environ.get("C2M_WINOGRAD_WGRAD", "off")      # "off" | "on" | "force"
 
 
@@ -271,8 +271,8 @@ class _ConvPlan:
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
-            if Hi % 2 == 0 and Wi % 16 == 0 and (_WINO_WGRAD == "force" or (
-                    _WINO_WGRAD == "on" and Cin >= 32 and Cout >= 32 and N * (Hi // 2) * (Wi // 16) >= 2048)):
+            if Hi % 2 == 0 and Wi % 8 == 0 and (_WINO_WGRAD == "force" or (
+                    _WINO_WGRAD == "on" and Cin >= 48 and Cout >= 48 and N * (Hi // 2) * (Wi // 8) >= 4096)):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)

@@ -85,7 +85,7 @@ int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interio
                   const int64_t* geom, int act, float slope, void* stream);
 
 /* Winograd weight gradient of the same layers: dg = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G (3x3, stride 1, pad 1,
- * H % 2 == 0, W % 16 == 0).  slab: c2m_wino_wgrad_splits(...) * 16 * M * K floats, dbslab: splits * M floats; dW in the
+ * H % 2 == 0, W % 8 == 0).  slab: c2m_wino_wgrad_splits(...) * 16 * M * K floats, dbslab: splits * M floats; dW in the
  * native [Cout][Cin][3][3] layout, db [Cout] (may be NULL).  Deterministic (fixed-order slab reduction).           */
 int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W);
 int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db, int M, int K,
