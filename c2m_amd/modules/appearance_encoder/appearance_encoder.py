@@ -60,7 +60,9 @@ class AppearanceEncoder(nn.Module):
         pooled_src = torch.cat(out[f"enco{self.pooling_after - 1}"].chunk(t_in, 1), dim=0)
         obj = ops.roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
         obj = self.roi_align_regressor(self.roi_align_blocks(obj))
-        scene = torch.repeat_interleave(out["app_encoded"].flatten(1), gnn.num_real_nodes * t_in, dim=0)
+        # == torch.repeat_interleave(app_encoded.flatten(1), gnn.num_real_nodes * t_in, dim=0) of the reference (:63) for
+        # the sorted per-node batch vector, without the host sync a tensor of repeat counts costs (HIP-graph capturable)
+        scene = out["app_encoded"].flatten(1).index_select(0, gnn.batch.repeat_interleave(t_in))
         fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))
         out["objects_feature"] = torch.cat(fused.unsqueeze(1).chunk(t_in, 0), 1)
         return out

@@ -47,7 +47,7 @@ class SparseMotionGenerator(nn.Module):
         if click_index is None:
             click_index = self.draw_click_index(data.num_real_nodes, data.x.device)
         u = torch.zeros(data.num_nodes, device=data.x.device)
-        u[click_index] = 1
+        u.index_fill_(0, click_index, 1.0)               # u[click_index] = 1 without the host round trip of index_put_
         u = u.unsqueeze(1)
         h, theta_map = self._encode(data, scene_features)
         return self.decoder(h, data.x[:, :2], theta_map, data.edge_index, u, latent, data.targets_theta)
