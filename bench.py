@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from c2m_amd import ops  # noqa: E402
 from c2m_amd.config import default_config, normalize_config  # noqa: E402
 from c2m_amd.modules.model import GeneratorFullModel  # noqa: E402
-from c2m_amd.synthetic import make_batch, make_step_rng, batch_to  # noqa: E402
+from c2m_amd.synthetic import make_batch, make_stream_batch, make_step_rng, batch_to  # noqa: E402
 from c2m_amd.train import TrainStep, init_distributed  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--windows", type=int, default=1,
+                    help="7-frame windows per stream sample (2 = BASELINE configs[4]'s 14-frame streams); clips/GPU = batch x windows")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,7 +112,8 @@ def main():
     model.to(dev).train()
     step = TrainStep(model, run_optimizers=args.full_step, distributed=world > 1 or args.force_reducer,
                      force_collectives=args.force_reducer)
-    batch = batch_to(make_batch(args.batch, args.height, args.width, 2, seed=rank), dev)
+    clips = args.batch * args.windows
+    batch = batch_to(make_stream_batch(args.batch, args.windows, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)
     batch["rng"] = {k: v.to(dev) for k, v in rng.items()}
 
@@ -136,7 +139,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    frames = world * args.batch * 7 * args.steps
+    frames = world * clips * 7 * args.steps
     result = {
         "metric": f"generator train-step frames/sec at {args.height}x{args.width}x7", "value": round(frames / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,14 +147,14 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE {'configs[1]' if (args.dtype, args.full_step) == ('f32', False) else 'configs[2-3] style (side measurement)'}: "
                                f"{args.height}x{args.width}, 7-frame clips (2 in + 5 predicted), "
-                               f"batch {args.batch}/GPU, {'fp32' if args.dtype == 'f32' else 'bf16 conv operands (fp32 accumulate, fp32 tensors)'}, "
+                               f"batch {args.batch}/GPU{'' if args.windows == 1 else f' x {args.windows} windows (14-frame streams)'}, {'fp32' if args.dtype == 'f32' else 'bf16 conv operands (fp32 accumulate, fp32 tensors)'}, "
                                + ("full adversarial step (G + D_image + D_video, 4 Adam steps), VGG loss on, "
                                   if args.full_step else "generator fwd+bwd only (no D), VGG loss on, ")
-                               + "random-init weights", "global_batch": world * args.batch,
+                               + "random-init weights", "global_batch": world * clips,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         # conv FLOPs scale with the pixel count ("for 256x512 multiply conv FLOPs by 4")
         "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * (args.height * args.width) / (128 * 256) * 1e-3 *
-                                             world * args.batch * args.steps / elapsed, 2),
+                                             world * clips * args.steps / elapsed, 2),
     }
     if args.check_grads:
         # all-reduced gradients must be bit-identical on every rank although each rank saw different data
@@ -177,7 +180,7 @@ def main():
             # (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json); counters cannot be read from inside the process
             traffic, traffic_src = None, None
             tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tp) and (args.batch, args.height, args.width, args.dtype, args.full_step) == \
+            if os.path.exists(tp) and args.windows == 1 and (args.batch, args.height, args.width, args.dtype, args.full_step) == \
                     (8, 128, 256, "f32", False):
                 with open(tp) as f:
                     traffic = json.load(f)["igemm"]["traffic_bytes_per_launch"]

@@ -102,6 +102,18 @@ def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_pred
     return batch_to(batch, device)
 
 
+def make_stream_batch(streams=1, windows=2, height=128, width=256, num_input_frames=2, num_predicted_frames=5,
+                      num_objects=3, seed=0, device="cpu"):
+    """BASELINE configs[4] ("14-frame clips"): t_out is fixed at 5 by the model (UpBlock2d chunk(5, 0)),
+    so a 14-frame stream sample is cut into `windows` consecutive 7-frame windows that are stacked along the batch axis
+     -- window w of stream s is clip s * windows + w.  Every synthetic field is drawn i.i.d. per frame (and
+    the instance rectangles are static), so cutting one long draw into windows and drawing the windows directly are the
+    same distribution; the windows are drawn directly."""
+    if windows < 1 or streams < 1:
+        raise ValueError("streams and windows must be >= 1")
+    return make_batch(streams * windows, height, width, num_input_frames, num_predicted_frames, num_objects, seed, device)
+
+
 def batch_to(batch, device):
     out = {}
     for k, v in batch.items():

@@ -119,3 +119,15 @@ def test_checkpoint_layout_round_trip_with_torch_adam_states(tmp_path):
     t = torch.optim.Adam(ps, lr=1e-4, betas=(0.5, 0.999), eps=1e-7)
     t.load_state_dict(saved["optimizer"])                          # our optimizer state is a valid torch Adam state
     assert float(t.state_dict()["state"][0]["step"]) == 1.0
+
+
+def test_stream_batch_windows_stack_along_the_batch_axis():
+    """BASELINE configs[4]: a 14-frame stream sample = two 7-frame windows; the per-rank batch doubles."""
+    from c2m_amd.synthetic import make_batch, make_stream_batch
+    b = make_stream_batch(streams=2, windows=2, height=32, width=64, num_objects=[3, 2, 3, 2])
+    assert b["video"].shape == (4, 3, 7, 32, 64) and b["target_bw_of"].shape == (4, 2, 5, 32, 64)
+    assert b["tracking_gnn"].num_real_nodes.tolist() == [3, 2, 3, 2] and b["tracking_gnn"].num_nodes == 10
+    ref = make_batch(4, 32, 64, num_objects=[3, 2, 3, 2])
+    assert torch.equal(b["video"], ref["video"]) and torch.equal(b["instance_mask"], ref["instance_mask"])
+    with pytest.raises(ValueError):
+        make_stream_batch(streams=1, windows=0)
