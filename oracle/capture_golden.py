@@ -358,6 +358,56 @@ def capture_inference(name, t_in, use_spade, batch_size, use_gt_eval, eval_mode,
     save(name, meta, arrays)
 
 
+TRACKS = os.path.join(OUT, "scene_tracks")
+
+
+def write_track_fixtures():
+    """Synthetic tracking files (our data, the reference's text format "x,y,w,h,score,id", 2048x1024 pixel boxes) and
+    one small Middlebury .flo file.  Deterministic; rewritten on every capture."""
+    os.makedirs(TRACKS, exist_ok=True)
+    g = np.random.default_rng(11)
+    scenes = {"aachen_000000_000019_": [11003, 13001, 18002], "bonn_000001_000004_": [12000]}
+    for prefix, ids in scenes.items():
+        for n, inst in enumerate(ids):
+            x, y = g.uniform(100, 1500), g.uniform(100, 700)
+            w, h = g.uniform(60, 300), g.uniform(40, 250)
+            with open(os.path.join(TRACKS, f"{prefix}{n:02d}.txt"), "w") as f:
+                for t in range(9):                       # longer than num_frames: only the first 7 are read
+                    f.write(f"{x:.3f},{y:.3f},{w:.3f},{h:.3f},0.9,{inst}\n")
+                    x, y = x + g.uniform(-40, 40), y + g.uniform(-15, 15)
+                    w, h = w * g.uniform(0.9, 1.1), h * g.uniform(0.9, 1.1)
+    flow = g.standard_normal((3, 5, 2)).astype("<f4")
+    with open(os.path.join(TRACKS, "tiny.flo"), "wb") as f:
+        f.write(np.float32(202021.25).tobytes() + np.int32(5).tobytes() + np.int32(3).tobytes() + flow.tobytes())
+    with open(os.path.join(TRACKS, "bad_magic.flo"), "wb") as f:
+        f.write(np.float32(1.0).tobytes() + np.int32(5).tobytes() + np.int32(3).tobytes() + flow.tobytes())
+
+
+def capture_data(ref_utils):
+    """load_scene_info (datasets/cityscapes.py:79) and read_flow (utils/utils.py:324) of the live reference on the
+    committed track files.  Nodes are stored sorted by instance id (glob order is file-system dependent)."""
+    from datasets import cityscapes as ref_ds
+    write_track_fixtures()
+    arrays, meta = {}, {"cases": []}
+    for prefix, t_in, lam in (("aachen_000000_000019_", 2, 1), ("aachen_000000_000019_", 1, 2.5),
+                              ("bonn_000001_000004_", 2, 1)):
+        cfg = {"train_params": {"num_input_frames": t_in}, "test_params": {"lambda_traj": lam}}
+        ids, d = ref_ds.load_scene_info(os.path.join(TRACKS, prefix), 7, [128, 256], cfg)
+        order = torch.argsort(d.source_frames_nodes_instance_ids[:, 0])
+        tag = f"{prefix}tin{t_in}_lam{lam}"
+        meta["cases"].append(dict(tag=tag, prefix=prefix, t_in=t_in, lambda_traj=lam))
+        for k in ("x", "y", "source_frames_nodes_roi", "source_frames_nodes_roi_padded", "target_frames_nodes_roi",
+                  "source_frames_nodes_instance_ids", "target_frames_nodes_instance_ids", "targets_barycenter",
+                  "targets_displacement", "targets_theta"):
+            arrays[f"{tag}.{k}"] = getattr(d, k)[order]
+        arrays[f"{tag}.num_real_nodes"] = d.num_real_nodes
+        arrays[f"{tag}.edge_index"] = d.edge_index
+        arrays[f"{tag}.tracking_ids"] = ids[:, order]
+    arrays["flo.tiny"] = ref_utils.read_flow(os.path.join(TRACKS, "tiny.flo"))
+    assert ref_utils.read_flow(os.path.join(TRACKS, "bad_magic.flo")) is None
+    save("data_scene_graph", meta, arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_utils = ref_shims.install()
@@ -365,6 +415,9 @@ def main():
     if "--inference-only" in sys.argv:      # added after the other fixtures were frozen: does not rewrite them
         capture_inference("inf_tin2_spade_eval", 2, True, 2, False, True, 5)
         capture_inference("inf_tin1_nospade_train_gt", 1, False, 1, True, False, 6)
+        return
+    if "--data-only" in sys.argv:           # likewise
+        capture_data(ref_utils)
         return
     print("ops");      capture_ops(ref_utils)
     print("blocks");   capture_blocks()
@@ -374,6 +427,8 @@ def main():
     print("inference")
     capture_inference("inf_tin2_spade_eval", 2, True, 2, False, True, 5)
     capture_inference("inf_tin1_nospade_train_gt", 1, False, 1, True, False, 6)
+    print("data")
+    capture_data(ref_utils)
 
 
 if __name__ == "__main__":

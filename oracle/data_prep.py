@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE (oracle) -- CPU restatement of the sample-building arithmetic of the reference's dataset class
 (src/datasets/cityscapes.py), from decoded arrays to the tensors of the batch dict.  torchvision's ToTensor is an absent
 third-party dependency (unpinned); its published behaviour is restated: uint8 HWC ndarray -> CHW float32
-`.div(255)`; non-uint8 arrays are only transposed.  "parity unpinned" for this file: the reference has no fixtures for its
-dataset code and needs image files to run.
+`.div(255)`; non-uint8 arrays are only transposed.  "parity unpinned" for the image / mask functions: the reference has
+no fixtures for its dataset code and they need torchvision + image files to run.  The scene-graph and .flo functions at the
+end of the file ARE pinned: tests/golden/data_scene_graph.npz holds the live reference's outputs on committed track files.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module."""
 import torch
 
@@ -41,3 +42,58 @@ def load_flow_occ(occ_u8, flow_hwc):
     occ = clip_mask(torch.stack([to_tensor(o) for o in occ_u8], dim=1))
     flow = torch.stack([torch.as_tensor(f).permute(2, 0, 1) for f in flow_hwc], dim=1)
     return occ, flow
+
+
+# ---------------------------------------------------------------------------------------------- scene graph
+# Pinned against the live reference by tests/golden/data_scene_graph.npz (oracle/capture_golden.py::capture_data).
+def scene_info(tracks, size, t_in, num_frames, lambda_traj=1):
+    """cityscapes.py:79-193 as scalar Python loops (one instance = its list of "x,y,w,h,...,id" lines).
+    Returns a dict of float32 / int64 numpy arrays with the field names of the reference's Data object."""
+    import numpy as np
+    from itertools import permutations
+    H, W = size
+    out = {k: [] for k in ("x", "roi", "roi_pad", "src_ids", "tgt_ids", "tgt_roi", "bary", "disp", "theta")}
+    for lines in tracks:
+        rows = [ln.split(",") for ln in lines[:num_frames]]
+        feat, roi_s, pad_s, ids_s, ids_t, roi_t, bary_t, disp_t, theta_t = [], [], [], [], [], [], [], [], []
+        last_bary = last_size = None
+        for idx, c in enumerate(rows):
+            bx, by, bw, bh = (float(v) for v in c[:4])
+            x_l, x_r = bx / 2048 * W, (bx + bw) / 2048 * W                        # :113-116
+            y_t, y_b = by / 1024 * H, (by + bh) / 1024 * H                        # :117-120
+            x_c = (x_l + x_r) / 2
+            if idx >= t_in and lambda_traj > 1:                                   # :128-141
+                s = rows[t_in - 1]
+                xs = (float(s[0]) / 2048 * W + (float(s[0]) + float(s[2])) / 2048 * W) / 2
+                d = (x_c - xs) * lambda_traj
+                x_c, x_l, x_r = xs + d, x_l + d, x_r + d
+            pad = [max(x_l - 15, 0), min(x_r + 15, W), max(y_t - 10, 0), min(y_b + 10, H)]
+            bary = np.array([(y_t + y_b) / 2 / H * 2 - 1, x_c / W * 2 - 1])       # :142
+            sz = np.array([bh / 1024, bw / 2048])                                 # :121
+            if idx < t_in:                                                        # :143-151
+                feat.append([bary[0], bary[1], sz[0], sz[1]] + list(np.eye(19)[int(c[-1]) // 1000]))
+                ids_s.append(int(c[-1])); roi_s.append([x_l, x_r, y_t, y_b]); pad_s.append(pad)
+                last_bary, last_size = bary, sz
+            else:                                                                 # :152-160
+                d = last_bary - bary
+                sc = last_size / sz
+                ids_t.append(int(c[-1])); roi_t.append([x_l, x_r, y_t, y_b]); bary_t.append(bary); disp_t.append(d)
+                theta_t.append([sc[1], 0, d[1], 0, sc[0], d[0]])
+        for k, v in zip(out, (feat, roi_s, pad_s, ids_s, ids_t, roi_t, bary_t, disp_t, theta_t)):
+            out[k].append(v)
+    n = len(tracks)
+    res = {k: np.asarray(v, dtype=np.int64 if k.endswith("ids") else np.float32) for k, v in out.items()}
+    res["edge_index"] = np.asarray(list(permutations(range(n), 2)) or [[0, 0]], dtype=np.int64).T
+    res["tracking_ids"] = np.concatenate([res["src_ids"], res["tgt_ids"]], 1).T
+    return res
+
+
+def read_flo(path):
+    """utils.py:324-343."""
+    import numpy as np
+    with open(path, "rb") as f:
+        if np.fromfile(f, np.float32, count=1) != 202021.25:
+            return None
+        w = int(np.fromfile(f, np.int32, count=1)[0])
+        h = int(np.fromfile(f, np.int32, count=1)[0])
+        return np.resize(np.fromfile(f, np.float32, count=2 * w * h), (h, w, 2))
