@@ -93,6 +93,53 @@ __global__ void norm_finalize_kernel(const float* __restrict__ partial, float* _
     }
 }
 
+// Batch statistics (mode 1): one wave per channel.  A thread per channel walks N * chunks partials through a chain of
+// dependent double divisions (8-10 us for N = 40); here each lane merges every 64th partial and the 64 lane results are
+// merged pairwise (Chan et al.), lane 0 holding the channel's statistics.
+__global__ __launch_bounds__(256) void norm_finalize_bn_kernel(const float* __restrict__ partial,
+                                                               float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, NormShape sh, float eps,
+                                                               float momentum) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= sh.C) return;                                   // wave-uniform
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int total = sh.N * sh.chunks;
+    for (int e = lane; e < total; e += 64) {
+        const int r = e / sh.chunks, c = e - r * sh.chunks;
+        const long q = (((long)r * sh.C + ch) * sh.chunks + c) * 2;
+        const long beg = (long)c * NORM_CHUNK;
+        const double nb = (double)((beg + NORM_CHUNK < sh.S ? beg + NORM_CHUNK : sh.S) - beg);
+        const double mb = partial[q], vb = partial[q + 1];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += vb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), vb = __shfl_down(m2, o, 64);
+        const double tot = n + nb;
+        if (tot > 0.0) {
+            const double delta = mb - mean;
+            mean += delta * nb / tot;
+            m2 += vb + delta * delta * n * nb / tot;
+            n = tot;
+        }
+    }
+    if (lane != 0) return;
+    const double var = m2 / n;
+    mean_out[ch] = (float)mean;
+    invstd_out[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+    }
+}
+
 C2M_API long c2m_norm_workspace_floats(int N, int C, long S) { return (long)N * C * norm_chunks(S) * 4; }
 
 C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
@@ -104,8 +151,12 @@ C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* ru
     hipLaunchKernelGGL(norm_partial_kernel, dim3((unsigned)((long)N * C * sh.chunks)), dim3(256), 0, s, x, workspace, S,
                        sh.chunks);
     const int nstat = mode == 0 ? N * C : C;
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(c2m_cdiv(nstat, 128)), dim3(128), 0, s, workspace, mean, invstd,
-                       running_mean, running_var, sh, eps, momentum);
+    if (mode == 1 && N * sh.chunks >= 16)
+        hipLaunchKernelGGL(norm_finalize_bn_kernel, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, workspace, mean, invstd,
+                           running_mean, running_var, sh, eps, momentum);
+    else
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(c2m_cdiv(nstat, 128)), dim3(128), 0, s, workspace, mean, invstd,
+                           running_mean, running_var, sh, eps, momentum);
     return (int)hipGetLastError();
 }
 
@@ -325,6 +376,44 @@ __global__ void norm_bwd_finalize_kernel(const BwdP p) {
     }
 }
 
+// One wave per channel (see norm_finalize_bn_kernel): batch mode sums all N * chunks partials of the channel; instance
+// mode gives each lane whole planes (their coefficients) and sums the lane totals for the affine gradients.
+__global__ __launch_bounds__(256) void norm_bwd_finalize_wave_kernel(const BwdP p) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= p.C) return;
+    const double ga = p.gamma ? (double)p.gamma[ch] : 1.0;
+    double s1 = 0.0, s2 = 0.0;
+    if (p.mode == 1) {
+        const int total = p.N * p.chunks;
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / p.chunks, c = e - r * p.chunks;
+            const long q = (((long)r * p.C + ch) * p.chunks + c) * 2;
+            s1 += p.partial[q]; s2 += p.partial[q + 1];
+        }
+    } else {
+        for (int r = lane; r < p.N; r += 64) {
+            const long plane = (long)r * p.C + ch;
+            double a = 0.0, b = 0.0;
+            for (int c = 0; c < p.chunks; ++c) {
+                const long q = (plane * p.chunks + c) * 2;
+                a += p.partial[q]; b += p.partial[q + 1];
+            }
+            p.coef[plane * 2 + 0] = (float)(ga * a / (double)p.S);
+            p.coef[plane * 2 + 1] = (float)(ga * b / (double)p.S);
+            s1 += a; s2 += b;
+        }
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane != 0) return;
+    if (p.mode == 1) {
+        const double cnt = (double)p.N * (double)p.S;
+        p.coef[ch * 2 + 0] = (float)(ga * s1 / cnt);
+        p.coef[ch * 2 + 1] = (float)(ga * s2 / cnt);
+    }
+    if (p.dgamma) { p.dgamma[ch] = (float)s2; p.dbeta[ch] = (float)s1; }
+}
+
 __global__ void norm_bwd_apply_kernel(const BwdP p) {
     const long total = (long)p.N * p.C * p.S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -398,7 +487,10 @@ C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, con
     p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
     hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
     const int nthreads = mode == 0 ? N * C : C;
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
+    if (N * p.chunks >= 16 && (mode == 1 || dgamma))
+        hipLaunchKernelGGL(norm_bwd_finalize_wave_kernel, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
     if (norm_vec_ok(S, x, gy, gb, dx))
         hipLaunchKernelGGL(norm_bwd_apply_vec_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
     else

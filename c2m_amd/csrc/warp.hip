@@ -249,36 +249,71 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
 }
 
 // adjoint of the x2 (align_corners=False, scale 0.5) upsample, gather form (deterministic, no atomics)
+__device__ __forceinline__ float upsample2x_bwd_pixel(const float* __restrict__ g, int y, int x, int Hi, int Wi) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    float wy[4], wx[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int oy = 2 * y - 1 + d, ox = 2 * x - 1 + d;
+        wy[d] = 0.0f; wx[d] = 0.0f;
+        if (oy >= 0 && oy < Ho) { const Lerp l = lerp_src(oy, Hi, 0.5f, false); wy[d] = (l.i0 == y ? l.l0 : 0.0f) + (l.i1 == y ? l.l1 : 0.0f); }
+        if (ox >= 0 && ox < Wo) { const Lerp l = lerp_src(ox, Wi, 0.5f, false); wx[d] = (l.i0 == x ? l.l0 : 0.0f) + (l.i1 == x ? l.l1 : 0.0f); }
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int oy = 2 * y - 1 + a;
+        if (wy[a] == 0.0f) continue;
+        float row = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ox = 2 * x - 1 + b;
+            if (wx[b] != 0.0f) row += wx[b] * g[oy * Wo + ox];
+        }
+        acc += wy[a] * row;
+    }
+    return acc;
+}
+
 template <typename I>
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long NC, int Hi, int Wi) {
-    const int Ho = 2 * Hi, Wo = 2 * Wi;
     const I total = (I)(NC * Hi * Wi);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
         const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
-        const float* __restrict__ g = gout + (long)nc * Ho * Wo;
-        float wy[4], wx[4];
+        gin[i] = upsample2x_bwd_pixel(gout + (long)nc * (4L * Hi * Wi), y, x, Hi, Wi);
+    }
+}
+
+// Even widths, 8-byte aligned tensors: each lane produces two adjacent gradients from four 8-byte loads per output row
+// (the interior weights are the constants 1/4, 3/4, 3/4, 1/4 in both directions); image borders take the generic path.
+template <typename I>
+__global__ void upsample2x_bwd_pair_kernel(const float* __restrict__ gout, float* __restrict__ gin, long NC, int Hi, int Wi) {
+    const int Wo = 2 * Wi, Wp = Wi / 2;
+    const I total = (I)(NC * Hi * Wp);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int j = (int)(i % (I)Wp); const I r = i / (I)Wp;
+        const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
+        const int x = 2 * j;
+        const float* __restrict__ g = gout + (long)nc * (4L * Hi * Wi);
+        float2 out;
+        if (y >= 1 && y < Hi - 1 && j >= 1 && x + 2 < Wi) {
+            float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int oy = 2 * y - 1 + d, ox = 2 * x - 1 + d;
-            wy[d] = 0.0f; wx[d] = 0.0f;
-            if (oy >= 0 && oy < Ho) { const Lerp l = lerp_src(oy, Hi, 0.5f, false); wy[d] = (l.i0 == y ? l.l0 : 0.0f) + (l.i1 == y ? l.l1 : 0.0f); }
-            if (ox >= 0 && ox < Wo) { const Lerp l = lerp_src(ox, Wi, 0.5f, false); wx[d] = (l.i0 == x ? l.l0 : 0.0f) + (l.i1 == x ? l.l1 : 0.0f); }
-        }
-        float acc = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int oy = 2 * y - 1 + a;
-            if (wy[a] == 0.0f) continue;
-            float row = 0.0f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int ox = 2 * x - 1 + b;
-                if (wx[b] != 0.0f) row += wx[b] * g[oy * Wo + ox];
+            for (int a = 0; a < 4; ++a) {
+                const float wy = (a == 0 || a == 3) ? 0.25f : 0.75f;
+                const float2* __restrict__ rp = reinterpret_cast<const float2*>(g + (2 * y - 1 + a) * Wo + 2 * x - 2);
+                const float2 v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3];
+                float row0 = 0.0f, row1 = 0.0f;
+                row0 += 0.25f * v0.y; row0 += 0.75f * v1.x; row0 += 0.75f * v1.y; row0 += 0.25f * v2.x;
+                row1 += 0.25f * v1.y; row1 += 0.75f * v2.x; row1 += 0.75f * v2.y; row1 += 0.25f * v3.x;
+                acc0 += wy * row0; acc1 += wy * row1;
             }
-            acc += wy[a] * row;
+            out = make_float2(acc0, acc1);
+        } else {
+            out = make_float2(upsample2x_bwd_pixel(g, y, x, Hi, Wi), upsample2x_bwd_pixel(g, y, x + 1, Hi, Wi));
         }
-        gin[i] = acc;
+        *reinterpret_cast<float2*>(gin + ((long)nc * Hi + y) * Wi + x) = out;
     }
 }
 
@@ -295,7 +330,11 @@ C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, i
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    C2M_IDX_DISPATCH(total * 4, upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, gout, gin, NC, Hi, Wi);
+    if ((Wi & 1) == 0 && Wi >= 4 && ((((uintptr_t)gout) | ((uintptr_t)gin)) & 7) == 0) {
+        C2M_IDX_DISPATCH(total * 4, upsample2x_bwd_pair_kernel, dim3(c2m_grid(total / 2, 256)), (hipStream_t)stream, gout, gin, NC, Hi, Wi);
+    } else {
+        C2M_IDX_DISPATCH(total * 4, upsample2x_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, gout, gin, NC, Hi, Wi);
+    }
     return (int)hipGetLastError();
 }
 

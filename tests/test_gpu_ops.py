@@ -259,7 +259,9 @@ def test_conv_big_wgrad_splitk():
 
 
 # ----------------------------------------------------------------------------------------------- norm + act
-@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 4, 5, 6, 8), (4, 16, 2, 4), (2, 3, 100, 90), (6, 8)])
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 4, 5, 6, 8), (4, 16, 2, 4), (2, 3, 100, 90), (6, 8),
+                                   # >= 16 partials per channel: the wave-per-channel finalize kernels
+                                   (20, 6, 16, 24), (70, 3, 4, 4), (2, 3, 300, 300)])
 @pytest.mark.parametrize("act", [None, "lrelu", "relu"])
 def test_batch_norm_act(shape, act):
     x = rnd(1, *shape) * 2 + 3.0          # non-zero mean: the statistics must be cancellation-safe
@@ -284,7 +286,7 @@ def test_batch_norm_act(shape, act):
     close(bg.grad, br.grad, 1e-4, 1e-4, "bn dbeta")
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 9, 11), (3, 8, 2, 4), (1, 4, 130, 70)])
+@pytest.mark.parametrize("shape", [(2, 5, 9, 11), (3, 8, 2, 4), (1, 4, 130, 70), (20, 5, 9, 11), (70, 3, 4, 4)])
 @pytest.mark.parametrize("affine", [True, False])
 def test_instance_norm_act(shape, affine):
     x = rnd(1, *shape) + 1.5
@@ -368,7 +370,7 @@ def test_flow_warp_full_size_c_oracle_bitexact():
     assert np.array_equal(y, ref)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (5, 8, 16, 32), (1, 2, 7, 5)])
+@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (5, 8, 16, 32), (1, 2, 7, 5), (1, 1, 1, 4), (2, 2, 3, 2), (3, 2, 9, 14)])
 def test_upsample2x(shape):
     x = rnd(1, *shape)
     xr = x.clone().requires_grad_(True)
