@@ -635,7 +635,38 @@ def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None):
     reflect = padding_mode == "reflect" and any(pad3)
     if padding_mode not in ("zeros", "reflect"):
         raise NotImplementedError(f"padding_mode {padding_mode}")
+    # The kernels address each tensor with 32-bit byte offsets (< 2 GiB).  Larger activations (40 folded frames x 128
+    # channels at 256x512 = 2.7 GB) are run as batch chunks: images are independent in the forward pass and the data
+    # gradient, and autograd sums the chunks' weight gradients.
+    n = x.shape[0]
+    k = _chunks_for_2gib(x.shape, w.shape, stride3, pad3)
+    if k > 1:
+        size = _cdiv(n, k)
+        return torch.cat([_ConvFn.apply(xc, w, b, stride3, pad3, reflect, act) for xc in x.split(size)], 0)
     return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act)
+
+
+_MAX_TENSOR_BYTES = int(0.9 * 2 ** 31)      # 10 % margin: the Winograd data gradient rounds its padded domain up to whole tiles
+
+
+def _chunks_for_2gib(xs, ws, stride, pad):
+    """Number of batch chunks that keeps the input (incl. its padded data-gradient domain) and the output of one
+    launch under 2 GiB; 1 for everything the bench configurations use at 128x256."""
+    n, cin, cout = xs[0], xs[1], ws[0]
+    sp_in = [d for d in xs[2:]]
+    k3 = list(ws[2:])
+    nd = len(sp_in)
+    padded, out = 1, 1
+    for d in range(nd):
+        padded *= sp_in[d] + 2 * pad[3 - nd + d]
+        out *= max((sp_in[d] + 2 * pad[3 - nd + d] - k3[d]) // stride[3 - nd + d] + 1, 1)
+    per_image = 4 * max(cin * padded, cout * out)
+    if n * per_image < _MAX_TENSOR_BYTES:
+        return 1
+    fit = (_MAX_TENSOR_BYTES - 1) // per_image
+    if fit < 1:
+        raise ValueError("tensor too large: one image exceeds the 32-bit byte offsets of the gather (< 2 GiB)")
+    return _cdiv(n, fit)
 
 
 # =============================================================================================== norm + act

@@ -548,3 +548,42 @@ def test_conv_degenerate_extents(xs, cout, k, pad):
     rel_close(xg.grad, xr.grad, 5e-5, "dgrad")
     rel_close(wg.grad, wr.grad, 1e-4, "wgrad")
     rel_close(bg.grad, br.grad, 1e-4, "bias grad")
+
+
+@pytest.mark.parametrize("case", [(6, 8, 20, 24, 16, 3, 1, 1, "reflect"), (5, 4, 3, 16, 16, 8, (3, 4, 4), (1, 2, 2), 1, "reflect"),
+                                  (7, 64, 16, 32, 64, 3, 1, 1, "zeros")])
+def test_conv_batch_chunking_for_tensors_over_2gib(case, monkeypatch):
+    """Activations >= 2 GiB (40 folded frames x 128 channels at 256x512) run as batch chunks; the limit is lowered here
+    so that small tensors take that path: same outputs and gradients as the single launch."""
+    if len(case) == 9:
+        n, cin, h, w_, cout, k, stride, pad, mode = case
+        xs, ws = (n, cin, h, w_), (cout, cin, k, k)
+    else:
+        n, cin, t, h, w_, cout, k, stride, pad, mode = case
+        xs, ws = (n, cin, t, h, w_), (cout, cin) + tuple(k)
+    x, w, b = rnd(1, *xs), rnd(2, *ws) * 0.1, rnd(3, ws[0]) * 0.1
+    nd = len(xs) - 2
+    s3, p3 = ops._triple(stride, nd), ops._pad3(pad, nd)
+    small = 1 << 10                                       # smallest power of two that still fits one image
+    while True:
+        monkeypatch.setattr(ops, "_MAX_TENSOR_BYTES", small)
+        try:
+            ops._chunks_for_2gib(xs, ws, s3, p3)
+            break
+        except ValueError:
+            small *= 2
+    monkeypatch.undo()
+    outs = []
+    for limit in (None, small):
+        if limit is not None:
+            monkeypatch.setattr(ops, "_MAX_TENSOR_BYTES", limit)
+            assert ops._chunks_for_2gib(xs, ws, s3, p3) >= 3
+        xg, wg, bg = (g(t_).requires_grad_(True) for t_ in (x, w, b))
+        y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
+        (y * g(rnd(4, *y.shape))).sum().backward()
+        outs.append((y.detach(), xg.grad, wg.grad, bg.grad))
+    for a, c, name in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
+        rel_close(c, a, 2e-5, name)
+    with pytest.raises(ValueError):
+        monkeypatch.setattr(ops, "_MAX_TENSOR_BYTES", 1024)
+        ops.conv(g(x), g(w), None, stride=stride, padding=pad, padding_mode=mode)
