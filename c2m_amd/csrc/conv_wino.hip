@@ -167,58 +167,84 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
         transform_store(d0, 0);
     }
     int pnext = 1;                                     // patch buffer of chunk + 1 = (chunk + 1) % 3
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    // One K-loop iteration; `ucur` holds U(chunk), U(chunk + 1) is loaded into `unext`.  The loop below is unrolled by two
+    // with the two register sets swapping roles, so no register copies follow the wait.  The U requests are issued in the
+    // shadow of the first eight MFMAs (two per MFMA pair) instead of in front of them, the DMA requests of patch(chunk + 2)
+    // behind those (U loads stay older than the DMAs, so the counted wait still separates them), and the input transform of
+    // the next chunk is mixed into the remaining MFMAs.
+    auto iteration = [&](const int chunk, f32x4 (&ucur)[8], f32x4 (&unext)[8]) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < p.nchunks;
         // patch(chunk + 1) (this wave's part) has landed: nothing younger is in flight at this point
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();       // V(chunk) complete; patch(chunk+1) complete; everyone is done with V(chunk-1) = buffer cur^1
-        // ---- this wave's V fragments, then the requests for later chunks (all through asm: the compiler inserts no vmcnt)
         float b[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 b[j][kk] = sV[cur * (16 * CKW * 32) + ((4 * wave + j) * CKW + 2 * kk + (lane >> 5)) * 32 + (lane & 31)];
-        f32x4 un[8];
-        {
-            const float* q = ubase + (more ? chunk + 1 : chunk) * ustride;
+        const float* q = ubase + (more ? chunk + 1 : chunk) * ustride;
+        auto mfma_pair = [&](int g) {                  // g = kk * 4 + j
+            const int kk = g >> 2, j = g & 3;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(un[i]) : "v"(q + i * 256) : "memory");
+            for (int mi = 0; mi < 2; ++mi) {
+                const f32x4 v = ucur[j * 2 + mi];
+                const float av = kk == 0 ? v.x : (kk == 1 ? v.y : (kk == 2 ? v.z : v.w));
+                acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][kk], acc[j][mi], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mfma_pair(g);
+#pragma unroll
+            for (int i = 2 * g; i < 2 * g + 2; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(unext[i]) : "v"(q + i * 256) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (chunk + 2 < p.nchunks) load_patch(chunk + 2, pnext == 2 ? 0 : pnext + 1);
-        // ---- the input transform of the NEXT chunk is interleaved with this chunk's MFMAs (same wave): LDS reads first,
-        // then the scheduler mixes the 32 MFMAs with the ~48 VALU and 16 LDS writes of the transform
+        // patch(chunk + 2) -- always issued, so the iteration is one basic block and the requests sit between MFMAs; past
+        // the last chunk every lane's offset is out of range (the loads return 0 into a patch buffer nobody reads)
+        const bool pre = chunk + 2 < p.nchunks;
+        const int soff = pre ? (chunk + 2) * CKW * p.in_sc * 4 : 0;
+        const int dbuf = pnext == 2 ? 0 : pnext + 1;
+#pragma unroll
+        for (int g = 4; g < 4 + PLOADS / 2; ++g) {
+            mfma_pair(g);
+#pragma unroll
+            for (int i = 2 * (g - 4); i < 2 * (g - 4) + 2; ++i) {
+                const unsigned dst = sp_lds + (unsigned)((dbuf * PLOADS * 256 + wave * 64 + i * 256) * 4);
+                const unsigned vo = pre ? pvo[i] : WINO_OOB;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float d[4][4];
         read_d(pnext, d);                               // (last chunk: stale but in-bounds data, result unused)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const f32x4 v = ua[j * 2 + mi];
-                    const float av = kk == 0 ? v.x : (kk == 1 ? v.y : (kk == 2 ? v.z : v.w));
-                    acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][kk], acc[j][mi], 0, 0, 0);
-                }
+        for (int g = 4 + PLOADS / 2; g < 16; ++g) mfma_pair(g);
         transform_store(d, cur ^ 1);                    // unconditional: one basic block, so it can interleave
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {                 // 2 MFMA : 3 VALU : 1 LDS write
+        for (int g = 0; g < 9; ++g) {                  // 2 MFMA : 4 VALU : 2 LDS writes (18 MFMAs)
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         }
-        // the 8 U loads are older than the (up to 6) DMA loads issued after them
-        if (chunk + 2 < p.nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the 8 U loads are older than the 6 DMA loads issued after them
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            asm volatile("" : "+v"(un[i]));            // the copies must stay behind the wait
-            ua[i] = un[i];
-        }
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(unext[i]));   // uses of U(chunk + 1) stay behind the wait
         pnext = pnext == 2 ? 0 : pnext + 1;
+    };
+    f32x4 ub[8];
+    int chunk = 0;
+    for (; chunk + 1 < p.nchunks; chunk += 2) {
+        iteration(chunk, ua, ub);
+        iteration(chunk + 1, ub, ua);
     }
+    if (chunk < p.nchunks) iteration(chunk, ua, ub);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) DMAs of the last iterations must not outlive the block's LDS
+    static_assert(PLOADS == 6, "the DMA issue slots assume six patch loads per thread");
     __syncthreads();
 
     // ---- inverse transform.  Column part in registers: R_i[q] = sum_j M[i][j] A[j][q], A = [[1,0],[1,1],[1,-1],[0,-1]]
