@@ -317,6 +317,62 @@ __global__ void upsample2x_bwd_pair_kernel(const float* __restrict__ gout, float
     }
 }
 
+// Large maps: one workgroup = an 8 x 64 tile of the input-resolution gradient; the 18 x 130 window of `gout` it needs is
+// staged in LDS once with coalesced loads (the gather forms above fetch every gout element four times through the L1),
+// then each lane combines two outputs from 8-byte LDS reads.  Same weights as upsample2x_bwd_pixel (out-of-range window
+// elements are stored as 0 and carry weight 0).
+constexpr int UB_TY = 8, UB_TX = 64, UB_LR = 2 * UB_TY + 2, UB_LC = 2 * UB_TX + 2, UB_LS = UB_LC + 2;
+__global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* __restrict__ gout, float* __restrict__ gin,
+                                                                  int Hi, int Wi) {
+    __shared__ __attribute__((aligned(8))) float tile[UB_LR][UB_LS];
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int tiles_x = (Wi + UB_TX - 1) / UB_TX, tiles_y = (Hi + UB_TY - 1) / UB_TY;
+    unsigned tb = blockIdx.x;
+    const int tx = tb % tiles_x; tb /= tiles_x;
+    const int ty = tb % tiles_y; const unsigned nc = tb / tiles_y;
+    const int y0 = ty * UB_TY, x0 = tx * UB_TX;
+    const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
+    const float* __restrict__ g = gout + (long)nc * Ho * Wo;
+    for (int e = threadIdx.x; e < UB_LR * UB_LC; e += 256) {
+        const int r = e / UB_LC, c = e - r * UB_LC;
+        const int gy = gy0 + r, gx = gx0 + c;
+        tile[r][c] = ((unsigned)gy < (unsigned)Ho && (unsigned)gx < (unsigned)Wo) ? g[gy * Wo + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int y = y0 + ly;
+    if (y >= Hi) return;
+    float wy[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int oy = 2 * y - 1 + d;
+        wy[d] = 0.0f;
+        if (oy >= 0 && oy < Ho) { const Lerp q = lerp_src(oy, Hi, 0.5f, false); wy[d] = (q.i0 == y ? q.l0 : 0.0f) + (q.i1 == y ? q.l1 : 0.0f); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int lx = l + 32 * h, x = x0 + lx;
+        if (x >= Wi) continue;
+        float wx[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int ox = 2 * x - 1 + d;
+            wx[d] = 0.0f;
+            if (ox >= 0 && ox < Wo) { const Lerp q = lerp_src(ox, Wi, 0.5f, false); wx[d] = (q.i0 == x ? q.l0 : 0.0f) + (q.i1 == x ? q.l1 : 0.0f); }
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float2 v0 = *reinterpret_cast<const float2*>(&tile[2 * ly + a][2 * lx]);
+            const float2 v1 = *reinterpret_cast<const float2*>(&tile[2 * ly + a][2 * lx + 2]);
+            float row = 0.0f;
+            row += wx[0] * v0.x; row += wx[1] * v0.y; row += wx[2] * v1.x; row += wx[3] * v1.y;
+            acc += wy[a] * row;
+        }
+        gin[((long)nc * Hi + y) * Wi + x] = acc;
+    }
+}
+
 C2M_API int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
@@ -330,6 +386,14 @@ C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, i
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
+    if (Wi >= 64 && Hi >= 8 && total * 4 < (1L << 31)) {
+        const long tiles = (long)c2m_cdiv(Wi, UB_TX) * c2m_cdiv(Hi, UB_TY) * NC;
+        if (tiles < (1L << 31)) {
+            hipLaunchKernelGGL(upsample2x_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, gout, gin,
+                               Hi, Wi);
+            return (int)hipGetLastError();
+        }
+    }
     if ((Wi & 1) == 0 && Wi >= 4 && ((((uintptr_t)gout) | ((uintptr_t)gin)) & 7) == 0) {
         C2M_IDX_DISPATCH(total * 4, upsample2x_bwd_pair_kernel, dim3(c2m_grid(total / 2, 256)), (hipStream_t)stream, gout, gin, NC, Hi, Wi);
     } else {

@@ -370,7 +370,9 @@ def test_flow_warp_full_size_c_oracle_bitexact():
     assert np.array_equal(y, ref)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (5, 8, 16, 32), (1, 2, 7, 5), (1, 1, 1, 4), (2, 2, 3, 2), (3, 2, 9, 14)])
+@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (5, 8, 16, 32), (1, 2, 7, 5), (1, 1, 1, 4), (2, 2, 3, 2), (3, 2, 9, 14),
+                                   # Wi >= 64 and Hi >= 8: the LDS-tiled backward kernel (ragged tiles included)
+                                   (2, 3, 9, 70), (1, 2, 16, 64), (1, 1, 8, 130), (3, 2, 21, 67)])
 def test_upsample2x(shape):
     x = rnd(1, *shape)
     xr = x.clone().requires_grad_(True)
