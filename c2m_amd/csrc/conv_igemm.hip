@@ -924,14 +924,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 
 // dW[m][c*taps + tap] = sum_s slab[s][m][col(c, tap)] with the (chunk, tap group, slot, channel) row order;
 // db[m] = sum_s slab[s][m][ones_col]
-// One workgroup = 64 consecutive outputs in the slab's own (m, column) order x 4 groups of splits (wave g sums the splits
-// s = g, g + 4, ...; its 64 lanes read 256 contiguous bytes per split), the four partial sums are combined in a fixed order
+// One workgroup = 64 consecutive outputs in the slab's own (m, column) order x G groups of splits (G = 4, or 16 from 64
+// splits on; wave g sums the splits s = g, g + G, ...; its 64 lanes read 256 contiguous bytes per split), the four partial sums are combined in a fixed order
 // through LDS.  A thread per output with the whole S loop left a 32 x 304 layer with 256 splits on 38 workgroups of
 // 256 dependent loads each (177 us for 12 MB).  The single write per output is the scattered one.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
-                                                           float* __restrict__ db, int M, int J, int Cin, int taps, int NS,
-                                                           int ntg, int ngroups, int S) {
-    __shared__ float part[4][64];
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
+                                                              float* __restrict__ db, int M, int J, int Cin, int taps, int NS,
+                                                              int ntg, int ngroups, int S) {
+    __shared__ float part[G][64];
     const int CK = 16 / NS;
     const int used = (ngroups + 1) * 16;                  // real groups + the ones group; pad columns are skipped
     const long total = (long)M * used;
@@ -956,22 +957,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         float acc = 0.f;
         if (dst != -1) {
             int sp = grp;
-            for (; sp + 12 < S; sp += 16) {                // four independent loads in flight
-                const float v0 = slab[(long)sp * per + src], v1 = slab[(long)(sp + 4) * per + src];
-                const float v2 = slab[(long)(sp + 8) * per + src], v3 = slab[(long)(sp + 12) * per + src];
+            for (; sp + 3 * G < S; sp += 4 * G) {          // four independent loads in flight
+                const float v0 = slab[(long)sp * per + src], v1 = slab[(long)(sp + G) * per + src];
+                const float v2 = slab[(long)(sp + 2 * G) * per + src], v3 = slab[(long)(sp + 3 * G) * per + src];
                 acc += v0; acc += v1; acc += v2; acc += v3;
             }
-            for (; sp < S; sp += 4) acc += slab[(long)sp * per + src];
+            for (; sp < S; sp += G) acc += slab[(long)sp * per + src];
         }
         __syncthreads();                                   // the previous round's reads of `part` are done
         part[grp][lane] = acc;
         __syncthreads();
         if (grp == 0 && dst != -1) {
-            const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < G; q += 4) v += (part[q][lane] + part[q + 1][lane]) + (part[q + 2][lane] + part[q + 3][lane]);
             if (dst <= -2) { if (db) db[-2 - dst] = v; }
             else dW[dst] = v;
         }
     }
+}
+
+static int launch_wgrad_reduce(long total, hipStream_t s, const float* slab, float* dW, float* db, int M, int J, int Cin,
+                               int taps, int NS, int ntg, int ngroups, int S) {
+    if (S >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(c2m_grid(total, 64)), dim3(1024), 0, s, slab, dW, db, M, J, Cin, taps,
+                           NS, ntg, ngroups, S);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(c2m_grid(total, 64)), dim3(256), 0, s, slab, dW, db, M, J, Cin, taps,
+                           NS, ntg, ngroups, S);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ thin layers
@@ -1308,9 +1322,7 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
         int rc2 = (int)hipGetLastError();
         if (rc2) return rc2;
         const long total2 = (long)p.M * (ngroups + 1) * 16;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total2, 64)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
-                           taps, NS, ntg, ngroups, Sthin);
-        return (int)hipGetLastError();
+        return launch_wgrad_reduce(total2, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Sthin);
     }
     const bool bf16 = g[34] == 1;
 #define C2M_WG(BMv, BNv, WGMv, WGNv)                                                                                  \
@@ -1332,9 +1344,7 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long total = (long)p.M * (ngroups + 1) * 16;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(c2m_grid(total, 64)), dim3(256), 0, s, slab, dW, db, p.M, p.J, Cin,
-                       taps, NS, ntg, ngroups, Seff);
-    return (int)hipGetLastError();
+    return launch_wgrad_reduce(total, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Seff);
 }
 
 // ------------------------------------------------------------------------------------------------ reflect fold
