@@ -847,13 +847,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             }
         }
     };
-    // software pipeline (64- and 32-row tiles; +8..15 % measured): the gathers of K-step i+1 are in flight while the
-    // MFMAs of step i run.  The 128x128 tile gains nothing from it (2 blocks/CU already cover the latency) and would
-    // pay 32 more VGPRs, so it loads at the top of its own step.
+    // The same loads in four parts (128-row tile): each part is issued between the MFMAs of one k-group of the previous step
+    // (no branch: the ones group loads through an out-of-range offset and is patched with a select).
+    struct PixCtx { unsigned yvo, ximg; int ots, oys, oxs; bool live; };
+    auto load_prep = [&](int pk) {
+        const int pix = pk + lane;
+        PixCtx c;
+        c.live = pix < pend;
+        int n, ot, oy, ox;
+        decompose_pix(c.live ? pix : pend - 1, p, n, ot, oy, ox);
+        const int sp = (ot * p.Ho + oy) * p.Wo + ox;
+        c.yvo = c.live ? (unsigned)(n * (int)p.dy_sn + sp) * 4u : C2M_OOB;
+        c.ximg = (unsigned)(n * (int)p.in_sn) * 4u;
+        c.ots = ot * p.st; c.oys = oy * p.sh; c.oxs = ox * p.sw;
+        return c;
+    };
+    auto load_a_part = [&](const PixCtx& c, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            const int row = m0 + wave * AROWS + s;
+            ra[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, c.yvo, row * (int)p.dy_sc * 4, 0));
+        }
+    };
+    auto load_b_group = [&](const PixCtx& c, int gq) {
+        const int grp = (j0 + wave * BROWSW) / 16 + gq;
+        const int4* __restrict__ jd = p.jtab + (long)grp * (1 + NS);
+        const int4 hdr = jd[0];
+        const bool ones = hdr.y == -2;
+        unsigned vo[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int so = spatial_off(jd[1 + q], c.ots, c.oys, c.oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
+            vo[q] = (c.live && so >= 0 && !ones) ? c.ximg + (unsigned)so * 4u : C2M_OOB;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int slot = s / CK, cc = s % CK;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                xrsrc, vo[slot], (hdr.x + cc * p.in_sc) * 4, 0));       // ones group: every offset is out of range -> 0
+            rb[gq * 16 + s] = (s == 0 && ones) ? 1.f : v;
+        }
+    };
+    // software pipeline (64- and 32-row tiles; +8..15 % measured): the gathers of K-step i+1 are issued in front of the
+    // MFMAs of step i and are in flight while they run.  For the 128x128 tile that form is 4 % slower than loading at the
+    // top of the step (64 load issues in front of the MFMAs); it interleaves the loads with the MFMAs instead (IL).
     constexpr bool PIPE = BM < 128;
+    // 128-row tile: loads interleaved with the MFMAs of the previous step (below) instead: +3.5...6 %
+    constexpr bool IL = BM == 128 && !BF && BGROUPS == 2 && AROWS == 32;
     issue_loads(pbeg);
     for (int pk = pbeg; pk < pend; pk += BK) {
-        if (!PIPE && pk > pbeg) issue_loads(pk);
+        if (!PIPE && !IL && pk > pbeg) issue_loads(pk);
         __syncthreads();   // previous K-step's fragment reads are done
         if constexpr (BF) {
 #pragma unroll
@@ -883,6 +926,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        } else
+        if constexpr (IL) {
+            // 128-row tile: the fragment reads of k-group g + 1 and a quarter of the NEXT step's loads ride in the shadow of
+            // group g's 32 MFMAs (past the split's end every lane is out of range: zeros that are never stored)
+            float a[2][8][MI], b[2][8][NI];
+            auto read_group = [&](int kg, float (&fa)[8][MI], float (&fb)[8][NI]) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int kcol = (kg * 8 + kk) * 2 + (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[kk][i] = sA[wm * TM + i * 32 + (lane & 31)][kcol];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) fb[kk][j] = sB[wn * TN + j * 32 + (lane & 31)][kcol];
+                }
+            };
+            read_group(0, a[0], b[0]);
+            PixCtx nctx;
+#pragma unroll
+            for (int kg = 0; kg < BK / 16; ++kg) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kg + 1 < BK / 16) read_group(kg + 1, a[(kg + 1) & 1], b[(kg + 1) & 1]);
+                if (kg == 0) { nctx = load_prep(pk + BK); load_a_part(nctx, 0, 16); }
+                else if (kg == 1) load_a_part(nctx, 16, 32);
+                else load_b_group(nctx, kg - 2);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][kk][i], b[kg & 1][kk][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {             // 2 MFMA : 1 fragment read pair : 1 load (+ its address arithmetic)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         } else
         // fragment reads in groups of 8 k-pairs issued ahead of their MFMAs (see the igemm kernel)
 #pragma unroll
