@@ -891,9 +891,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     // software pipeline (64- and 32-row tiles; +8..15 % measured): the gathers of K-step i+1 are issued in front of the
     // MFMAs of step i and are in flight while they run.  For the 128x128 tile that form is 4 % slower than loading at the
     // top of the step (64 load issues in front of the MFMAs); it interleaves the loads with the MFMAs instead (IL).
-    constexpr bool PIPE = BM < 128;
-    // 128-row tile: loads interleaved with the MFMAs of the previous step (below) instead: +3.5...6 %
-    constexpr bool IL = BM == 128 && !BF && BGROUPS == 2 && AROWS == 32;
+    // fp32: the loads of step i+1 (and the fragment reads of k-group g+1) are interleaved with the MFMAs of step i
+    // (k-group g) below: +3.5...6 % on the 128-row tile over loading at the top of the step, +6...12 % on the 64- and
+    // 32-row tiles over the PIPE form
+    constexpr bool IL = !BF && BGROUPS == 2;
+    constexpr bool PIPE = BM < 128 && !IL;
     issue_loads(pbeg);
     for (int pk = pbeg; pk < pend; pk += BK) {
         if (!PIPE && !IL && pk > pbeg) issue_loads(pk);
@@ -928,8 +930,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             }
         } else
         if constexpr (IL) {
-            // 128-row tile: the fragment reads of k-group g + 1 and a quarter of the NEXT step's loads ride in the shadow of
-            // group g's 32 MFMAs (past the split's end every lane is out of range: zeros that are never stored)
+            // the fragment reads of k-group g + 1 and a part of the NEXT step's loads ride in the shadow of group g's MFMAs
+            // (past the split's end every lane is out of range: zeros that are never stored)
             float a[2][8][MI], b[2][8][NI];
             auto read_group = [&](int kg, float (&fa)[8][MI], float (&fb)[8][NI]) {
 #pragma unroll
@@ -947,9 +949,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             for (int kg = 0; kg < BK / 16; ++kg) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kg + 1 < BK / 16) read_group(kg + 1, a[(kg + 1) & 1], b[(kg + 1) & 1]);
-                if (kg == 0) { nctx = load_prep(pk + BK); load_a_part(nctx, 0, 16); }
-                else if (kg == 1) load_a_part(nctx, 16, 32);
-                else load_b_group(nctx, kg - 2);
+                if constexpr (AROWS == 32) {
+                    if (kg == 0) { nctx = load_prep(pk + BK); load_a_part(nctx, 0, 16); }
+                    else if (kg == 1) load_a_part(nctx, 16, 32);
+                    else load_b_group(nctx, kg - 2);
+                } else {                                   // 64- / 32-row tiles: all of dY with the first group
+                    if (kg == 0) { nctx = load_prep(pk + BK); load_a_part(nctx, 0, AROWS); }
+                    else if (kg <= 2) load_b_group(nctx, kg - 1);
+                }
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -957,11 +964,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][kk][i], b[kg & 1][kk][j], acc[i][j], 0, 0, 0);
+                constexpr int MPG = 8 * MI * NI;           // MFMAs per k-group: 32 / 16 / 8
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {             // 2 MFMA : 1 fragment read pair : 1 load (+ its address arithmetic)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                for (int g = 0; g < 16; ++g) {             // per slot: MFMAs, a fragment read pair, a load (+ its addresses)
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG >= 32 ? 2 : 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MPG >= 16 ? 2 : 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, MPG >= 16 ? 1 : 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 }
             }
