@@ -6,7 +6,7 @@ for round in 1 2; do
 for v in "$@"; do
   if [ "$v" = "default" ]; then unset C2M_AMD_LIB; else export C2M_AMD_LIB=$PWD/c2m_amd/lib/libc2m_hip_$v.so; fi
   for s in "${SHAPES[@]}"; do
-    echo "[$v r$round] $s :: $(python tools/conv_microbench.py $s 8 all 2>/dev/null | tr '\n' ' ' | cut -c1-600)"
+    echo "[$v r$round] $s :: $(python tools/conv_microbench.py $s ${ITERS:-8} all 2>/dev/null | tr '\n' ' ' | cut -c1-600)"
   done
 done
 done
