@@ -249,8 +249,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
 
     // ---- inverse transform.  Column part in registers: R_i[q] = sum_j M[i][j] A[j][q], A = [[1,0],[1,1],[1,-1],[0,-1]]
     // Row part through LDS: Y[0][q] = R_0 + R_1 + R_2, Y[1][q] = R_1 - R_2 - R_3 (i = wave)
-    float* __restrict__ sR = sV;                     // [q][w][16 cout][32 tiles] = 16 KB per pass (16 of the 64 couts)
+    // Every thread owns one output pixel (x, y) of the region for the whole epilogue and walks over the output channels, so
+    // the pixel's tile, row parity, bounds and target address are computed once (the per-element index arithmetic used to
+    // cost as much as the stores: 27 % of the kernel on the 64-channel layers).
+    constexpr int QS = 4 * 16 * 32 + 16;             // q stride: +16 floats keeps the two column parities on different banks
+    float* __restrict__ sR = sV;                     // [q][w][16 cout][32 tiles] per pass (16 of the 64 couts)
     const int m0 = mt * 64;
+    const int ex = tid & 15, ey = (tid >> 4) & 7, c0 = tid >> 7;
+    const int oy = oy0 + ey, ox = ox0 + ex;
+    const bool inb = oy < p.Ho && ox < p.Wo;
+    const bool top = (ey & 1) == 0;
+    float* __restrict__ ybase;
+    long cstride;
+    {
+        const int yi = oy - p.lo_y, xi = ox - p.lo_x;
+        if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y && (unsigned)xi < (unsigned)p.ext_x) {
+            ybase = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
+            cstride = p.y2_sc;
+        } else {
+            ybase = p.Y + p.out_off + (long)img * p.out_sn + (long)oy * p.out_sh + ox;
+            cstride = p.out_sc;
+        }
+    }
+    // R rows this pixel combines: top row r0 + r1 + r2, bottom row r1 - r2 - r3; `rq` points at r1, `ro` at r0 or r3
+    const float* __restrict__ rq = sR + (ex & 1) * QS + (1 * 16 + c0) * 32 + (ey >> 1) * 8 + (ex >> 1);
+    const int ro = top ? -16 * 32 : 2 * 16 * 32;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -260,26 +283,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = hf * 8 + rr;
                 const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);        // 0..15 within the half
-                sR[((0 * 4 + wave) * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
-                sR[((1 * 4 + wave) * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
+                sR[0 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
+                sR[1 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
             }
             __syncthreads();
             // 16 couts x 8 rows x 16 columns; consecutive threads -> consecutive x (64-byte row segments)
-            for (int e = tid; e < 16 * WR * WC; e += 256) {
-                const int x = e & 15, y = (e >> 4) & 7, co = e >> 7;
-                const int n = (y >> 1) * 8 + (x >> 1), q = x & 1;
-                const float* __restrict__ rq = sR + (q * 4 * 16 + co) * 32 + n;
-                const float r0 = rq[0 * 16 * 32], r1 = rq[1 * 16 * 32], r2 = rq[2 * 16 * 32], r3 = rq[3 * 16 * 32];
-                float v = (y & 1) == 0 ? (r0 + r1) + r2 : (r1 - r2) - r3;
-                const int cout = m0 + mi * 32 + hf * 16 + co, oy = oy0 + y, ox = ox0 + x;
-                if (cout < p.M && oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int co = c0 + 2 * it;
+                const float r1 = rq[co * 32 - c0 * 32], r2 = rq[co * 32 - c0 * 32 + 16 * 32], rx = rq[co * 32 - c0 * 32 + ro];
+                float v = top ? (rx + r1) + r2 : (r1 - r2) - rx;
+                const int cout = m0 + mi * 32 + hf * 16 + co;
+                if (inb && cout < p.M) {
                     if (p.bias) v += p.bias[cout];
                     v = c2m_act(v, p.act, p.slope);
-                    const int yi = oy - p.lo_y, xi = ox - p.lo_x;
-                    if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y && (unsigned)xi < (unsigned)p.ext_x)
-                        p.Y2[(long)img * p.y2_sn + (long)cout * p.y2_sc + (long)yi * p.y2_sh + xi] = v;
-                    else
-                        p.Y[p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + ox] = v;
+                    ybase[(long)cout * cstride] = v;
                 }
             }
         }
