@@ -589,18 +589,21 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
     }
 }
 
-// 16-byte form: 4 consecutive outputs share a channel when chan_stride % 4 == 0
+// 16-byte form: 4 consecutive outputs share a channel when chan_stride % 4 == 0.  I = 32-bit indices whenever the slab
+// fits (the bias channel needs a division per element; in 64 bits it costs more than the S loads)
+template <typename I>
 __global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, float4* __restrict__ out,
-                                         const float* __restrict__ bias, long total4, int S, long chan_stride4, int M,
+                                         const float* __restrict__ bias, long total4_, int S, long chan_stride4_, int M,
                                          int act, float slope) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const I total4 = (I)total4_, chan_stride4 = (I)chan_stride4_;
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total4; i += (I)gridDim.x * blockDim.x) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int z = 0; z < S; ++z) {
-            const float4 v = slab[(long)z * total4 + i];
+            const float4 v = slab[(long)z * total4_ + i];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         if (bias) {
-            const float b = bias[(int)((i / chan_stride4) % M)];
+            const float b = bias[(int)((i / chan_stride4) % (I)M)];
             acc.x += b; acc.y += b; acc.z += b; acc.w += b;
         }
         out[i] = make_float4(c2m_act(acc.x, act, slope), c2m_act(acc.y, act, slope), c2m_act(acc.z, act, slope),
@@ -743,9 +746,14 @@ C2M_API int c2m_splitk_reduce(const float* slab, float* out, const float* bias, 
     C2M_ENTER();
     if (total <= 0) return 0;
     if ((total & 3) == 0 && (!bias || (chan_stride & 3) == 0) && ((((uintptr_t)slab) | ((uintptr_t)out)) & 15) == 0) {
-        hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias, total / 4,
-                           splits, bias ? chan_stride / 4 : 1, M, act, slope);
+        if (total / 4 < (1L << 31))
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel<unsigned>, dim3(c2m_grid(total / 4, 256)), dim3(256), 0,
+                               (hipStream_t)stream, reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias,
+                               total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
+        else
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel<long>, dim3(c2m_grid(total / 4, 256)), dim3(256), 0,
+                               (hipStream_t)stream, reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias,
+                               total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, out,
@@ -1034,7 +1042,8 @@ __global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float* __res
         long dst = -1;                                     // -1: padding / out of range, -2: bias gradient
         long src = 0;
         if (i < total) {
-            const int m = (int)(i / used);
+            // (outputs < 2^31 in practice: a 32-bit division instead of a 64-bit one per output)
+            const int m = total < (1L << 31) ? (int)((unsigned)i / (unsigned)used) : (int)(i / used);
             const int col = (int)(i - (long)m * used);
             const int g = col >> 4, within = col & 15;
             if (g == ngroups) {
