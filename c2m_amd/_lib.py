@@ -29,6 +29,10 @@ _SIGS = {
     "c2m_prep_video": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_seg_onehot": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_flow_occ": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "c2m_event_create": (c_int, [c_void_p]),
+    "c2m_event_record": (c_int, [c_void_p, c_void_p]),
+    "c2m_event_elapsed_ms": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "c2m_event_destroy": (c_int, [c_void_p]),
     "c2m_adam_chunk": (c_int, []),
     "c2m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_double] * 5 + [c_void_p]),
     "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),

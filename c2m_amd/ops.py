@@ -88,6 +88,7 @@ class ConvProfiler:
 
     def __init__(self):
         self.records = []          # (kind, flops, start_event, end_event, tag, algorithmic bytes)
+        self._pool, self._used = [], 0
 
     def __enter__(self):
         ConvProfiler.active = self
@@ -95,6 +96,31 @@ class ConvProfiler:
 
     def __exit__(self, *exc):
         ConvProfiler.active = None
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for e in self._pool:
+                L.c2m_event_destroy(e)
+        except Exception:
+            pass
+
+    def _event(self):
+        """HIP timing event without the system-scope fence of torch.cuda.Event (csrc/events.hip)."""
+        if self._used == len(self._pool):
+            import ctypes
+            h = ctypes.c_void_p(None)
+            _lib.check(_lib.lib().c2m_event_create(ctypes.addressof(h)), "event_create")
+            self._pool.append(h.value)
+        self._used += 1
+        return self._pool[self._used - 1]
+
+    @staticmethod
+    def _ms(e0, e1):
+        import ctypes
+        ms = ctypes.c_float(0.0)
+        _lib.check(_lib.lib().c2m_event_elapsed_ms(e0, e1, ctypes.addressof(ms)), "event_elapsed")
+        return float(ms.value)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -104,7 +130,7 @@ class ConvProfiler:
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += self._ms(e0, e1)
         return out
 
     def table(self):
@@ -114,7 +140,7 @@ class ConvProfiler:
         for kind, flops, e0, e1, tag, _ in self.records:
             d = agg.setdefault((kind,) + tuple(tag), [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += e0.elapsed_time(e1)
+            d[1] += self._ms(e0, e1)
             d[2] += flops
         rows = [(k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in agg.items()]
         return sorted(rows, key=lambda r: -r[2])
@@ -124,10 +150,11 @@ def _timed(kind, flops, fn, tag=(), nbytes=0):
     prof = ConvProfiler.active
     if prof is None:
         return fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    L, st = _lib.lib(), _stream()
+    e0, e1 = prof._event(), prof._event()
+    _lib.check(L.c2m_event_record(e0, st), "event_record")
     rc = fn()
-    e1.record()
+    _lib.check(L.c2m_event_record(e1, st), "event_record")
     prof.records.append((kind, flops, e0, e1, tag, nbytes))
     return rc
 

@@ -164,6 +164,13 @@ int c2m_prep_seg_onehot(const uint8_t* labels_bthw, float* bg_mask, float* fg_ma
 int c2m_prep_flow_occ(const uint8_t* occ_bthw, const float* flow_bthwc, float* occ_out, float* flow_out, int B, int T,
                       int H, int W, void* stream);
 
+/* ---- measurement (events.hip): timing events without the system-scope fence of a default hipEventRecord; used by the
+ * roofline measurement of bench.py (HIP events on the launch stream), never by the product path.        */
+int c2m_event_create(void** event_out);
+int c2m_event_record(void* event, void* stream);
+int c2m_event_elapsed_ms(void* start, void* stop, float* ms);
+int c2m_event_destroy(void* event);
+
 /* ---- optimizer (optim.hip): SURVEY §8f-1 --------------------------------------------------------------------
  * The four torch.optim.Adam(betas=(0.5,0.999), eps=1e-7) of modules/model.py:54-99, stepped at trainer/trainer.py:155-165:
  * one launch per parameter group.  table = device int64 [4][ntensors] {param, grad, exp_avg, exp_avg_sq} pointers,
