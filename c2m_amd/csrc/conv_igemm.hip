@@ -23,6 +23,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvP {
     const float* A;
@@ -726,7 +727,7 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2 && p.ncls == 1) {      // thin output: vector-ALU kernel
         // g[35] = +-KW: 2-D stride-1 square KW x KW tap set in row-major order (dx ascending / descending)
         const int kw = (int)(g[35] < 0 ? -g[35] : g[35]);
-        if ((kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
+        if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
             g[29] == kw * kw && g[28] > 0 && g[28] * kw * kw * 16 <= 48 * 1024) {
             if (kw == 3) return launch_thin_rows<3>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
             return launch_thin_rows<7>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
@@ -1338,6 +1339,169 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_kernel(const WgradP p, in
     }
 }
 
+// Row-blocked weight gradient for <= 4 output channels and a 2-D stride-1 square KW x KW kernel (the 7x7 RGB head, the 3x3
+// flow / occlusion heads): a workgroup owns CPB input channels and ALL taps, every lane walks over groups of PX = 4
+// horizontally adjacent pixels of the split: per tap row one gathered segment of PX + KW - 1 inputs feeds KW taps x PX pixels
+// x MT outputs, i.e. 2.8x (7x7) / 2x (3x3) fewer loads per FMA than the per-pixel kernel above, which is bound by load
+// issue (13 TF/s on the 7x7 head).  KW*KW*CPB*MT accumulators per lane (147 for the 7x7 head); block reduction and slab
+// layout as above, so the same wgrad_reduce_kernel finishes.  Channel block 0 also sums dY for the bias gradient.
+template <int MT, int KW, int CPB, int RI>
+__global__ __launch_bounds__(256) void conv_thin_wgrad_rows_kernel(const WgradP p, int lns, int ntg, int Cin, int ngroups,
+                                                                   int quads_per_split) {
+    constexpr int PX = 4, NV = PX + KW - 1, NACC = CPB * RI * KW * MT;
+    __shared__ float red[4][NACC + MT];
+    const int NS = 1 << lns, lck = 4 - lns, CK = 16 >> lns;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * CPB;
+    const int i0 = blockIdx.y * RI;              // first tap row of this workgroup (rows >= KW contribute nothing)
+    const int split = blockIdx.z;
+    const int groups_x = p.Wo / PX;
+    const int total = p.Npix / PX;
+    const int qbeg = split * quads_per_split;
+    int qend = qbeg + quads_per_split; qend = qend < total ? qend : total;
+    auto tap_entry = [&](int t) { return p.jtab[(t >> lns) * (1 + NS) + 1 + (t & (NS - 1))]; };   // chunk 0's taps
+    const int dx0 = tap_entry(0).z, dy0 = tap_entry(0).y;        // row-major taps, dy / dx ascending by one
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    float acc[CPB][RI][KW][MT];
+    float accb[MT];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c)
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[c][i][j][m] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) accb[m] = 0.f;
+    // Two register sets: the loads of pixel group g + 256 (all KW rows x CPB channels: one latency per group instead of one
+    // per row) are in flight while group g is accumulated; the kernel runs one wave per SIMD (147 accumulators for the 7x7
+    // head), so nothing else would hide them.  Groups past the split's end load through out-of-range offsets (zeros).
+    // Input row segments: every lane loads its own four pixels once (one 16-byte load per row; the per-tap gathers of the
+    // first version fetched each pixel up to KW times through separate requests that were all in flight together, and the
+    // L2 served every one of them).  The HL halo pixels on each side come from the neighbouring lanes (shuffles in
+    // accumulate()), from the pixel's own quad at a reflected image border, and from memory only for the first / last live
+    // lane of a wave.
+    constexpr int HL = (KW - 1) / 2;
+    auto load_group = [&](int g, float (&dy)[MT][PX], float (&v)[RI][CPB][NV], int& fl) {
+        const bool live = g < qend;
+        const int gg = live ? g : qend - 1;
+        const int xg = gg % groups_x; const int r = gg / groups_x;
+        const int oy = r % p.Ho; const int n = r / p.Ho;
+        const int ox0 = xg * PX;
+        const bool first = xg == 0, last = xg == groups_x - 1;
+        const bool memL = live && !first && lane == 0;
+        const bool memR = live && !last && (lane == 63 || g + 1 >= qend);
+        fl = (first ? 2 : 0) | (last ? 4 : 0) | (memL ? 8 : 0) | (memR ? 16 : 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < p.M && live) {
+                const float4 t = *reinterpret_cast<const float4*>(p.dY + (long)n * p.dy_sn + (long)m * p.dy_sc + (long)oy * p.Wo + ox0);
+                dy[m][0] = t.x; dy[m][1] = t.y; dy[m][2] = t.z; dy[m][3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < PX; ++q) dy[m][q] = 0.f;
+            }
+        }
+        const unsigned img_byte = (unsigned)(n * (int)p.in_sn) * 4u;
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            int iy = oy + dy0 + i0 + i;
+            bool rok = live && i0 + i < KW;
+            if (p.reflect) { iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy; }
+            else rok = rok && (unsigned)iy < (unsigned)p.Hi;
+            const unsigned rbase = img_byte + (unsigned)(iy * (int)p.in_sh + ox0) * 4u;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {
+                const bool cok = rok && c0 + c < Cin;
+                const int soff = (c0 + c) * p.in_sc * 4;
+                const f32x4 own = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, cok ? rbase : C2M_OOB, soff, 0));
+                v[i][c][HL + 0] = own.x; v[i][c][HL + 1] = own.y; v[i][c][HL + 2] = own.z; v[i][c][HL + 3] = own.w;
+#pragma unroll
+                for (int e = 0; e < HL; ++e) {
+                    v[i][c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        xrsrc, (cok && memL) ? rbase - (unsigned)(HL - e) * 4u : C2M_OOB, soff, 0));
+                    v[i][c][HL + 4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        xrsrc, (cok && memR) ? rbase + (unsigned)(4 + e) * 4u : C2M_OOB, soff, 0));
+                }
+            }
+        }
+    };
+    auto accumulate = [&](const float (&dy)[MT][PX], float (&v)[RI][CPB][NV], const int fl) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < PX; ++q) accb[m] += dy[m][q];
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {
+#pragma unroll
+                for (int e = 0; e < HL; ++e) {
+                    const float up = __shfl_up(v[i][c][4 + e], 1, 64);                 // left neighbour's pixel 4 - HL + e
+                    const float dn = __shfl_down(v[i][c][HL + e], 1, 64);              // right neighbour's pixel e
+                    const float bl = p.reflect ? v[i][c][HL + HL - e] : 0.f;           // image border: own pixel HL - e
+                    const float br = p.reflect ? v[i][c][HL + 2 - e] : 0.f;            //               own pixel 2 - e
+                    v[i][c][e] = (fl & 8) ? v[i][c][e] : ((fl & 2) ? bl : up);
+                    v[i][c][HL + 4 + e] = (fl & 16) ? v[i][c][HL + 4 + e] : ((fl & 4) ? br : dn);
+                }
+#pragma unroll
+                for (int j = 0; j < KW; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < PX; ++q) acc[c][i][j][m] = fmaf(dy[m][q], v[i][c][q + j], acc[c][i][j][m]);
+            }
+    };
+    float dyA[MT][PX], dyB[MT][PX];
+    float vA[RI][CPB][NV], vB[RI][CPB][NV];
+    int flA = 0, flB = 0;
+    int g = qbeg + threadIdx.x;
+    if (qbeg < qend) {
+        load_group(g, dyA, vA, flA);
+        // uniform trip count (whole workgroup): the shuffles in accumulate() need every lane of the wave
+        const int rounds = (qend - qbeg + 511) / 512;
+        for (int it = 0; it < rounds; ++it, g += 512) {
+            load_group(g + 256, dyB, vB, flB);
+            accumulate(dyA, vA, flA);
+            load_group(g + 512, dyA, vA, flA);
+            accumulate(dyB, vB, flB);
+        }
+    }
+    // block reduction: wave shuffles, then 4 partials through LDS (fixed order)
+#pragma unroll
+    for (int c = 0; c < CPB; ++c)
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float v = wave_sum(acc[c][i][j][m]);
+                    if (lane == 0) red[wave][((c * RI + i) * KW + j) * MT + m] = v;
+                }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float v = wave_sum(accb[m]);
+        if (lane == 0) red[wave][NACC + m] = v;
+    }
+    __syncthreads();
+    float* __restrict__ out = p.slab + (long)split * p.M * p.J;
+    for (int e = threadIdx.x; e < NACC + MT; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e >= NACC) {                                          // bias gradient column (ones group), channel block 0 only
+            const int m = e - NACC;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && m < p.M) out[(long)m * p.J + ngroups * 16] = v;
+            continue;
+        }
+        const int m = e % MT, j = (e / MT) % KW, i = i0 + (e / (MT * KW)) % RI, c = c0 + e / (MT * KW * RI);
+        const int t = i * KW + j;
+        if (m >= p.M || c >= Cin || i >= KW) continue;
+        const int col = (((c >> lck) * ntg + (t >> lns)) << 4) + ((t & (NS - 1)) << lck) + (c & (CK - 1));
+        out[(long)m * p.J + col] = v;
+    }
+}
+
 #ifndef C2M_WG64_BN
 #define C2M_WG64_BN 128
 #endif
@@ -1401,7 +1565,33 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
     const int Seff = c2m_cdiv(p.Npix, per);   // <= S; unused slabs are never read
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.J / BN, c2m_cdiv(p.M, BM), Seff);
-    if (p.M <= 4 && p.Npix >= 16384) {                    // thin output: vector-ALU kernel, same slab layout
+    if (p.M <= 4 && p.Npix >= 16384) {                    // thin output: vector-ALU kernels, same slab layout
+        // g[35] = KW: 2-D stride-1 square KW x KW tap set in row-major order -> row-blocked kernel
+        const int kw = (int)g[35];
+        if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
+            taps == kw * kw && Cin > 0 && (p.dy_sn % 4) == 0 && (p.dy_sc % 4) == 0 && ((uintptr_t)dY & 15) == 0) {
+            const int lns = NS == 1 ? 0 : (NS == 2 ? 1 : 2);
+            // tap rows per workgroup: everything must fit the 256 architectural VGPRs (see the kernel)
+            const int cpb = kw == 7 ? 1 : 2, ri = kw == 7 ? (p.M == 1 ? 4 : (p.M == 2 ? 3 : 2)) : 3;
+            const int cblocks = c2m_cdiv(Cin, cpb);
+            const int quads = p.Npix / 4;
+            const int units = cblocks * c2m_cdiv(kw, ri);
+            int St = (1024 + units - 1) / units;          // ~1024 workgroups, >= 2048 pixel groups each
+            if (St > S) St = S;                           // the caller's slab holds S splits
+            if (St > c2m_cdiv(quads, 2048)) St = c2m_cdiv(quads, 2048);
+            if (St < 1) St = 1;
+            const int qps = c2m_cdiv(quads, St);
+            const int Srows = c2m_cdiv(quads, qps);
+            dim3 rg(cblocks, c2m_cdiv(kw, ri), Srows);
+#define C2M_THIN_WR(MT, RI7) \
+            if (kw == 7) hipLaunchKernelGGL((conv_thin_wgrad_rows_kernel<MT, 7, 1, RI7>), rg, dim3(256), 0, s, p, lns, ntg, Cin, ngroups, qps); \
+            else         hipLaunchKernelGGL((conv_thin_wgrad_rows_kernel<MT, 3, 2, 3>), rg, dim3(256), 0, s, p, lns, ntg, Cin, ngroups, qps);
+            if (p.M == 1) { C2M_THIN_WR(1, 4) } else if (p.M == 2) { C2M_THIN_WR(2, 3) } else { C2M_THIN_WR(3, 2) }   // 4 output rows would spill
+#undef C2M_THIN_WR
+            int rc3 = (int)hipGetLastError();
+            if (rc3) return rc3;
+            return launch_wgrad_reduce((long)p.M * (ngroups + 1) * 16, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Srows);
+        }
         constexpr int GPB = 2;
         const int ng = ngroups + 1;                       // real groups + the ones group
         // pixel splits sized for ~1024 blocks but >= 16K pixels each (the block reduction is per block)

@@ -43,6 +43,8 @@ CONV_CASES = [
     ((1, 6, 128, 144), 3, (7, 7), 1, 3, "zeros"),
     ((1, 3, 128, 160), 16, (3, 3), 1, 1, "zeros"),      # thin DATA gradient (3 input channels): row-blocked kernel, dx descending
     ((2, 5, 64, 132), 2, (7, 7), 1, 3, "reflect"),      # row-blocked thin kernel with reflected rows / columns
+    ((1, 9, 128, 132), 1, (3, 3), 1, 1, "zeros"),       # row-blocked thin wgrad, channel count not a multiple of its block
+    ((2, 10, 64, 136), 4, (3, 3), 1, 1, "reflect"),
     ((1, 5, 3, 40, 160), 2, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
     ((2, 32, 20, 64), 48, (3, 3), 1, 1, "reflect"),      # LDS-patch kernel, 64-row tile, reflect patch loads
     ((1, 48, 12, 96), 130, (3, 3), 1, 1, "zeros"),      # LDS-patch kernel, 128-row tiles, 3 channel chunks
