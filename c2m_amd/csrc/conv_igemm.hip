@@ -1166,8 +1166,20 @@ __global__ __launch_bounds__(256) void conv_thin_rows_kernel(const ConvP p, int 
     const int total = p.Npix / PX;
     const int dx_first = tap_entry(0).z, dx_last = tap_entry(KW - 1).z;
     const int lo = dx_first < dx_last ? dx_first : dx_last;
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
-        const int xg = g % groups_x; int r = g / groups_x;
+    // Symmetric tap sets on inputs as wide as the output (every layer this kernel sees): each lane loads its own four input
+    // pixels of a row with one 16-byte load and takes the HL halo pixels on each side from the neighbouring lanes, from its
+    // own quad at a reflected image border, and from memory only as the first / last lane of a wave.  (Gathering the
+    // PX + KW - 1 window per lane fetched every pixel up to KW times through requests that were all in flight together.)
+    constexpr int HL = (KW - 1) / 2;
+    const bool sym = lo == -HL && p.Wi == p.Wo && (p.in_sh % 4) == 0 && (p.in_sc % 4) == 0 && (p.in_sn % 4) == 0 &&
+                     (((uintptr_t)p.X) & 15) == 0;
+    const int lane = threadIdx.x & 63;
+    const int rounds = (total - (int)blockIdx.x * 256 + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);   // uniform per workgroup
+    int g = blockIdx.x * 256 + threadIdx.x;
+    for (int it = 0; it < rounds; ++it, g += gridDim.x * 256) {
+        const bool live = g < total;
+        const int gg = live ? g : total - 1;
+        const int xg = gg % groups_x; int r = gg / groups_x;
         const int oy = r % p.Ho; const int n = r / p.Ho;
         const int ox0 = xg * PX;
         const unsigned img_byte = (unsigned)(n * (int)p.in_sn) * 4u;
@@ -1176,30 +1188,53 @@ __global__ __launch_bounds__(256) void conv_thin_rows_kernel(const ConvP p, int 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int q = 0; q < PX; ++q) acc[m][q] = 0.f;
-        unsigned cvo[NV];                                  // column byte offsets of this lane's NV inputs
+        const bool first = xg == 0, last = xg == groups_x - 1;
+        const bool memL = live && !first && lane == 0;
+        const bool memR = live && !last && (lane == 63 || g + 1 >= total);
+        unsigned cvo[NV];                                  // column byte offsets of this lane's NV inputs (gather form)
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             int ix = ox0 + lo + e;
-            bool ok = true;
+            bool ok = live;
             if (p.reflect) { ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix; }
-            else ok = (unsigned)ix < (unsigned)p.Wi;
+            else ok = ok && (unsigned)ix < (unsigned)p.Wi;
             cvo[e] = ok ? (unsigned)ix * 4u : C2M_OOB;
         }
         for (int i = 0; i < KW; ++i) {                    // tap rows (square kernel)
             int iy = oy + tap_entry(i * KW).y;
-            bool rok = true;
+            bool rok = live;
             if (p.reflect) { iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy; }
-            else rok = (unsigned)iy < (unsigned)p.Hi;
+            else rok = rok && (unsigned)iy < (unsigned)p.Hi;
             const unsigned rbase = img_byte + (unsigned)(iy * (int)p.in_sh) * 4u;
             unsigned vo[NV];
 #pragma unroll
             for (int e = 0; e < NV; ++e) vo[e] = (rok && cvo[e] != C2M_OOB) ? rbase + cvo[e] : C2M_OOB;
+            const unsigned own_vo = rok ? rbase + (unsigned)ox0 * 4u : C2M_OOB;
             const float4* __restrict__ wrow = sW + i * KW;
             for (int c = 0; c < Cin; ++c) {
                 float v[NV];
+                if (sym) {
+                    const int soff = c * p.in_sc * 4;
+                    const f32x4 own = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, own_vo, soff, 0));
+                    v[HL + 0] = own.x; v[HL + 1] = own.y; v[HL + 2] = own.z; v[HL + 3] = own.w;
 #pragma unroll
-                for (int e = 0; e < NV; ++e)
-                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[e], c * p.in_sc * 4, 0));
+                    for (int e = 0; e < HL; ++e) {
+                        const float ml = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            xrsrc, (rok && memL) ? own_vo - (unsigned)(HL - e) * 4u : C2M_OOB, soff, 0));
+                        const float mr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            xrsrc, (rok && memR) ? own_vo + (unsigned)(4 + e) * 4u : C2M_OOB, soff, 0));
+                        const float up = __shfl_up(v[4 + e], 1, 64);                   // left neighbour's pixel 4 - HL + e
+                        const float dn = __shfl_down(v[HL + e], 1, 64);                // right neighbour's pixel e
+                        const float bl = p.reflect ? v[HL + HL - e] : 0.f;             // image border: own pixel HL - e
+                        const float br = p.reflect ? v[HL + 2 - e] : 0.f;              //               own pixel 2 - e
+                        v[e] = memL ? ml : (first ? bl : up);
+                        v[HL + 4 + e] = memR ? mr : (last ? br : dn);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e)
+                        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[e], c * p.in_sc * 4, 0));
+                }
 #pragma unroll
                 for (int j = 0; j < KW; ++j) {
                     const float4 w4 = wrow[c * (KW * KW) + j];          // same address in every lane: LDS broadcast
@@ -1212,6 +1247,7 @@ __global__ __launch_bounds__(256) void conv_thin_rows_kernel(const ConvP p, int 
                 }
             }
         }
+        if (!live) continue;
         float* __restrict__ yb = p.Y + p.out_off + (long)n * p.out_sn + (long)oy * p.out_sh + (long)ox0 * p.out_sw;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
