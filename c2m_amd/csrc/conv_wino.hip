@@ -308,35 +308,48 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
 // kernel reads: Upack[chunk][mt][w][j][mi][lane][kk] = U[xi = 4w + j][m = mt*64 + mi*32 + (lane & 31)][c = chunk*8 + 2kk + (lane >> 5)].
 // dgrad = 0: m = output channel, c = input channel, g = w[m][c];  dgrad = 1 (data gradient of a stride-1 conv): m = input
 // channel, c = output channel, g = w[c][m] rotated by 180 degrees.
+// One thread per (m, c): the nine filter taps are read once and all 16 transformed values written (each store instruction
+// of a wave covers 256 consecutive floats of Upack).  A thread per output value re-read the taps 16 times.
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int K, int Cin_native,
-                                   int dgrad, int mtiles, long total) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+                                   int dgrad, int mtiles, long pairs) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
         const int kk = (int)(i & 3); long r = i >> 2;
         const int lane = (int)(r & 63); r >>= 6;
-        const int ji = (int)(r & 7); r >>= 3;
-        const int mi = ji & 1, j = ji >> 1;
-        const int wv = (int)(r & 3); r >>= 2;
+        const int mi = (int)(r & 1); r >>= 1;
         const int mt = (int)(r % mtiles); const int chunk = (int)(r / mtiles);
         const int m = mt * 64 + mi * 32 + (lane & 31), c = chunk * CKW + 2 * kk + (lane >> 5);
-        float v = 0.f;
+        float u[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) u[a][b2] = 0.f;
         if (m < M && c < K) {
             const float* __restrict__ g = dgrad ? w + ((long)c * Cin_native + m) * 9 : w + ((long)m * Cin_native + c) * 9;
             float gg[3][3];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) gg[a][b] = dgrad ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
-            // row i = wv of G g: coefficients over a
-            float row[3];
+                for (int b2 = 0; b2 < 3; ++b2) gg[a][b2] = dgrad ? g[(2 - a) * 3 + (2 - b2)] : g[a * 3 + b2];
+            float row[4][3];                                  // G g
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float g0 = gg[0][b], g1 = gg[1][b], g2 = gg[2][b];
-                row[b] = wv == 0 ? g0 : (wv == 1 ? 0.5f * ((g0 + g1) + g2) : (wv == 2 ? 0.5f * ((g0 - g1) + g2) : g2));
+            for (int b2 = 0; b2 < 3; ++b2) {
+                const float g0 = gg[0][b2], g1 = gg[1][b2], g2 = gg[2][b2];
+                row[0][b2] = g0; row[1][b2] = 0.5f * ((g0 + g1) + g2); row[2][b2] = 0.5f * ((g0 - g1) + g2); row[3][b2] = g2;
             }
-            v = j == 0 ? row[0] : (j == 1 ? 0.5f * ((row[0] + row[1]) + row[2])
-                                          : (j == 2 ? 0.5f * ((row[0] - row[1]) + row[2]) : row[2]));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {                     // (G g) G^T
+                u[a][0] = row[a][0];
+                u[a][1] = 0.5f * ((row[a][0] + row[a][1]) + row[a][2]);
+                u[a][2] = 0.5f * ((row[a][0] - row[a][1]) + row[a][2]);
+                u[a][3] = row[a][2];
+            }
         }
-        up[i] = v;
+        const long base = ((long)chunk * mtiles + mt) * 4;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                up[((((base + wv) * 8 + (j * 2 + mi)) * 64 + lane) << 2) + kk] = u[wv][j];
     }
 }
 
@@ -350,8 +363,8 @@ C2M_API int c2m_wino_filter_transform(const float* w, float* upack, int Cout, in
     const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
     if (M <= 0 || K <= 0) return 0;
     const long total = c2m_wino_upack_floats(M, K);
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, upack, M, K,
-                       Cin, dgrad, c2m_cdiv(M, 64), total);
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(c2m_grid(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, upack, M,
+                       K, Cin, dgrad, c2m_cdiv(M, 64), total / 16);
     return (int)hipGetLastError();
 }
 
