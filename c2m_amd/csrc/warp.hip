@@ -446,10 +446,36 @@ C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int
     return (int)hipGetLastError();
 }
 
+// even sizes, 8-byte aligned tensors: one thread per 2x2 window (every input is read once: a thread per input pixel reads
+// each window four times), two 8-byte loads + one gradient, two 8-byte stores
+template <typename I>
+__global__ void maxpool2_bwd_win_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                        float* __restrict__ gin, long NC, int Hi, int Wi) {
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const I total = (I)(NC * Ho * Wo);
+    for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
+        const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
+        const long base = (long)nc * Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+        const float2 a = *reinterpret_cast<const float2*>(in + base), b = *reinterpret_cast<const float2*>(in + base + Wi);
+        const float v[4] = {a.x, a.y, b.x, b.y};
+        int arg = 0; float m = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
+        const float g = gout[i];
+        *reinterpret_cast<float2*>(gin + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
+        *reinterpret_cast<float2*>(gin + base + Wi) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+    }
+}
+
 C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
+    if ((Hi & 1) == 0 && (Wi & 1) == 0 && ((((uintptr_t)in) | ((uintptr_t)gin)) & 7) == 0) {
+        C2M_IDX_DISPATCH(total, maxpool2_bwd_win_kernel, dim3(c2m_grid(total / 4, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
+        return (int)hipGetLastError();
+    }
     C2M_IDX_DISPATCH(total, maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
     return (int)hipGetLastError();
 }

@@ -401,8 +401,9 @@ def test_resize_bilinear_align_false(size):
     close(ops.resize_bilinear(g(x), size), F.interpolate(x, size=size, mode="bilinear"), 1e-5, 1e-6)
 
 
-def test_maxpool():
-    x = rnd(1, 3, 5, 8, 12)
+@pytest.mark.parametrize("shape", [(3, 5, 8, 12), (2, 3, 7, 9), (1, 2, 6, 5)])   # even sizes: one thread per window
+def test_maxpool(shape):
+    x = rnd(1, *shape)
     x[0, 0, 0, 0:2] = 1.0   # a tie: gradient must go to the first maximum
     x[0, 0, 1, 0:2] = 1.0
     xr = x.clone().requires_grad_(True)
