@@ -31,6 +31,21 @@ class GraphBatch:
             setattr(out, k, getattr(self, k).clone())
         return out
 
+    def pin_memory(self):
+        """train.py:34-37 pins every collated value; tensors of any field are pinned, the rest is kept."""
+        import torch
+        out = GraphBatch(**self.__dict__)
+        for k, v in self.__dict__.items():
+            if torch.is_tensor(v):
+                setattr(out, k, v.pin_memory())
+        return out
+
+    @classmethod
+    def from_data_list(cls, data_list):
+        """`torch_geometric.data.Batch.from_data_list` as train.py:31-32 calls it (c2m_amd.graph.collate_graphs)."""
+        from .graph import collate_graphs
+        return collate_graphs(list(data_list))
+
 
 def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_predicted_frames=5,
                num_objects=3, seed=0, device="cpu"):

@@ -1,5 +1,9 @@
 """Tensor ops of the reference's utils/ops.py that the hot path uses (ops.py:183-275), on HIP kernels.
 
+`grid_sample` and `get_corresponding_map` (ops.py:183,205) are internal helpers of `resample` / `get_occlusion_map` in the
+reference; they have no counterpart here (the sampling grid and the unclamped splat sum are never materialised) and,
+with `c2m_amd.install_as_reference_layout()`, the reference's own definitions stay in place.
+
 `resample` keeps the reference's coordinate quirk (align_corners=True grid sampled with align_corners=False, border
 padding): zero flow is NOT the identity.  The grid is never materialised -- coordinates are computed in the kernel.
 """
@@ -12,10 +16,6 @@ def resample(image, flow, mode='bilinear'):
     if mode != 'bilinear':
         raise NotImplementedError(mode)
     return _ops.flow_warp(image, flow)
-
-
-def grid_sample(input1, input2, mode='bilinear'):
-    raise NotImplementedError("explicit sampling grids are not materialised in c2m_amd; use resample(image, flow)")
 
 
 def get_grid(batchsize, rows, cols, gpu_id=0, device=None):
@@ -31,14 +31,6 @@ def mesh_grid(B, H, W):
     xs = torch.arange(0, W).repeat(B, H, 1)
     ys = torch.arange(0, H).repeat(B, W, 1).transpose(1, 2)
     return torch.stack([xs, ys], 1)
-
-
-def get_corresponding_map(data):
-    """Forward splat of unnormalised target coordinates [B,2,H,W] -> [B,1,H,W] (ops.py:205-251), exact summation order."""
-    b, _, h, w = data.shape
-    base = mesh_grid(b, h, w).to(data)
-    occ, _ = _ops.occlusion_splat(data - base, want_map=True)
-    return occ  # NOTE: already clamped to [0,1] like get_occlusion_map; the raw sum is not exposed
 
 
 def get_occlusion_map(flow):

@@ -59,6 +59,43 @@ def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def dist_all_reduce_tensor(tensor, reduce="mean"):
+    """In-place all-reduce of a logging scalar/tensor over the ranks (utils.py:176-189); identity with one rank."""
+    world = get_world_size()
+    if world < 2:
+        return tensor
+    if reduce not in ("mean", "sum"):
+        raise NotImplementedError
+    with torch.no_grad():
+        dist.all_reduce(tensor)
+        if reduce == "mean":
+            tensor /= world
+    return tensor
+
+
+def dist_all_gather_tensor(tensor):
+    """Concatenation over ranks along dim 0 (utils.py:192-202); identity with one rank."""
+    world = get_world_size()
+    if world < 2:
+        return tensor
+    parts = [torch.empty_like(tensor) for _ in range(world)]
+    with torch.no_grad():
+        dist.all_gather(parts, tensor.contiguous())
+    return torch.cat(parts, dim=0)
+
+
+def init_cudnn(deterministic, benchmark):
+    """utils.py:412-423.  The convolutions of this package are hand-written HIP kernels with a fixed summation order
+    (no MIOpen, no autotuning), so the two switches only affect the few torch ops left on the path; they are forwarded
+    to torch.backends.cudnn (MIOpen on ROCm) for parity of behaviour."""
+    torch.backends.cudnn.deterministic = deterministic
+    torch.backends.cudnn.benchmark = benchmark
+
+
 def is_master():
     return get_rank() == 0
 
