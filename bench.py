@@ -1,21 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- generator train-step frames/sec at 128x256x7 on 1/2/4/8 MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): c2m_journal_cityscapes surface, 128x256, 7-frame clips (num_input_frames=2 +
+Default workload = BASELINE.json configs[1]: c2m_journal_cityscapes surface, 128x256, 7-frame clips (num_input_frames=2 +
 5 predicted), per-GPU batch 8, fp32, generator forward + backward (both discriminators off, VGG perceptual loss on),
 synthetic data + random-init weights, weak scaling over ranks with the mean-of-ranks gradient all-reduce (RCCL).
 A step = zero_grad + forward + backward (+ gradient all-reduce when N > 1); inputs are resident in HBM.
+`--config 2|3|4` select the other BASELINE configurations (see CONFIGS below).
+
+Launch: `python bench.py --gpus N` starts N ranks ITSELF (one process per GPU through torch.distributed.run, RCCL over
+xGMI) when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py --gpus N` it
+joins the existing rendezvous.  A world size different from --gpus is an error, never a silent 1-rank run.
 
 One JSON line on rank 0.  Extra objects:
-  roofline     dominant kernels = conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (fp32 MFMA; forward and
-               data-gradient launches): algorithmic (direct-convolution) FLOPs / HIP-event time of those launches,
-               measured inside the timed steps on the launch stream; peak = 157.3 TFLOP/s fp32 matrix.  The Winograd
-               kernel executes 2.25x fewer MFMA FLOPs than the algorithmic count on the layers it covers.
+  roofline     all conv MFMA launches (Winograd, implicit-GEMM gather / LDS-patch, weight gradient), HIP-event timed on
+               the launch stream inside the timed steps.  `achieved` = EXECUTED MFMA FLOP/s (algorithmic direct-conv
+               FLOPs on the unpadded domain; Winograd launches divided by their 2.25x multiply reduction) against the
+               fp32 matrix peak; per-family and whole-step figures beside it.
   cpu_baseline the CPU oracle (oracle/c2m_oracle.py, validated bit-exact against the reference) timed on this host
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +35,22 @@ sys.path.insert(0, ROOT)
 from c2m_amd import ops  # noqa: E402
 from c2m_amd.config import default_config, normalize_config  # noqa: E402
 from c2m_amd.modules.model import GeneratorFullModel  # noqa: E402
-from c2m_amd.synthetic import make_batch, make_stream_batch, make_step_rng, batch_to  # noqa: E402
+from c2m_amd.synthetic import make_stream_batch, make_batch, make_step_rng, batch_to  # noqa: E402
 from c2m_amd.train import TrainStep, init_distributed  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (only used by the --dtype bf16 side measurement)
-ALGO_GFLOP_PER_CLIP = 1068.6      # 7-frame 128x256 G-only clip, fwd+bwd (FlopCounterMode on the reference)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD, 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
+WINOGRAD_REDUCTION = 2.25         # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
+# SURVEY.md 8d, FlopCounterMode on the reference graph, per 7-frame clip at 128x256 (conv FLOPs scale with the pixels)
+ALGO_GFLOP_PER_CLIP = {False: 1068.6, True: 1159.8}          # [full_step]
+
+# BASELINE.json configs[k] -> flags (configs[0] is the CPU reference case = the cpu_baseline leg of this file)
+CONFIGS = {
+    1: dict(height=128, width=256, batch=8, windows=1, dtype="f32", full_step=False),
+    2: dict(height=256, width=512, batch=4, windows=1, dtype="bf16", full_step=True),
+    3: dict(height=128, width=256, batch=8, windows=1, dtype="bf16", full_step=True),     # global batch 64 at 8 ranks
+    4: dict(height=256, width=512, batch=4, windows=2, dtype="bf16", full_step=True),     # 14-frame streams = 2 windows
+}
 
 
 def bench_config(height, width, full_step=False):
@@ -41,8 +58,40 @@ def bench_config(height, width, full_step=False):
                                            use_image_discriminator=full_step, use_video_discriminator=full_step))
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
-    """Oracle fwd + bwd of ONE clip (B=1) on the host cores; the same graph the GPU runs, generator-only."""
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        n = len(seen)
+    except OSError:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n or avail, avail))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, seconds_budget=30.0):
+    """Oracle fwd + bwd of ONE clip (B=1) on the host cores; the same graph the GPU runs, generator-only.
+    A B=1 graph does not scale to a 128-core host (more threads = slower), so a short sweep picks the thread count with
+    the best throughput, then >= 3 steps are timed at that count."""
     from oracle import c2m_oracle as O
     import copy
     torch.manual_seed(0)
@@ -53,25 +102,72 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     h, w = cfg["train_params"]["input_size"]
     batch = make_batch(1, h, w, 2, seed=0)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=0)
-    times = []
-    t_start = time.time()
-    for it in range(6):
+
+    def one_step():
         S = O.State(sd)
         b = dict(batch)
         b["tracking_gnn"] = batch["tracking_gnn"].clone()
         t0 = time.time()
         _, lg, _, _ = O.forward(S, cfg, b, rng)
         O.train_step_backward(cfg, lg, {}, {})
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
+        return time.time() - t0
+
+    phys = _physical_cores()
+    prev = torch.get_num_threads()
+    t_start = time.time()
+    sweep = {}
+    for nt in sorted({n for n in (8, 16, 32, 64, phys) if n <= phys}):
+        torch.set_num_threads(nt)
+        if not sweep:
+            one_step()                           # warm-up (allocator, oneDNN primitive caches)
+        sweep[nt] = one_step()
+        if time.time() - t_start > 0.5 * seconds_budget:
             break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while len(times) < 3 or (len(times) < 6 and time.time() - t_start < seconds_budget):
+        times.append(one_step())
+    torch.set_num_threads(prev)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} timed steps (after 1 warm-up) of 1 clip (B=1, 7 frames, {h}x{w}, G-only fwd+bwd); "
-                      f"median {med:.3f} s/step"}
+    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": best, "kind": "port",
+            "host": f"{_cpu_model()}, {phys} physical cores visible",
+            "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
+            "reference_code_datapoint": "the reference itself, build container (8 vCPU): 3.0 frames/s G-only (SURVEY.md 6)",
+            "sample": f"{len(times)} timed steps of 1 clip (B=1, 7 frames, {h}x{w}, G-only fwd+bwd) at {best} threads "
+                      f"(best of the sweep); median {med:.3f} s/step"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """Not under a launcher: start n ranks (one per GPU) as children and return their exit code.  This process has not
+    touched the GPU (no HIP call before this point), and it never execs: the children are fresh processes."""
+    have = torch.cuda.device_count()              # does not initialise the GPU
+    if have < n and not os.environ.get("C2M_REHEARSAL_SHARED_GPU"):   # rehearsal: all ranks share GPU 0 over gloo (tests)
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _family(s, names, divide=1.0, peak=PEAK_FP32_MFMA_TFLOPS, step_s=None):
+    fl = sum(s[n]["flops"] for n in names if n in s)
+    ms = sum(s[n]["ms"] for n in names if n in s)
+    nl = sum(s[n]["launches"] for n in names if n in s)
+    if nl == 0:
+        return None
+    alg = fl / (ms * 1e-3) / 1e12
+    return {"launches": nl, "ms": round(ms, 3), "algorithmic_tflops": round(alg, 2),
+            "executed_mfma_tflops": round(alg / divide, 2), "frac": round(alg / divide / peak, 4),
+            "share_of_step_time": round(ms * 1e-3 / step_s, 3) if step_s else None}
 
 
 def main():
@@ -79,39 +175,56 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--windows", type=int, default=1,
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1,
+                    help="BASELINE.json configs[k]: 1 = the metric's configuration (default); 2 = 256x512 B4 bf16 full step; "
+                         "3 = 128x256 B8/rank bf16 full step; 4 = 256x512, 2 x 7-frame windows, bf16 full step")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
+    ap.add_argument("--windows", type=int, default=None,
                     help="7-frame windows per stream sample (2 = BASELINE configs[4]'s 14-frame streams); clips/GPU = batch x windows")
-    ap.add_argument("--height", type=int, default=128)
-    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="conv operand precision: f32 = BASELINE configs[1] (the bench line); bf16 = configs[2-4] mode")
-    ap.add_argument("--full-step", action="store_true",
+    ap.add_argument("--full-step", action="store_true", default=None,
                     help="full adversarial step of BASELINE configs[2-4]: both discriminators on + the four Adam steps")
     ap.add_argument("--check-grads", action="store_true",
-                    help="after the run, verify that every rank holds bit-identical (all-reduced) gradients")
+                    help="after the run, verify that every rank holds bit-identical (all-reduced) gradients "
+                         "(always on when N > 1)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     args = ap.parse_args()
+    for k, v in CONFIGS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
 
-    if "--force-reducer" in sys.argv:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))
+    if args.force_reducer:
         os.environ["C2M_FORCE_PROCESS_GROUP"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     rank, local_rank, world = init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}`)")
+    if world > 1 and not dist.is_initialized():
+        raise SystemExit("bench.py: WORLD_SIZE > 1 but no process group (MASTER_ADDR / MASTER_PORT missing)")
     dev = torch.device("cuda", local_rank)
     cfg = bench_config(args.height, args.width, args.full_step)
     ops.set_conv_precision("bf16" if args.dtype == "bf16" else "fp32")
     import copy
-    torch.manual_seed(0)                       # identical initial weights on every rank (== DDP's rank-0 broadcast)
+    torch.manual_seed(0)          # same seed on every rank; the reducer ALSO broadcasts rank 0's parameters and buffers
     model = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
                                model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
     model.to(dev).train()
-    step = TrainStep(model, run_optimizers=args.full_step, distributed=world > 1 or args.force_reducer,
-                     force_collectives=args.force_reducer)
+    distributed = world > 1 or args.force_reducer
+    step = TrainStep(model, run_optimizers=args.full_step, distributed=distributed,
+                     force_collectives=args.force_reducer, measure_comm=True)
     clips = args.batch * args.windows
     batch = batch_to(make_stream_batch(args.batch, args.windows, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)
@@ -124,6 +237,8 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
+    if step.reducer is not None:
+        step.reducer.reset_measurements()
     barrier()
     prof = None if args.no_roofline else ops.ConvProfiler()
     t0 = time.perf_counter()
@@ -140,26 +255,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     frames = world * clips * 7 * args.steps
+    step_s = elapsed / args.steps
+    tflop_per_step = ALGO_GFLOP_PER_CLIP[bool(args.full_step)] * (args.height * args.width) / (128 * 256) * 1e-3 * clips
+    prec = "fp32" if args.dtype == "f32" else "bf16 conv operands (fp32 accumulate, fp32 tensors)"
     result = {
         "metric": f"generator train-step frames/sec at {args.height}x{args.width}x7", "value": round(frames / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1000.0 * step_s, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE {'configs[1]' if (args.dtype, args.full_step) == ('f32', False) else 'configs[2-3] style (side measurement)'}: "
-                               f"{args.height}x{args.width}, 7-frame clips (2 in + 5 predicted), "
-                               f"batch {args.batch}/GPU{'' if args.windows == 1 else f' x {args.windows} windows (14-frame streams)'}, {'fp32' if args.dtype == 'f32' else 'bf16 conv operands (fp32 accumulate, fp32 tensors)'}, "
+        "config": {"workload": f"BASELINE configs[{args.config}]: {args.height}x{args.width}, 7-frame clips (2 in + 5 predicted), "
+                               f"batch {args.batch}/GPU{'' if args.windows == 1 else f' x {args.windows} windows (14-frame streams)'}, {prec}, "
                                + ("full adversarial step (G + D_image + D_video, 4 Adam steps), VGG loss on, "
                                   if args.full_step else "generator fwd+bwd only (no D), VGG loss on, ")
                                + "random-init weights", "global_batch": world * clips,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
-        # conv FLOPs scale with the pixel count ("for 256x512 multiply conv FLOPs by 4")
-        "achieved_tflops_algorithmic": round(ALGO_GFLOP_PER_CLIP * (args.height * args.width) / (128 * 256) * 1e-3 *
-                                             world * clips * args.steps / elapsed, 2),
+        "rccl_ranks": world if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
+        "achieved_tflops_algorithmic": round(tflop_per_step * world / step_s, 2),
     }
-    if args.check_grads:
+    if step.reducer is not None:
+        result["allreduce_bytes_per_step"] = step.reducer.bytes_per_step()
+        result["allreduce_buckets"] = len(step.reducer.buckets)
+        ex = step.reducer.exposed_ms()
+        if ex is not None and world > 1:
+            t = torch.tensor([ex], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ex = float(t.item())
+        result["allreduce_exposed_ms_per_step"] = None if ex is None else round(ex, 3)
+    if args.check_grads or world > 1:
         # all-reduced gradients must be bit-identical on every rank although each rank saw different data
         gsum = torch.stack([p.grad.double().abs().sum() for p in model.parameters() if p.grad is not None])
-        local = torch.stack([gsum.sum(), (gsum * torch.arange(1, gsum.numel() + 1, device=dev)).sum()]).cpu()
+        local = torch.stack([gsum.sum(), (gsum * torch.arange(1, gsum.numel() + 1, device=dev)).sum()])
         if dist.is_initialized() and world > 1:
             gathered = [torch.zeros_like(local) for _ in range(world)]
             dist.all_gather(gathered, local)
@@ -168,38 +293,51 @@ def main():
             same = True
         if not same:
             raise SystemExit(f"rank {rank}: gradients differ across ranks after the all-reduce")
-        result["grad_sync"] = "identical on all ranks"
+        result["grad_sync"] = f"bit-identical gradient fingerprints on all {world} rank(s)" if distributed else "single rank, no reducer"
     if rank == 0:
         if prof is not None:
             s = prof.summary()
-            sfx = "_bf16" if args.dtype == "bf16" else ""
-            peak = PEAK_BF16_MFMA_TFLOPS if sfx else PEAK_FP32_MFMA_TFLOPS
-            ig = s.get("igemm" + sfx, dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
-            wg = s.get("wgrad" + sfx, dict(launches=0, flops=0.0, ms=1e-9, bytes=0.0))
+            bf = args.dtype == "bf16"
+            sfx = "_bf16" if bf else ""
+            peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+            fam = {
+                "winograd_fwd_dgrad (conv_wino_kernel)": _family(s, ["wino"], WINOGRAD_REDUCTION, PEAK_FP32_MFMA_TFLOPS, elapsed),
+                "direct_fwd_dgrad (conv_igemm_kernel, conv_patch3x3_kernel)": _family(s, ["igemm" + sfx], 1.0, peak, elapsed),
+                "wgrad (conv_wgrad_kernel)": _family(s, ["wgrad" + sfx], 1.0, peak, elapsed),
+                "winograd_wgrad (conv_wino_wgrad_kernel)": _family(s, ["wino_wgrad"], WINOGRAD_REDUCTION, PEAK_FP32_MFMA_TFLOPS, elapsed),
+            }
+            fam = {k: v for k, v in fam.items() if v}
+            ms_all = sum(v["ms"] for v in fam.values())
+            exe = sum(v["executed_mfma_tflops"] * v["ms"] for v in fam.values()) / ms_all
+            alg = sum(v["algorithmic_tflops"] * v["ms"] for v in fam.values()) / ms_all
+            nl = sum(v["launches"] for v in fam.values())
+            nbytes = sum(d["bytes"] for d in s.values())
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            # (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json); counters cannot be read from inside the process
+            # (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json); counters cannot be read from inside the process
             traffic, traffic_src = None, None
-            tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tp) and args.windows == 1 and (args.batch, args.height, args.width, args.dtype, args.full_step) == \
-                    (8, 128, 256, "f32", False):
+            tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(tp) and args.config == 1 and (args.batch, args.windows, args.height, args.width) == (8, 1, 128, 256) \
+                    and args.dtype == "f32" and not args.full_step:
                 with open(tp) as f:
-                    traffic = json.load(f)["igemm"]["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-            ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+                    tj = json.load(f)
+                traffic, traffic_src = tj["conv"]["traffic_bytes_per_launch"], tj["note"]
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (conv forward + data-gradient launches)",
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "flops_counted": "algorithmic direct-convolution FLOPs (2*M*K*Npix)",
-                "traffic": traffic, "traffic_unit": "bytes/launch",
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(ig["bytes"] / max(ig["launches"], 1)),
-                "launches_per_step": ig["launches"] // args.steps,
-                "avg_launch_us": round(1000.0 * ig["ms"] / max(ig["launches"], 1), 2),
-                "gflop_per_launch": round(ig["flops"] / max(ig["launches"], 1) / 1e9, 3),
-                "share_of_step_time": round(ig["ms"] / (1000.0 * elapsed), 3),
-                "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2),
-                          "launches_per_step": wg["launches"] // args.steps,
-                          "share_of_step_time": round(wg["ms"] / (1000.0 * elapsed), 3)},
+                "bound": "mfma",
+                "kernel": "all conv MFMA launches: conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (forward, "
+                          "data gradient) + conv_wgrad_kernel (weight gradient)",
+                "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe / peak, 4),
+                "flops_counted": "EXECUTED MFMA FLOPs = algorithmic direct-convolution FLOPs (2*M*K*Npix on the unpadded "
+                                 "domain) with Winograd launches divided by 2.25",
+                "algorithmic_tflops": round(alg, 2),
+                "families": fam,
+                "whole_step": {"algorithmic_tflop_per_step": round(tflop_per_step, 3),
+                               "achieved": round(tflop_per_step / step_s, 2), "frac": round(tflop_per_step / step_s / peak, 4),
+                               "definition": "SURVEY 8d: FlopCounterMode FLOPs of the reference graph / step wall time"},
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1)),
+                "launches_per_step": nl // args.steps,
+                "avg_launch_us": round(1000.0 * ms_all / max(nl, 1), 2),
+                "share_of_step_time": round(ms_all / (1000.0 * elapsed), 3),
             }
         if prof is not None and args.conv_table:
             with open(args.conv_table, "w") as f:
@@ -207,7 +345,7 @@ def main():
                 for tag, n, ms, tf in prof.table():
                     f.write(f"{tag} | {n / args.steps:.1f} {ms / args.steps:.3f} {tf:.1f}\n")
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg)
+            result["cpu_baseline"] = cpu_baseline(bench_config(args.height, args.width, False))
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -29,11 +29,17 @@ class _Bucket:
             off += p.numel()
         self.work = None
         self.launched = False
+        self.ready = False
         self.pending = 0
 
 
 class GradientReducer:
-    def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False):
+    def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False, buffers=(),
+                 measure=False):
+        """buffers: module buffers (BatchNorm running statistics, spectral-norm u/v) that are broadcast from rank 0
+        together with the parameters at construction (what DistributedDataParallel's constructor does); afterwards they
+        stay per-rank like the reference's BatchNorm.  measure: record HIP events around the join in finish() so that
+        `exposed_ms()` reports the all-reduce time that was NOT hidden behind backward."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collectives: issue the all-reduces even in a 1-rank group (exercises the RCCL / side-stream path on a
@@ -65,9 +71,18 @@ class GradientReducer:
             for i, p in enumerate(b.params):
                 self.where[id(p)] = (b, i)
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
-        self.expected = None          # ids of params that fire in the final backward (learned on step 1)
+        self.expected = None          # ids of params that fire in the final backward (learned on step 1, rank-agreed)
+        self.ever_fired = None        # ids of params that receive a gradient at all (learned on step 1, rank-agreed)
         self.fired_final, self.fired_any = set(), set()
         self.armed = False
+        self.next_bucket = 0          # buckets are all-reduced strictly in index order: same RCCL call sequence on all ranks
+        self.measure = measure and self.on_gpu
+        self._exposed = []            # (event at end of backward compute, event after the side stream was joined)
+        if self.world > 1:            # identical starting point on every rank, whatever the callers seeded
+            with torch.no_grad():
+                for t in list(uniq) + [b for b in buffers if torch.is_tensor(b)]:
+                    dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in uniq]
         self.zero_grad()
 
@@ -76,12 +91,13 @@ class GradientReducer:
         """Replaces optimizer.zero_grad(): zero the buckets and (re)bind every .grad to its bucket view."""
         for b in self.buckets:
             b.flat.zero_()
-            b.work, b.launched = None, False
+            b.work, b.launched, b.ready = None, False, False
             for p, v in zip(b.params, b.views):
                 p.grad = v
         self.fired_final.clear()
         self.fired_any.clear()
         self.armed = False
+        self.next_bucket = 0
 
     def arm(self):
         """Call right before the last backward() of the step."""
@@ -90,6 +106,8 @@ class GradientReducer:
         if self.expected is not None:
             for b in self.buckets:
                 b.pending = sum(1 for p in b.params if id(p) in self.expected)
+                b.ready = b.pending == 0
+            self._launch_ready()
 
     def _on_grad(self, p):
         b, i = self.where[id(p)]
@@ -103,7 +121,13 @@ class GradientReducer:
         if self.expected is not None and id(p) in self.expected and not b.launched:
             b.pending -= 1
             if b.pending == 0:
-                self._launch(b)
+                b.ready = True
+                self._launch_ready()
+
+    def _launch_ready(self):
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket].ready:
+            self._launch(self.buckets[self.next_bucket])
+            self.next_bucket += 1
 
     def _launch(self, b):
         b.launched = True
@@ -120,19 +144,48 @@ class GradientReducer:
 
     def finish(self):
         """After the last backward: reduce the remaining buckets, join streams, drop never-touched grads."""
-        for b in self.buckets:
+        ev0 = None
+        if self.measure and self.collectives:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(self.device))
+        for b in self.buckets:                         # index order (see next_bucket)
             if not b.launched:
                 self._launch(b)
+        self.next_bucket = len(self.buckets)
         if self.on_gpu and self.collectives:
             for b in self.buckets:
                 if b.work is not None:
                     b.work.wait()
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            if ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record(torch.cuda.current_stream(self.device))
+                self._exposed.append((ev0, ev1))
         if self.expected is None:
-            self.expected = set(self.fired_final)
+            # Step 1: agree across ranks on which parameters fire (in the final backward / at all).  Every later step
+            # uses the agreed sets, so all ranks issue the same bucket sequence and drop the same gradients even if a
+            # data-dependent branch made one rank's graph differ.
+            fin = torch.tensor([[float(id(p) in self.fired_final), float(id(p) in self.fired_any)] for p in self.params],
+                               device=self.device)
+            if self.world > 1:
+                dist.all_reduce(fin, op=dist.ReduceOp.MAX, group=self.group)
+            fin = fin.cpu()
+            self.expected = {id(p) for p, f in zip(self.params, fin) if f[0] > 0}
+            self.ever_fired = {id(p) for p, f in zip(self.params, fin) if f[1] > 0}
         for p in self.params:
-            if id(p) not in self.fired_any:
+            if id(p) not in self.fired_any and id(p) not in self.ever_fired:
                 p.grad = None
+
+    def exposed_ms(self):
+        """Mean GPU time per step between the end of the backward kernels and the moment the compute stream may go on
+        (all-reduce time that the overlap did not hide); None unless constructed with measure=True on a GPU."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+
+    def reset_measurements(self):
+        self._exposed = []
 
     def bytes_per_step(self):
         return 4 * sum(b.numel for b in self.buckets)

@@ -14,8 +14,6 @@ class SpatiallyAdaptiveNorm(nn.Module):
         super().__init__()
         padding = kernel_size // 2
         self.mlps = nn.ModuleList()
-        self.gammas = nn.ModuleList()
-        self.betas = nn.ModuleList()
         self.bias_only = bias_only
         self.interpolation = interpolation
         if type(cond_dims) != list:

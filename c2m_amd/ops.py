@@ -36,11 +36,19 @@ def _p(t):
 
 
 def _dev(*ts):
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("c2m_amd ops need tensors on a HIP device (no CPU fallback by design)")
-        if t is not None and t.dtype != torch.float32:
+        if t.dtype != torch.float32:
             raise RuntimeError(f"c2m_amd ops compute in fp32, got {t.dtype}")
+        if cur is None:
+            cur = _cur_device()
+        if t.device.index != cur:       # kernels are launched on the CURRENT device's stream (see _stream)
+            raise RuntimeError(f"c2m_amd ops: tensor on cuda:{t.device.index} but the current device is cuda:{cur}; "
+                               "call torch.cuda.set_device() (or use `with torch.cuda.device(...)`) first")
 
 
 def _f(t):
@@ -421,6 +429,11 @@ class _ConvPlan:
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
+        # Algorithmic FLOPs (roofline bookkeeping): the data gradient of a convolution has the MACs of its forward
+        # (2 * Cout * K * output pixels -- FlopCounterMode's count).  Reflect-padded layers LAUNCH over the
+        # padded domain; every launch is credited with its share of the forward count, not with the padded volume.
+        self.fwd_flops = 2.0 * Cout * self.K * N * osp
+        self.dgrad_work = float(sum(c["taps"] * c["npix"] for c in self.classes)) or 1.0
         # ---- class batching: the stride parity classes of a k % s == 0 conv share every dimension (same taps per
         # class, same Q extents) and differ only in weights, tap table and output origin -> ONE launch
         # (blockIdx.z = class), which fills the chip where a single class (1/s^d of the pixels) cannot
@@ -530,7 +543,7 @@ class _ConvFn(torch.autograd.Function):
             U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+            _lib.check(_timed("wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                               lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
                                                       LRELU_SLOPE, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
@@ -571,7 +584,7 @@ class _ConvFn(torch.autograd.Function):
             tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
             # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
             tgt = torch.empty(pl.dgrad_target, device=x.device, dtype=torch.float32) if pl.reflect else gx
-            _lib.check(_timed("igemm", 2.0 * Cin * Cout * 9 * npix,
+            _lib.check(_timed("wino", pl.fwd_flops,
                               lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
                                                       _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
                               4 * (gy.numel() + w.numel() + x.numel())), "conv_wino dgrad")
@@ -599,7 +612,7 @@ class _ConvFn(torch.autograd.Function):
                     tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
                            pl.reflect, S)
                     _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
-                                      2.0 * Cin * Cout * cb["taps"] * grp["npix"] * grp["ncls"],
+                                      pl.fwd_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
                                       lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
                                                                None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
                                                                _stream()), tag,
@@ -617,7 +630,7 @@ class _ConvFn(torch.autograd.Function):
                     w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
                         w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
-                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cin * Cout * c["taps"] * c["npix"],
+                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.fwd_flops * c["taps"] * c["npix"] / pl.dgrad_work,
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
                                                            _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
                                   4 * (gy.numel() + w.numel() + x.numel()) // len(pl.classes)), "conv_igemm dgrad")
@@ -637,7 +650,7 @@ class _ConvFn(torch.autograd.Function):
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             Hi, Wi = pl.dims[4:6]
             tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wino_wgrad(_p(gy), _p(x), _p(slab), _p(dbslab), _p(gw), _p(gb_t), Cout,
                                                             Cin, N, Hi, Wi, int(pl.reflect), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wino_wgrad")

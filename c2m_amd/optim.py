@@ -75,6 +75,9 @@ class Adam(torch.optim.Adam):
                 table, sizes, bm, n, nblocks = sub["table"]
                 _lib.check(L.c2m_adam_step(_p(table), _p(sizes), _p(bm), n, nblocks, beta1, beta2, group["eps"],
                                            group["lr"] / bc1, math.sqrt(bc2), _stream()), "adam_step")
+            # the kernel writes through raw pointers: tell autograd (saved-tensor checks) and every `_version`-keyed
+            # cache (ops._packed: packed / Winograd-transformed copies of frozen weights) that the values changed
+            torch.autograd.graph.increment_version(plist)
         return loss
 
     def _build_plan(self, plist, sig):

@@ -29,7 +29,7 @@ def init_distributed():
 
 class TrainStep:
     def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0,
-                 force_collectives=False):
+                 force_collectives=False, measure_comm=False):
         self.c2m = c2m
         self.tp = c2m.train_params
         self.loss_weights = loss_weights or self.tp["loss_weights"]
@@ -40,8 +40,8 @@ class TrainStep:
         if self.tp["use_video_discriminator"]:
             self.optimizers.append(c2m.d_optimizer_video)
         distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
-        self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb,
-                                       force_collectives=force_collectives) if distributed else None
+        self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb, buffers=list(c2m.buffers()),
+                                       force_collectives=force_collectives, measure=measure_comm) if distributed else None
 
     def zero_grad(self):
         if self.reducer is not None:

@@ -1,7 +1,8 @@
-"""TEST INFRASTRUCTURE -- builds the C restatement (oracle/c2m_oracle_index.c) into oracle/_ref/.
+"""TEST INFRASTRUCTURE -- builds the C restatement (oracle/c2m_oracle_index.c) into oracle/_build/.
 
-The Python reference has no compilable sources of its own on the hot path (pure PyTorch), so
-oracle/_ref/ only ever holds this library.  Called from __graft_entry__.build(); tests load the .so.
+The Python reference has no compilable sources of its own on the hot path (pure PyTorch), so there is no
+"reference compiled here" (`oracle/_ref/`) for this project: `_build/` holds OUR C restatement only, pinned by the
+reference-captured fixtures.  Called from __graft_entry__.build(); tests load the .so.
 """
 import ctypes
 import os
@@ -9,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "c2m_oracle_index.c")
-OUT_DIR = os.path.join(HERE, "_ref")
+OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "liboracle_index.so")
 FMA_MODE = 7  # frozen by tests/test_oracle_golden.py::test_c_oracle_fma_mode_is_pinned
 

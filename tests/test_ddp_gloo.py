@@ -112,3 +112,70 @@ def test_single_process_reducer_matches_plain_autograd():
             assert p.grad is None
         else:
             torch.testing.assert_close(p.grad, ref[k], rtol=1e-6, atol=1e-8)
+
+
+class Branchy(nn.Module):
+    """head_x only runs when the data asks for it: ranks can end up with different autograd graphs."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 8)
+        self.head = nn.Linear(8, 3)
+        self.head_x = nn.Linear(8, 3)
+        self.bn = nn.BatchNorm1d(8)
+
+    def forward(self, x, use_x):
+        h = self.bn(torch.relu(self.a(x)))
+        out = self.head(h).abs().mean()
+        return out + self.head_x(h).pow(2).mean() if use_x else out
+
+
+def _worker_divergent(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(10 + rank)             # DIFFERENT initial weights and buffers per rank: the reducer must broadcast rank 0's
+        model = Branchy()
+        with torch.no_grad():
+            model.bn.running_mean.fill_(float(rank + 1))
+        red = GradientReducer(list(model.parameters()), bucket_mb=0.0002, buffers=list(model.buffers()))
+        start = {k: v.clone().numpy() for k, v in model.state_dict().items()}     # numpy: pickled by value
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + rank))
+        grads = []
+        for step in range(3):
+            red.zero_grad()
+            red.arm()
+            model(x, use_x=(rank == 0)).backward()      # rank 1 never touches head_x
+            red.finish()
+            grads.append({k: (p.grad.clone().numpy() if p.grad is not None else None)
+                          for k, p in model.named_parameters()})
+        q.put((rank, start, grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_broadcast_and_rank_divergent_graph():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_divergent, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(world):
+        rank, start, grads = q.get(timeout=120)
+        results[rank] = (start, grads)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0                          # no hang / size mismatch although the graphs differ
+    for k in results[0][0]:                             # parameters AND buffers start from rank 0's values
+        assert (results[0][0][k] == results[1][0][k]).all(), k
+    assert float(results[1][0]["bn.running_mean"][0]) == 1.0
+    for step in range(3):
+        g0, g1 = results[0][1][step], results[1][1][step]
+        for k in g0:                                    # every rank ends every step with the same gradient set and values
+            assert (g0[k] is None) == (g1[k] is None), (step, k)
+            if g0[k] is not None:
+                assert (g0[k] == g1[k]).all(), (step, k)
+        assert g1["head_x.weight"] is not None and abs(g1["head_x.weight"]).sum() > 0   # mean with rank 0's contribution

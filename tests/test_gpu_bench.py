@@ -25,7 +25,23 @@ def test_bench_single_process_contract():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in r, k
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "mfma"
-    assert 0 < r["roofline"]["frac"] < 1
+    rf = r["roofline"]
+    assert 0 < rf["frac"] < 1 and 0 < rf["whole_step"]["frac"] < 1
+    assert rf["achieved"] <= rf["algorithmic_tflops"]              # executed MFMA FLOPs never exceed the algorithmic count
+    for fam in rf["families"].values():
+        assert 0 < fam["frac"] < 1, fam                             # every family is priced against the MFMA pipe it runs on
+    assert r["rccl_ranks"] == 0 and "config" in r and "BASELINE configs[1]" in r["config"]["workload"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus 2 on a one-GPU box must fail loudly (never a silent 1-rank line), with or without a launcher."""
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_under_torchrun_with_rccl_reducer():
@@ -37,7 +53,9 @@ def test_bench_under_torchrun_with_rccl_reducer():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     r = _json_line(out.stdout)
-    assert r["n_gpus"] == 1 and r["value"] > 0
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["rccl_ranks"] == 1
+    assert r["allreduce_bytes_per_step"] > 4e8 and r["allreduce_buckets"] >= 10
+    assert r["allreduce_exposed_ms_per_step"] is not None
 
 
 def test_two_rank_rehearsal_on_one_gpu_gradients_identical():
@@ -45,11 +63,13 @@ def test_two_rank_rehearsal_on_one_gpu_gradients_identical():
     two ranks on one device): different data per rank, bucketed all-reduce overlapped with backward on HIP tensors, and
     every rank must end up with bit-identical gradients.  The production launch uses RCCL (previous test)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2M_REHEARSAL_SHARED_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch",
-           "1", "--no-cpu-baseline", "--no-roofline", "--check-grads"]
+    env.pop("WORLD_SIZE", None)
+    # plain `python bench.py --gpus 2`: bench.py starts the two ranks itself (the form the scaling driver may use)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "1", "--no-cpu-baseline",
+           "--no-roofline"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     r = _json_line(out.stdout)
-    assert r["n_gpus"] == 2 and r["value"] > 0 and r["grad_sync"] == "identical on all ranks"
+    assert r["n_gpus"] == 2 and r["value"] > 0 and "bit-identical" in r["grad_sync"] and "2 rank" in r["grad_sync"]
+    assert r["allreduce_bytes_per_step"] > 4e8
     assert r["config"]["global_batch"] == 2 and r["config"]["parallelism"] == "dp2"

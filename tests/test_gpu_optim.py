@@ -70,6 +70,30 @@ def test_adam_state_dict_exchanges_with_torch_adam():
         torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
 
 
+def test_adam_step_invalidates_frozen_weight_pack_cache():
+    """GAN pattern: freeze D (its packed / Winograd-transformed weights get cached), unfreeze, train with the raw-pointer
+    Adam kernel, freeze again -> the next forward must see the NEW weights (Adam.step bumps `_version`)."""
+    from c2m_amd import ops
+    torch.manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device=DEV) * 0.05)      # Winograd-eligible shape: both caches
+    x = torch.randn(2, 64, 32, 64, device=DEV)
+    opt = Adam([w], lr=1e-1, betas=(0.5, 0.999), eps=1e-7)
+    w.requires_grad_(False)
+    y0 = ops.conv(x, w, None, 1, 1)
+    y0_again = ops.conv(x, w, None, 1, 1)                                      # served from the cache
+    assert torch.equal(y0, y0_again)
+    v0 = w._version
+    w.requires_grad_(True)
+    ops.conv(x, w, None, 1, 1).square().mean().backward()
+    opt.step()
+    assert w._version > v0
+    w.requires_grad_(False)
+    y1 = ops.conv(x, w, None, 1, 1)
+    ref = torch.nn.functional.conv2d(x.cpu().double(), w.detach().cpu().double(), padding=1)
+    assert (y1.cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert (y1 - y0).abs().max() > 1e-3
+
+
 def _tiny_cfg():
     cfg = normalize_config(default_config(num_input_frames=2, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
                                           out_channel=16, ndf=4, use_spade=True, use_image_discriminator=True,
