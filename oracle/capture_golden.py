@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shims  # noqa: E402
-from oracle.golden_util import synth_state, state_spec, summarize, pack_mask  # noqa: E402
+from oracle.golden_util import synth_state, state_spec, summarize, pack_mask, synth_input, compact  # noqa: E402
 from c2m_amd.config import default_config, normalize_config  # noqa: E402
 from c2m_amd.synthetic import make_batch, GraphBatch  # noqa: E402
 
@@ -358,6 +358,78 @@ def capture_inference(name, t_in, use_spade, batch_size, use_gt_eval, eval_mode,
     save(name, meta, arrays)
 
 
+def run_module_compact(mod, seed, in_specs, call, grad_inputs):
+    """run_module for big modules: inputs come from seeds (golden_util.synth_input) and every stored tensor goes through
+    golden_util.compact (whole if small, fingerprint + subsample if large)."""
+    spec = state_spec(mod.state_dict())
+    mod.load_state_dict(synth_state(spec, seed))
+    mod.train()
+    inputs = {k: synth_input(v) for k, v in in_specs.items()}
+    for k in grad_inputs:
+        inputs[k].requires_grad_(True)
+    out = call(mod, **inputs)
+    outs = out if isinstance(out, dict) else {"y": out}
+    total = 0
+    for i, (k, v) in enumerate(sorted(outs.items())):
+        total = total + (v * rnd(seed + 100 + i, *v.shape)).sum()
+    total.backward()
+    arrays = {}
+    for k, v in outs.items():
+        arrays.update(compact("out", k, v))
+    for k in grad_inputs:
+        arrays.update(compact("gin", k, inputs[k].grad))
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            arrays.update(compact("grad", k, p.grad))
+    for k, b in mod.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            arrays.update(compact("buf", k, b))
+    arrays["nograd"] = np.frombuffer(json.dumps(
+        [k for k, p in mod.named_parameters() if p.requires_grad and p.grad is None]).encode(), dtype=np.uint8)
+    return spec, arrays
+
+
+def capture_modules_round2():
+    """Stand-alone OcclusionAwareGenerator (both use_spade values, generator.py:126-158) and DenseMotionDecoder
+    (motion_autoencoder.py:107-149) -- SURVEY 8c's capture list; until round 2 they were only covered end to end."""
+    from modules.generator.generator import OcclusionAwareGenerator
+    from modules.motion_estimator.motion_autoencoder import DenseMotionDecoder
+    fp = dict(input_channel=6, block_expansion=4, num_down_blocks=3, max_expansion=32, padding_mode="reflect", use_decoder=True)
+    gin = {"first_frame": dict(seed=70, shape=[5, 3, 32, 64], kind="rand"),
+           "flow": dict(seed=71, shape=[5, 2, 32, 64], kind="randn", scale=2.0),
+           "occlusion_map": dict(seed=72, shape=[5, 1, 32, 64], kind="rand")}
+    for use_spade in (True, False):
+        gp = dict(block_expansion=4, num_down_blocks=3, max_expansion=32, num_bottleneck_blocks=2, padding_mode="reflect",
+                  use_skip=False, use_spade=use_spade)
+        mod = OcclusionAwareGenerator(copy.deepcopy(gp), copy.deepcopy(fp), input_channel=3, dataset="cityscapes")
+        seed = 2100 + int(use_spade)
+        spec, arrays = run_module_compact(mod, seed, gin, lambda m, **kw: m(kw["first_frame"], kw["flow"], kw["occlusion_map"]),
+                                          ("first_frame", "flow", "occlusion_map"))
+        save("mod_generator_" + ("spade" if use_spade else "nospade"),
+             dict(module="generator", spec=spec, seed=seed, generator=gp, flow_embedder=fp, inputs=gin), arrays)
+
+    dp = dict(in_channel=48, out_channel=4, block_expansion=4, max_expansion=32, num_up_blocks=5, padding_mode="reflect",
+              use_appearance_feature=True, use_feature_resample=True, num_input_frames=1, num_predicted_frames=5,
+              scale_factor=1, input_size=[128, 256], sparse_down=4)
+    mod = DenseMotionDecoder(copy.deepcopy(dp))
+    B = 1
+    din = {"z": dict(seed=80, shape=[B, 48, 5, 2, 4], kind="randn"),
+           "sparse_motion": dict(seed=81, shape=[B, 2, 5, 128, 256], kind="randn", scale=3.0),
+           "sparse_occlusion": dict(seed=82, shape=[B, 1, 5, 128, 256], kind="mask", scale=0.3)}
+    for lvl, (c, h, w) in {4: (32, 4, 8), 3: (32, 8, 16), 2: (16, 16, 32), 1: (8, 32, 64)}.items():
+        din[f"app.enco{lvl}"] = dict(seed=83 + lvl, shape=[B, c, h, w], kind="randn")
+    for lvl, (c, h, w) in {3: (32, 8, 16), 2: (16, 16, 32), 1: (8, 32, 64), 0: (4, 64, 128)}.items():
+        din[f"sparse.enco_sparse_{lvl}"] = dict(seed=90 + lvl, shape=[B, c, 5, h, w], kind="randn")
+
+    def call_dec(m, **kw):
+        app = {k[4:]: v for k, v in kw.items() if k.startswith("app.")}
+        sp = {k[7:]: v for k, v in kw.items() if k.startswith("sparse.")}
+        return m(app, sp, kw["sparse_motion"], kw["sparse_occlusion"], kw["z"])
+    grad_in = tuple(k for k in din if k not in ("sparse_motion", "sparse_occlusion"))
+    spec, arrays = run_module_compact(mod, 2200, din, call_dec, grad_in)
+    save("mod_dense_decoder", dict(module="dense_decoder", spec=spec, seed=2200, decoder=dp, inputs=din), arrays)
+
+
 TRACKS = os.path.join(OUT, "scene_tracks")
 
 
@@ -419,11 +491,18 @@ def main():
     if "--data-only" in sys.argv:           # likewise
         capture_data(ref_utils)
         return
+    if "--round2-only" in sys.argv:         # likewise (round 2: VERDICT r01 "close the parity holes")
+        capture_e2e("e2e_tin1_nospade_gt", 1, False, 1, True, False, 7)
+        capture_modules_round2()
+        return
     print("ops");      capture_ops(ref_utils)
     print("blocks");   capture_blocks()
     print("e2e")
     capture_e2e("e2e_tin2_spade_full", 2, True, 2, True, True, 3)
     capture_e2e("e2e_tin1_nospade_pred", 1, False, 1, False, False, 4)
+    capture_e2e("e2e_tin1_nospade_gt", 1, False, 1, True, False, 7)
+    print("modules")
+    capture_modules_round2()
     print("inference")
     capture_inference("inf_tin2_spade_eval", 2, True, 2, False, True, 5)
     capture_inference("inf_tin1_nospade_train_gt", 1, False, 1, True, False, 6)

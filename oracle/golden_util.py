@@ -65,3 +65,55 @@ def pack_mask(t):
 def unpack_mask(bits, shape):
     n = int(np.prod(shape))
     return np.unpackbits(bits)[:n].reshape(shape).astype(np.float32)
+
+
+# ---- compact module fixtures (round 2): inputs regenerated from seeds, large tensors stored as fingerprint + subsample
+COMPACT_LIMIT = 4096
+
+
+def synth_input(spec):
+    """spec = dict(seed, shape, kind in {"randn", "rand", "mask"}, scale): a seeded CPU tensor (torch's CPU generator is
+    deterministic across hosts), so fixtures need not store the inputs."""
+    g = torch.Generator(device="cpu").manual_seed(int(spec["seed"]))
+    shape = tuple(spec["shape"])
+    if spec["kind"] == "randn":
+        return torch.randn(shape, generator=g) * float(spec.get("scale", 1.0))
+    if spec["kind"] == "rand":
+        return torch.rand(shape, generator=g) * float(spec.get("scale", 1.0))
+    if spec["kind"] == "mask":
+        return (torch.rand(shape, generator=g) > float(spec.get("scale", 0.3))).float()
+    raise KeyError(spec["kind"])
+
+
+def compact(prefix, name, t):
+    """{key: array} for one tensor: whole if small, else [sum, abs-sum, sq-sum, first, last] + every k-th element."""
+    t = t.detach().cpu()
+    if t.numel() <= COMPACT_LIMIT:
+        return {f"{prefix}.{name}": t.numpy()}
+    k = -(-t.numel() // COMPACT_LIMIT)
+    return {f"sum{prefix}.{name}": summarize(t.float()), f"sub{prefix}.{name}": t.reshape(-1)[::k].clone().numpy()}
+
+
+def check_compact(arr, prefix, name, got, tol, what, floor=0.0):
+    """Compare `got` with the stored form of <prefix>.<name>; max-abs error relative to the tensor's scale."""
+    got = got.detach().cpu().double()
+    key = f"{prefix}.{name}"
+    if key in arr:
+        ref = torch.from_numpy(np.array(arr[key])).double()
+        assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+        scale = max(float(ref.abs().max()), floor, 1e-30)
+        err = float((got - ref).abs().max())
+        assert err <= tol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+        return
+    ref_sub = torch.from_numpy(np.array(arr[f"sub{prefix}.{name}"])).double()
+    k = -(-got.numel() // COMPACT_LIMIT)
+    sub = got.reshape(-1)[::k]
+    assert sub.shape == ref_sub.shape, f"{what}: subsample {tuple(sub.shape)} vs {tuple(ref_sub.shape)}"
+    scale = max(float(ref_sub.abs().max()), floor, 1e-30)
+    err = float((sub - ref_sub).abs().max())
+    assert err <= tol * scale, f"{what}: subsample max abs err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+    rs = np.array(arr[f"sum{prefix}.{name}"])
+    gs = summarize(got)
+    n = got.numel()
+    assert abs(gs[1] - rs[1]) <= tol * abs(rs[1]) + tol * floor * n, f"{what}: abs-sum {gs[1]} vs {rs[1]}"
+    assert abs(gs[2] - rs[2]) <= 2 * tol * abs(rs[2]) + (tol * floor) ** 2 * n, f"{what}: sq-sum {gs[2]} vs {rs[2]}"

@@ -214,3 +214,90 @@ def test_bf16_mode_step_vs_fp32_oracle_and_20_step_descent():
     assert ops.set_conv_precision("fp32") == "fp32", "context manager must restore the precision"
     assert totals[-1] < 0.9 * totals[0], f"no descent over 20 steps: {totals[0]:.4f} -> {totals[-1]:.4f}"
     assert np.mean(totals[-5:]) < np.mean(totals[:5])
+
+
+# ------------------------------------------------------------------ BASELINE configs[2]: 256x512, bf16, full G + D step + VGG
+def _cfg2():
+    return normalize_config(default_config(height=256, width=512, num_input_frames=2, use_image_discriminator=True,
+                                           use_video_discriminator=True))
+
+
+def test_config2_256x512_bf16_full_step_vs_fp32_oracle():
+    """The full-width network at 256x512, 7-frame clip, both discriminators + VGG, bf16 conv operands (B=1): losses within
+    SURVEY 8d's 2e-2 of the fp32 CPU oracle, index/mask tensors bit-exact (they never leave fp32)."""
+    from c2m_amd import ops
+    import os
+    cfg = _cfg2()
+    tp = cfg["train_params"]
+    torch.manual_seed(0)
+    model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
+                               dataset="cityscapes")
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = make_batch(1, 256, 512, 2, seed=31)
+    rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=0)
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    S = O.State(sd0)
+    ob = dict(batch)
+    ob["tracking_gnn"] = batch["tracking_gnn"].clone()
+    oo, olg, oldi, oldv = O.forward(S, cfg, ob, rng)
+    model.to(DEV).train()
+    gb = batch_to(batch, DEV)
+    gb["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+    step = TrainStep(model, run_optimizers=True, distributed=False)
+    with ops.conv_precision("bf16"):
+        out, lg, ld = step(gb)
+    torch.cuda.synchronize()
+    for k, v in olg.items():
+        ref, got = float(v.detach()), float(lg[k].detach())
+        assert np.isfinite(got) and abs(got - ref) <= 2e-2 * abs(ref) + 1e-4, f"bf16 256x512 loss {k}: {got} vs fp32 oracle {ref}"
+    od = {"total_image_dis": (oldi["d_real"] + oldi["d_fake"]) * 0.5, "total_video_dis": (oldv["d_real"] + oldv["d_fake"]) * 0.5}
+    for k, v in od.items():
+        ref, got = float(v.detach()), float(ld[k].detach())
+        assert abs(got - ref) <= 2e-2 * abs(ref) + 1e-4, f"bf16 256x512 {k}: {got} vs {ref}"
+    for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw", "sparse_motion_bw"):
+        assert torch.equal(out[k].cpu(), oo[k]), f"{k} must stay bit-exact in bf16 mode"
+    for p in model.parameters():
+        assert p.grad is None or bool(torch.isfinite(p.grad).all())
+
+
+def test_config2_batch4_properties():
+    """configs[2] at its own batch (B=4, 256x512, bf16, full step): properties that do not need a 4-clip CPU oracle run --
+    bit-repeatable step, finite losses, index/mask path bit-exact against the oracle's raster + splat for all 4 samples, the
+    non-adversarial objective descending over a few optimizer steps."""
+    from c2m_amd import ops
+    cfg = _cfg2()
+    tp = cfg["train_params"]
+    batch = make_batch(4, 256, 512, 2, seed=41)
+    rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=1)
+    gb = batch_to(batch, DEV)
+    gb["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+    first = []
+    with ops.conv_precision("bf16"):
+        for rep in range(2):
+            torch.manual_seed(0)
+            model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
+                                       dataset="cityscapes").to(DEV).train()
+            step = TrainStep(model, run_optimizers=True, distributed=False)
+            out, lg, ld = step(gb)
+            first.append(({k: float(v.detach()) for k, v in lg.items()}, out["sparse_occ_bw"].clone(),
+                          model.generator.final[0].weight.grad.clone()))
+            if rep == 0:
+                del model, step
+        assert first[0][0] == first[1][0], "the step must be bit-repeatable"
+        assert torch.equal(first[0][1], first[1][1]) and torch.equal(first[0][2], first[1][2])
+        assert all(np.isfinite(v) for v in first[0][0].values())
+        # per-sample index/mask path vs the reference restatement (gt thetas: identical inputs -> bit-exact)
+        gnn = batch["tracking_gnn"]
+        oo = O.generate_sparse_motion(cfg, gnn, {f"theta_{t}": gnn.targets_theta[:, t] for t in range(5)},
+                                      batch["instance_mask"][:, :, 1].float(), True)
+        for k in ("sparse_motion_bin", "sparse_occ_bw", "sparse_occ_fw", "sparse_motion_bw"):
+            assert torch.equal(out[k].cpu(), oo[k]), k
+        w = tp["loss_weights"]
+        skip = ("total_gen", "g_gan_image", "g_gan_video", "feature_matching_image", "feature_matching_video")
+        totals = [sum(v * w[k] for k, v in first[1][0].items() if k not in skip)]
+        for it in range(5):
+            _, lg, _ = step(gb)
+            vals = {k: float(v.detach()) for k, v in lg.items()}
+            assert all(np.isfinite(v) for v in vals.values()), f"step {it + 2}: {vals}"
+            totals.append(sum(v * w[k] for k, v in vals.items() if k not in skip))
+    assert totals[-1] < totals[0], f"no descent: {totals}"

@@ -173,6 +173,59 @@ def test_perceptual_vgg():
         close(summarize(taps[k]), c.arr["sum.tap_" + k], rtol=1e-5, atol=1e-5, what=k)
 
 
+# ----------------------------------------------------------------------------------- stand-alone modules (round 2)
+def _module_inputs(c, device="cpu"):
+    from oracle.golden_util import synth_input
+    return {k: synth_input(v).to(device) for k, v in c.meta["inputs"].items()}
+
+
+def _oracle_module_call(c, S, inp):
+    m = c.meta
+    if m["module"] == "generator":
+        cfg = {"model_params": {"generator": m["generator"], "flow_embedder": m["flow_embedder"]}}
+        return {"y": O.generator(S, cfg, inp["first_frame"], inp["flow"], inp["occlusion_map"], p="")}
+    dp = m["decoder"]
+    cfg = {"train_params": {"num_predicted_frames": dp["num_predicted_frames"]},
+           "model_params": {"motion_estimator": {"dense_motion_decoder": dp,
+                                                 "sparse_motion_encoder": {"num_down_blocks": dp["sparse_down"]}}}}
+    app = {k[4:]: v for k, v in inp.items() if k.startswith("app.")}
+    sp = {k[7:]: v for k, v in inp.items() if k.startswith("sparse.")}
+    flow, occ = O.dense_motion_decoder(S, "", cfg, app, sp, inp["sparse_motion"], inp["sparse_occlusion"], inp["z"])
+    return {"dense_motion": flow, "occlusion": occ}
+
+
+MODULE_GRAD_INPUTS = {"generator": ("first_frame", "flow", "occlusion_map")}
+
+
+@pytest.mark.parametrize("name", names("mod_"))
+def test_standalone_module(name):
+    """OcclusionAwareGenerator (both use_spade) and DenseMotionDecoder of the live reference vs the oracle."""
+    from oracle.golden_util import check_compact
+    c = Case(name)
+    seed = c.meta["seed"]
+    S = O.State(synth_state(c.meta["spec"], seed))
+    inp = _module_inputs(c)
+    gin = MODULE_GRAD_INPUTS.get(c.meta["module"]) or tuple(k for k in inp if k not in ("sparse_motion", "sparse_occlusion"))
+    for k in gin:
+        inp[k].requires_grad_(True)
+    outs = _oracle_module_call(c, S, inp)
+    total = 0
+    for j, (k, v) in enumerate(sorted(outs.items())):
+        total = total + (v * rnd(seed + 100 + j, *v.shape)).sum()
+    total.backward()
+    for k, v in outs.items():
+        check_compact(c.arr, "out", k, v, 1e-5, f"{name} out.{k}")
+    for k in gin:
+        check_compact(c.arr, "gin", k, inp[k].grad, 1e-4, f"{name} d{k}")
+    grads = S.grads()
+    ref_keys = {k.split(".", 1)[1] for k in c.arr if k.startswith(("grad.", "sumgrad."))}
+    assert set(grads) == ref_keys, f"{name}: params with grads differ: {sorted(set(grads) ^ ref_keys)[:6]}"
+    for k in ref_keys:
+        check_compact(c.arr, "grad", k, grads[k], 1e-4, f"{name} grad.{k}", floor=1e-6)
+    nograd = [k for k, v in S.t.items() if v.requires_grad and v.grad is None]
+    assert sorted(nograd) == sorted(c.json("nograd"))
+
+
 # ----------------------------------------------------------------------------------- whole step
 @pytest.mark.parametrize("name", names("e2e_"))
 def test_end_to_end_step(name):
