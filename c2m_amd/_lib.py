@@ -41,8 +41,8 @@ _SIGS = {
     "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
     "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_void_p]),
     "c2m_flow_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "c2m_flow_warp_bwd_needs_zero": (c_int, [c_int] * 4),
-    "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "c2m_flow_warp_bwd_workspace_bytes": (c_long, [c_int] * 6),
+    "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p]),
     "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_void_p]),
     "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),

@@ -81,16 +81,144 @@ __global__ void flow_warp_fwd_kernel(const float* __restrict__ img, const float*
     }
 }
 
-// gimg (zero-initialised by the caller) accumulated with float atomics; gflow written (each pixel owns its flow);
-// when channels are chunked (gridDim.y > 1) gflow is accumulated with atomics instead and must be zeroed too.
-__global__ void flow_warp_bwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
-                                     const float* __restrict__ occ, const float* __restrict__ gout,
-                                     float* __restrict__ gimg, float* __restrict__ gflow, int N, int C, int H, int W,
-                                     int cchunk) {
+// ---- backward, deterministic (no float atomics) -------------------------------------------------------------------
+// d(image): a scatter in the reference (grid_sampler_2d_backward adds g*w into the 4 taps of every output pixel).  Here
+// it is a GATHER over an inverted tap list that is built once per image n and shared by all C channels (the flow does not
+// depend on the channel): count taps per source pixel -> exclusive scan -> fill (dest, corner) keys + weights -> sort each
+// bucket by key -> every source pixel sums its contributions in ascending (dest, corner) order.  Integer atomics only
+// place the entries; the fp32 summation order is fixed, so gradients are bit-reproducible run to run.
+// d(flow): each output pixel owns its two values; when channels are chunked over gridDim.y the chunks write partial
+// sums that a second kernel adds in chunk order.
+struct WarpInvP {
+    const float* flow;
+    const float* occ;
+    int N, H, W;
+};
+
+__global__ void warp_inv_count_kernel(const WarpInvP p, int* __restrict__ count) {
+    const long HW = (long)p.H * p.W, total = (long)p.N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.W); const long r = i / p.W;
+        const int y = (int)(r % p.H); const long n = r / p.H;
+        const long sp = (long)y * p.W + x;
+        const WarpCoord k = warp_coord(p.flow[(n * 2 + 0) * HW + sp], p.flow[(n * 2 + 1) * HW + sp], x, y, p.H, p.W);
+        int* __restrict__ c = count + n * HW;
+        atomicAdd(c + (long)k.y0 * p.W + k.x0, 1);
+        if (k.okx1) atomicAdd(c + (long)k.y0 * p.W + k.x1, 1);
+        if (k.oky1) atomicAdd(c + (long)k.y1 * p.W + k.x0, 1);
+        if (k.okx1 && k.oky1) atomicAdd(c + (long)k.y1 * p.W + k.x1, 1);
+    }
+}
+
+// exclusive scan of count within each image (one 1024-thread block per image); also copies offsets into cursor
+__global__ __launch_bounds__(1024) void warp_inv_scan_kernel(const int* __restrict__ count, int* __restrict__ offset,
+                                                             int* __restrict__ cursor, int HW) {
+    __shared__ int part[1024];
+    const long base = (long)blockIdx.x * HW;
+    const int per = (HW + 1023) / 1024;
+    const int beg = min((int)threadIdx.x * per, HW), end = min(beg + per, HW);
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += count[base + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = beg; i < end; ++i) {
+        offset[base + i] = run;
+        cursor[base + i] = run;
+        run += count[base + i];
+    }
+}
+
+__global__ void warp_inv_fill_kernel(const WarpInvP p, int* __restrict__ cursor, int* __restrict__ keys,
+                                     float* __restrict__ vals) {
+    const long HW = (long)p.H * p.W, total = (long)p.N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.W); const long r = i / p.W;
+        const int y = (int)(r % p.H); const long n = r / p.H;
+        const int sp = y * p.W + x;
+        const WarpCoord k = warp_coord(p.flow[(n * 2 + 0) * HW + sp], p.flow[(n * 2 + 1) * HW + sp], x, y, p.H, p.W);
+        int* __restrict__ cur = cursor + n * HW;
+        int* __restrict__ kk = keys + n * HW * 4;
+        float* __restrict__ vv = vals + n * HW * 4;
+        int slot = atomicAdd(cur + (long)k.y0 * p.W + k.x0, 1);
+        kk[slot] = sp * 4 + 0; vv[slot] = k.nw;
+        if (k.okx1) { slot = atomicAdd(cur + (long)k.y0 * p.W + k.x1, 1); kk[slot] = sp * 4 + 1; vv[slot] = k.ne; }
+        if (k.oky1) { slot = atomicAdd(cur + (long)k.y1 * p.W + k.x0, 1); kk[slot] = sp * 4 + 2; vv[slot] = k.sw; }
+        if (k.okx1 && k.oky1) { slot = atomicAdd(cur + (long)k.y1 * p.W + k.x1, 1); kk[slot] = sp * 4 + 3; vv[slot] = k.se; }
+    }
+}
+
+// per source pixel: sort its bucket by key in place (insertion sort; buckets hold ~4 entries for a smooth flow)
+__global__ void warp_inv_sort_kernel(const int* __restrict__ count, const int* __restrict__ offset,
+                                     int* __restrict__ keys, float* __restrict__ vals, long nimg, int HW) {
+    const long total = nimg * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long o = (i / HW) * (long)HW * 4 + offset[i];
+        const int n = count[i];
+        for (int a = 1; a < n; ++a) {
+            const int ka = keys[o + a]; const float va = vals[o + a];
+            int j = a;
+            while (j > 0 && keys[o + j - 1] > ka) { keys[o + j] = keys[o + j - 1]; vals[o + j] = vals[o + j - 1]; --j; }
+            keys[o + j] = ka; vals[o + j] = va;
+        }
+    }
+}
+
+// grid: x = source-pixel blocks over N*H*W, y = channel chunk.  Every element of gimg is written (no zero-init needed).
+__global__ void flow_warp_bwd_img_kernel(const float* __restrict__ gout, const float* __restrict__ occ,
+                                         const int* __restrict__ count, const int* __restrict__ offset,
+                                         const int* __restrict__ keys, const float* __restrict__ vals,
+                                         float* __restrict__ gimg, int N, int C, int HW, int cchunk) {
+    constexpr int FAST = 8;
+    const long total = (long)N * HW;
+    const int c0 = blockIdx.y * cchunk;
+    const int c1 = min(c0 + cchunk, C);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW; const int sp = (int)(i - n * HW);
+        const int cnt = count[i];
+        const long o = n * (long)HW * 4 + offset[i];
+        int d[FAST]; float w[FAST];
+#pragma unroll
+        for (int e = 0; e < FAST; ++e) {
+            const bool ok = e < cnt;
+            const int key = ok ? keys[o + e] : 0;
+            d[e] = key >> 2;
+            // the reference multiplies the incoming gradient by the occlusion value first: (g * occ) * weight
+            w[e] = ok ? vals[o + e] : 0.0f;
+        }
+        float oc[FAST];
+#pragma unroll
+        for (int e = 0; e < FAST; ++e) oc[e] = (occ && e < cnt) ? occ[n * HW + d[e]] : 1.0f;
+        for (int c = c0; c < c1; ++c) {
+            const float* __restrict__ g = gout + (n * C + c) * (long)HW;
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < FAST; ++e)
+                if (e < cnt) acc += (g[d[e]] * oc[e]) * w[e];
+            for (int e = FAST; e < cnt; ++e) {          // strongly converging flow: the tail of a long list
+                const int de = keys[o + e] >> 2;
+                acc += (g[de] * (occ ? occ[n * HW + de] : 1.0f)) * vals[o + e];
+            }
+            gimg[(n * C + c) * (long)HW + sp] = acc;
+        }
+    }
+}
+
+// d(flow): partial sums per channel chunk -> gfpart[chunk][n][2][HW] (or straight into gflow when there is one chunk)
+__global__ void flow_warp_bwd_flow_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                          const float* __restrict__ occ, const float* __restrict__ gout,
+                                          float* __restrict__ dst, int N, int C, int H, int W, int cchunk) {
     const long HW = (long)H * W;
     const long total = (long)N * HW;
     const int c0 = blockIdx.y * cchunk;
     const int c1 = min(c0 + cchunk, C);
+    float* __restrict__ out = dst + (long)blockIdx.y * N * 2 * HW;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         const int x = (int)(p % W); const long r = p / W;
         const int y = (int)(r % H); const int n = (int)(r / H);
@@ -104,28 +232,24 @@ __global__ void flow_warp_bwd_kernel(const float* __restrict__ img, const float*
         for (int c = c0; c < c1; ++c) {
             const long pb = ((long)n * C + c) * HW;
             const float g = gout[pb + sp] * o;
-            if (gimg) {
-                atomicAdd(gimg + pb + i00, g * k.nw);
-                if (k.okx1) atomicAdd(gimg + pb + i01, g * k.ne);
-                if (k.oky1) atomicAdd(gimg + pb + i10, g * k.sw);
-                if (k.okx1 && k.oky1) atomicAdd(gimg + pb + i11, g * k.se);
-            }
-            if (gflow) {
-                const float* __restrict__ pl = img + pb;
-                const float vnw = pl[i00];
-                const float vne = k.okx1 ? pl[i01] : 0.0f;
-                const float vsw = k.oky1 ? pl[i10] : 0.0f;
-                const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
-                gix += g * (k.s_ * (vne - vnw) + k.n_ * (vse - vsw));
-                giy += g * (k.e_ * (vsw - vnw) + k.w_ * (vse - vne));
-            }
+            const float* __restrict__ pl = img + pb;
+            const float vnw = pl[i00];
+            const float vne = k.okx1 ? pl[i01] : 0.0f;
+            const float vsw = k.oky1 ? pl[i10] : 0.0f;
+            const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
+            gix += g * (k.s_ * (vne - vnw) + k.n_ * (vse - vsw));
+            giy += g * (k.e_ * (vsw - vnw) + k.w_ * (vse - vne));
         }
-        if (gflow) {
-            float* gx = gflow + ((long)n * 2 + 0) * HW + sp;
-            float* gy = gflow + ((long)n * 2 + 1) * HW + sp;
-            if (gridDim.y == 1) { *gx = gix * k.gmx; *gy = giy * k.gmy; }
-            else { atomicAdd(gx, gix * k.gmx); atomicAdd(gy, giy * k.gmy); }
-        }
+        out[((long)n * 2 + 0) * HW + sp] = gix * k.gmx;
+        out[((long)n * 2 + 1) * HW + sp] = giy * k.gmy;
+    }
+}
+
+__global__ void warp_flow_chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ gflow, long numel, int chunks) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
+        float acc = part[i];
+        for (int c = 1; c < chunks; ++c) acc += part[(long)c * numel + i];
+        gflow[i] = acc;
     }
 }
 
@@ -151,21 +275,52 @@ C2M_API int c2m_flow_warp_fwd(const float* img, const float* flow, const float* 
     return (int)hipGetLastError();
 }
 
-// Returns 1 in *gflow_needs_zero when the caller must zero gflow before the launch (channel-chunked accumulation).
-C2M_API int c2m_flow_warp_bwd_needs_zero(int N, int C, int H, int W) {
+// Workspace of c2m_flow_warp_bwd (bytes): the inverted tap list of d(image) (count, offset, cursor: N*HW ints each;
+// keys, weights: 4*N*HW each) and the per-chunk partial sums of d(flow).  Neither output needs to be zeroed.
+C2M_API long c2m_flow_warp_bwd_workspace_bytes(int N, int C, int H, int W, int want_gimg, int want_gflow) {
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
-    return grid.y > 1 ? 1 : 0;
+    const long px = (long)N * H * W;
+    long b = 0;
+    if (want_gimg) b += px * 4 * 3 + px * 4 * 4 * 2;
+    if (want_gflow && grid.y > 1) b += (long)grid.y * px * 2 * 4;
+    return b > 0 ? b : 4;
 }
 
 C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
-                              float* gflow, int N, int C, int H, int W, void* stream) {
+                              float* gflow, int N, int C, int H, int W, void* workspace, void* stream) {
     C2M_ENTER();
     if ((long)N * C * H * W <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
-    hipLaunchKernelGGL(flow_warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, flow, occ, gout, gimg,
-                       gflow, N, C, H, W, cchunk);
+    const long HW = (long)H * W, px = (long)N * HW;
+    char* ws = (char*)workspace;
+    if (gimg) {
+        int* count = (int*)ws;
+        int* offset = count + px;
+        int* cursor = offset + px;
+        int* keys = cursor + px;
+        float* vals = (float*)(keys + px * 4);
+        ws += px * 4 * 3 + px * 4 * 4 * 2;
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * px, s);
+        if (e != hipSuccess) return (int)e;
+        WarpInvP p{flow, occ, N, H, W};
+        const int g1 = c2m_grid(px, 256);
+        hipLaunchKernelGGL(warp_inv_count_kernel, dim3(g1), dim3(256), 0, s, p, count);
+        hipLaunchKernelGGL(warp_inv_scan_kernel, dim3((unsigned)N), dim3(1024), 0, s, count, offset, cursor, (int)HW);
+        hipLaunchKernelGGL(warp_inv_fill_kernel, dim3(g1), dim3(256), 0, s, p, cursor, keys, vals);
+        hipLaunchKernelGGL(warp_inv_sort_kernel, dim3(g1), dim3(256), 0, s, count, offset, keys, vals, (long)N, (int)HW);
+        hipLaunchKernelGGL(flow_warp_bwd_img_kernel, grid, dim3(256), 0, s, gout, occ, count, offset, keys, vals, gimg, N,
+                           C, (int)HW, cchunk);
+    }
+    if (gflow) {
+        float* dst = grid.y > 1 ? (float*)ws : gflow;
+        hipLaunchKernelGGL(flow_warp_bwd_flow_kernel, grid, dim3(256), 0, s, img, flow, occ, gout, dst, N, C, H, W, cchunk);
+        if (grid.y > 1)
+            hipLaunchKernelGGL(warp_flow_chunk_sum_kernel, dim3(c2m_grid(px * 2, 256)), dim3(256), 0, s, dst, gflow,
+                               px * 2, (int)grid.y);
+    }
     return (int)hipGetLastError();
 }
 

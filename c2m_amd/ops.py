@@ -783,13 +783,13 @@ class _FlowWarpFn(torch.autograd.Function):
         img, flow, occ = ctx.saved_tensors
         N, C, H, W = img.shape
         L = _lib.lib()
-        gimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
-        gflow = None
-        if ctx.needs_input_grad[1]:
-            gflow = (torch.zeros_like if L.c2m_flow_warp_bwd_needs_zero(N, C, H, W) else torch.empty_like)(flow)
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         if gimg is not None or gflow is not None:
+            ws = torch.empty(L.c2m_flow_warp_bwd_workspace_bytes(N, C, H, W, int(gimg is not None), int(gflow is not None)),
+                             device=img.device, dtype=torch.uint8)
             _lib.check(L.c2m_flow_warp_bwd(_p(img), _p(flow), _p(occ), _p(_f(gout)), _p(gimg), _p(gflow), N, C, H, W,
-                                           _stream()), "flow_warp_bwd")
+                                           _p(ws), _stream()), "flow_warp_bwd")
         return gimg, gflow, None
 
 

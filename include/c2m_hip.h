@@ -117,9 +117,12 @@ int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act,
  * motion_autoencoder.py:125 (fused "* occlusion"), losses.py:219, model.py:204,208.                          */
 int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H, int W,
                       void* stream);
-int c2m_flow_warp_bwd_needs_zero(int N, int C, int H, int W);
+/* backward of the above (ATen grid_sampler_2d_backward: a float-atomic scatter on GPUs).  Deterministic here: d(image) is
+ * gathered through an inverted tap list built in `workspace`, d(flow) is summed in a fixed channel order; neither
+ * output needs zero-initialisation and either may be NULL.                                                      */
+long c2m_flow_warp_bwd_workspace_bytes(int N, int C, int H, int W, int want_gimg, int want_gflow);
 int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
-                      float* gflow, int N, int C, int H, int W, void* stream);
+                      float* gflow, int N, int C, int H, int W, void* workspace, void* stream);
 /* F.interpolate(bilinear) (utils/utils.py:349 align_corners=True; motion_autoencoder.py:123, up_block.py:10).  */
 int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
                         double scale_factor, void* stream);

@@ -336,8 +336,32 @@ def test_flow_warp_golden(name):
     if "gout" in i:
         (y * g(i["gout"])).sum().backward()
         gin = c.group("gin")
-        close(img.grad, gin["image"], 1e-5, 1e-6, "d image (atomic order)")
+        close(img.grad, gin["image"], 1e-5, 1e-6, "d image")
         close(flow.grad, gin["flow"], 1e-4, 1e-5, "d flow")
+
+
+@pytest.mark.parametrize("shape", [(40, 64, 8, 16), (5, 3, 128, 256), (8, 256, 16, 32), (2, 5, 9, 13)])
+def test_flow_warp_backward_is_bit_repeatable(shape):
+    """No float atomics: d(image) is gathered through the inverted tap list in a fixed (dest pixel, corner) order and
+    d(flow) is summed in a fixed channel order, so two launches give identical bits -- also for a strongly converging
+    flow (long tap lists) and with the occlusion factor."""
+    N, C, H, W = shape
+    img, go = g(rnd(11, *shape)), g(rnd(12, *shape))
+    occ = g(torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(13)))
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    converge = torch.stack([(W / 2 - xs) * 0.9, (H / 2 - ys) * 0.9], 0).unsqueeze(0).repeat(N, 1, 1, 1)
+    for flow in (rnd(14, N, 2, H, W, scale=2.5), converge + rnd(15, N, 2, H, W, scale=0.3)):
+        grads = []
+        for _ in range(2):
+            ig, fg = img.clone().requires_grad_(True), g(flow).requires_grad_(True)
+            (ops.flow_warp(ig, fg, occ) * go).sum().backward()
+            grads.append((ig.grad.clone(), fg.grad.clone()))
+        assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+        # and the values are right (CPU restatement; its own scatter order differs only in rounding)
+        ir, fr = img.cpu().clone().requires_grad_(True), flow.clone().requires_grad_(True)
+        ((O.resample(ir, fr) * occ.cpu()) * go.cpu()).sum().backward()
+        rel_close(grads[0][0], ir.grad, 2e-5, "d image (converging flow)" if flow is not None else "")
+        rel_close(grads[0][1], fr.grad, 2e-4, "d flow")
 
 
 @pytest.mark.parametrize("shape", [(40, 16, 4, 8), (5, 64, 32, 64), (2, 3, 128, 256), (3, 7, 9, 13)])
