@@ -404,10 +404,17 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
 // Winograd form of the 3x3 stride-1 weight gradient (same layers as above):
 //   dg[co][ci] = G^T [ sum_tiles (A dY A^T)[co][tile] (.) (B^T d B)[ci][tile] ] G
 // i.e. 16 independent GEMMs dU_xi[co][ci] = dM_xi[co][:] . V_xi[ci][:] contracted over the 2x2-output tiles (N*H/2*W/2 of
-// them) -- again 16 multiplies where the direct form needs 36.  One workgroup = 64 output channels x 32 input channels
-// over a range of 2x16-output regions (8 tiles each = one chunk, K = 8): both patches arrive by LDS-DMA one chunk ahead
-// of their transform, the two transforms of chunk c+1 are interleaved with the MFMAs of chunk c (double-buffered
-// operand images in LDS: dM [xi][tile][co], V [xi][tile][ci] -- lanes along the channel, conflict-free on both sides).
+// them) -- 16 multiplies where the direct form needs 36.
+//
+// One workgroup = 64 output channels x 64 input channels x 16 frequencies over a range of 2x16-output regions (8 tiles =
+// one chunk = 4 MFMA k-steps).  Wave w owns the transformed ROW i = w (xi = 4w .. 4w+3): 4 xi x (2 x 2 tiles of 32x32) x
+// 16 = 256 accumulator registers, one workgroup per CU.  Only the RAW patches are staged (double buffered: dY [co][2][16]
+// and X [ci][4][24]); every lane builds its own MFMA fragments in registers: the A fragment of lane
+// (co = lane & 31, tile = lane >> 5) is row i of A dY A^T of that lane's 2x2 dY block (4 floats from LDS, 7 VALU -> 4 xi),
+// the B fragment is row i of B^T d B of its 4x4 input patch (2 raw rows x 4 floats, 8 VALU -> 4 xi).  No transformed
+// operand ever goes through LDS (round 1's kernel wrote and re-read both and was bound by the ~170 non-MFMA instructions
+// per 32 MFMAs); per 16 MFMAs a wave issues ~30 VALU and 16 ds_read_b64 (2-way bank conflicts at most: irrelevant at
+// this intensity).
 // Pixel ranges are split over workgroups into slabs [split][xi][Cout][Cin] (+ a bias-gradient slab from the plain sum of
 // dY); wino_wgrad_reduce_kernel sums the splits in a fixed order, applies G^T (.) G and writes dW in its native layout.
 struct WinoWgP {
@@ -419,21 +426,17 @@ struct WinoWgP {
     int regions, per_split;          // 2x16-output regions in total / per workgroup
 };
 
-constexpr int GR = 2, GC = 8, GT = 4;                // region rows, cols, tiles (one chunk: K = 4 tiles)
-constexpr int GY_STRIDE = GR * GC + 1;               // 17: dY patch [co][2][8] + 1 pad (odd stride: conflict-free)
-constexpr int GX_STRIDE = (GR + 2) * (GC + 2) + 1;   // 41: X patch [ci][4][10] + 1 pad
-constexpr int GY_LOADS = (64 * GY_STRIDE + 255) / 256;   // 5
-constexpr int GX_LOADS = (64 * GX_STRIDE + 255) / 256;   // 11
+constexpr int GR = 2, GC = 16, GT = 8;               // region rows, cols, tiles (one chunk: 4 k-steps of 2 tiles)
+constexpr int GY_STRIDE = GR * GC + 4;               // 36: dY patch [co][2][16] + 4 pad (16-B units stay aligned)
+constexpr int GX_COLS = GC + 8;                      // 24: image columns ox0-4 .. ox0+19 as six aligned 16-B units
+constexpr int GX_STRIDE = 4 * GX_COLS + 4;           // 100: X patch [ci][4][24] + 4 pad
+constexpr int GY_UNITS = 64 * GR * (GC / 4) / 256;   // 2 float4 per thread and chunk
+constexpr int GX_UNITS = 64 * 4 * (GX_COLS / 4) / 256;   // 6
 
-// Workgroup = 64 output channels x 64 input channels x 16 frequencies = 256 accumulator registers per lane (AGPRs; one
-// workgroup per CU).  Issue-slot budget: the 32 MFMAs of a chunk occupy 32 x 16 issue quads; everything else of the
-// chunk (patch DMA, both transforms, fragment reads, address arithmetic) must stay well below that and be spread
-// between the MFMAs (one MFMA : ~6 other instructions), because instructions behind a stalled MFMA cannot overtake it.
 __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
-    __shared__ float pY[2][GY_LOADS * 256];
-    __shared__ float pX[2][GX_LOADS * 256];
-    __shared__ float sDM[2][16 * GT * 64];             // [xi][tile][co]
-    __shared__ float sVV[2][16 * GT * 64];             // [xi][tile][ci]
+    __shared__ float pY[2][64 * GY_STRIDE];
+    __shared__ float pX[2][64 * GX_STRIDE];
+    __shared__ float sDb[2 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
@@ -444,115 +447,85 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     const int nchunks = rend - rbeg;
     const int regions_x = p.W / GC, regions_y = p.H / GR;
 
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned long ya = (unsigned long)p.dY, xa = (unsigned long)p.X;
-    const u32x4 rsy = {(unsigned)ya, (unsigned)(ya >> 32) & 0xffffu, p.dy_bytes, 0x00020000u};
-    const u32x4 rsx = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
-    const unsigned py_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pY[0][0];
-    const unsigned px_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&pX[0][0];
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
 
-    // patch slots of this thread; byte offsets relative to the region origin (the origin is the scalar offset per chunk)
-    unsigned yvo[GY_LOADS];
+    // Raw patches are fetched as aligned 16-byte units into registers one chunk ahead and stored with ds_write_b128
+    // (an LDS-DMA piece costs the issuing wave 60-185 cycles and these waves are MFMA-issue bound; 8 plain loads + 8 LDS
+    // stores per chunk cost it ~200).  dY unit u = tid + i*256: (co, row, quarter).  X unit: (ci, r, q), r = input rows
+    // oy0-1 .. oy0+2, q = columns ox0-4+4q ..: the halo columns ox0-1 and ox0+16 are element 3 of unit 0 and element 0 of
+    // unit 5.  At the left / right image edge those two units are loaded from the neighbouring inside unit and the
+    // reflected element (x[1] resp. x[W-2]) is moved into place in registers; zero padding loads out of range (= 0).
+    unsigned yvo[GY_UNITS]; int ydst[GY_UNITS];
 #pragma unroll
-    for (int i = 0; i < GY_LOADS; ++i) {
-        const int s = tid + i * 256;
-        const int co = s / GY_STRIDE, rem = s % GY_STRIDE;
-        const bool ok = co < 64 && rem < GR * GC && m0 + co < p.M;
-        yvo[i] = ok ? (unsigned)((m0 + co) * HW + (rem / GC) * p.W + rem % GC) * 4u : WINO_OOB;
+    for (int i = 0; i < GY_UNITS; ++i) {
+        const int u = tid + i * 256;
+        const int co = u >> 3, row = (u >> 2) & 1, q = u & 3;
+        yvo[i] = m0 + co < p.M ? (unsigned)((m0 + co) * HW + row * p.W + q * 4) * 4u : WINO_OOB;
+        ydst[i] = co * GY_STRIDE + row * GC + q * 4;
     }
-    // X patch: (ci, r, c), r in 0..3 (input rows oy0-1 ..), c in 0..9.  Interior regions use the precomputed offsets;
-    // regions touching the image border recompute theirs (zero / reflect padding)
-    unsigned xvo[GX_LOADS];
-    int xci[GX_LOADS], xrc[GX_LOADS];
+    int xch[GX_UNITS], xr[GX_UNITS], xq[GX_UNITS], xdst[GX_UNITS];
 #pragma unroll
-    for (int i = 0; i < GX_LOADS; ++i) {
-        const int s = tid + i * 256;
-        const int ci = s / GX_STRIDE, rem = s % GX_STRIDE;
-        const bool ok = ci < 64 && rem < (GR + 2) * (GC + 2) && c0 + ci < p.K;
-        const int r = rem / (GC + 2), c = rem % (GC + 2);
-        xci[i] = ok ? (c0 + ci) * HW : -1;
-        xrc[i] = r * 16 + c;
-        xvo[i] = ok ? (unsigned)((c0 + ci) * HW + (r - 1) * p.W + (c - 1)) * 4u : WINO_OOB;     // may wrap: added to soff
+    for (int i = 0; i < GX_UNITS; ++i) {
+        const int u = tid + i * 256;
+        const int ci = u / 24, rem = u % 24;
+        xr[i] = rem / 6; xq[i] = rem % 6;
+        xch[i] = c0 + ci < p.K ? (c0 + ci) * HW : -1;
+        xdst[i] = ci * GX_STRIDE + xr[i] * GX_COLS + xq[i] * 4;
     }
-    auto issue_dma = [&](int region, int buf) {
+    f32x4 gy[GY_UNITS], gx[GX_UNITS];
+    auto fetch = [&](int region) {
         const int rx = region % regions_x; int t = region / regions_x;
         const int ry = t % regions_y; const int img = t / regions_y;
         const int oy0 = ry * GR, ox0 = rx * GC;
         const int ysoff = (int)(((long)img * p.dy_sn + (long)oy0 * p.W + ox0) * 4);
 #pragma unroll
-        for (int i = 0; i < GY_LOADS; ++i) {
-            const unsigned dst = py_lds + (unsigned)((buf * GY_LOADS * 256 + wave * 64 + i * 256) * 4);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(yvo[i]), "s"(rsy), "s"(ysoff) : "memory");
-        }
-        const bool interior = ry > 0 && ry + 1 < regions_y && rx > 0 && rx + 1 < regions_x;    // wave-uniform
+        for (int i = 0; i < GY_UNITS; ++i)
+            gy[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, yvo[i], ysoff, 0));
         const unsigned ximg = (unsigned)((long)img * p.x_sn * 4);
-        const unsigned xorg = ximg + (unsigned)(oy0 * p.W + ox0) * 4u;
 #pragma unroll
-        for (int i = 0; i < GX_LOADS; ++i) {
-            unsigned vo;
-            if (interior) {
-                vo = xvo[i] == WINO_OOB ? WINO_OOB : xvo[i] + xorg;
+        for (int i = 0; i < GX_UNITS; ++i) {
+            int iy = oy0 - 1 + xr[i], ix = ox0 - 4 + 4 * xq[i];
+            bool ok = xch[i] >= 0;
+            if (p.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+                ix = ix < 0 ? 0 : ix; ix = ix >= p.W ? p.W - 4 : ix;          // edge halo: neighbouring inside unit
             } else {
-                int iy = oy0 - 1 + (xrc[i] >> 4), ix = ox0 - 1 + (xrc[i] & 15);
-                bool ok = xci[i] >= 0;
-                if (p.reflect) {
-                    iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
-                    ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
-                } else {
-                    ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                }
-                vo = ok ? ximg + (unsigned)(xci[i] + iy * p.W + ix) * 4u : WINO_OOB;
+                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             }
-            const unsigned dst = px_lds + (unsigned)((buf * GX_LOADS * 256 + wave * 64 + i * 256) * 4);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(vo), "s"(rsx), "s"(0) : "memory");
+            const unsigned vo = ok ? ximg + (unsigned)(xch[i] + iy * p.W + ix) * 4u : WINO_OOB;
+            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
+            gx[i] = v;
+        }
+    };
+    auto stash = [&](int region, int buf) {
+        const int rx = region % regions_x;
+        const bool left = p.reflect && rx == 0, right = p.reflect && rx == regions_x - 1;     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < GY_UNITS; ++i) *reinterpret_cast<f32x4*>(&pY[buf][ydst[i]]) = gy[i];
+#pragma unroll
+        for (int i = 0; i < GX_UNITS; ++i) {
+            f32x4 v = gx[i];
+            if (left && xq[i] == 0) v[3] = v[1];            // column -1 -> column 1 (unit holds columns 0..3)
+            if (right && xq[i] == 5) v[0] = v[2];           // column W -> column W-2 (unit holds columns W-4..W-1)
+            *reinterpret_cast<f32x4*>(&pX[buf][xdst[i]]) = v;
         }
     };
 
-    // transform role of a thread: channel ch = tid & 63 (as output channel AND as input channel), tile tq = tid >> 6
-    const int ch = tid & 63, tq = tid >> 6;
-    float dbacc = 0.f;
-    float yv[4], xv[4][4];
-    auto read_patches = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) yv[e] = pY[buf][ch * GY_STRIDE + (e >> 1) * GC + 2 * tq + (e & 1)];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) xv[a][b] = pX[buf][ch * GX_STRIDE + a * (GC + 2) + 2 * tq + b];
-    };
-    auto transform_store = [&](int ob) {
-        // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
-        const float y00 = yv[0], y01 = yv[1], y10 = yv[2], y11 = yv[3];
-        dbacc += (y00 + y01) + (y10 + y11);
-        const float T[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
-        float* __restrict__ d = &sDM[ob][tq * 64 + ch];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d[(4 * i + 0) * GT * 64] = T[i][0];
-            d[(4 * i + 1) * GT * 64] = T[i][0] + T[i][1];
-            d[(4 * i + 2) * GT * 64] = T[i][0] - T[i][1];
-            d[(4 * i + 3) * GT * 64] = -T[i][1];
-        }
-        // V = B^T d B
-        float x[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            x[0][b] = xv[0][b] - xv[2][b];
-            x[1][b] = xv[1][b] + xv[2][b];
-            x[2][b] = xv[2][b] - xv[1][b];
-            x[3][b] = xv[1][b] - xv[3][b];
-        }
-        float* __restrict__ v = &sVV[ob][tq * 64 + ch];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[(4 * i + 0) * GT * 64] = x[i][0] - x[i][2];
-            v[(4 * i + 1) * GT * 64] = x[i][1] + x[i][2];
-            v[(4 * i + 2) * GT * 64] = x[i][2] - x[i][1];
-            v[(4 * i + 3) * GT * 64] = x[i][1] - x[i][3];
-        }
-    };
+    // row i = wave of the two transforms as wave-uniform coefficients (exact: the factors are 0 / +-1)
+    //   A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]:   T = ya * row0 + yb * row1
+    //   B^T d,   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]:   x = d[ra] + xs * d[rb]
+    const float ya_c = wave == 3 ? 0.f : 1.f;
+    const float yb_c = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float xs_c = wave == 1 ? 1.f : -1.f;
+    const int cl = lane & 31, kl = lane >> 5;
+    const int yoff = cl * GY_STRIDE + 2 * kl;                       // + q * 32 * GY_STRIDE + 4 * ks (+ GC for row 1)
+    // patch column 2t+j (j = 0..3; patch column 0 = image column ox0-1) = local column 2t+3+j: read the three aligned
+    // pairs from local column 2t+2 and use elements 1..4
+    const int xoff_a = cl * GX_STRIDE + ra * GX_COLS + 2 * kl + 2;  // + q * 32 * GX_STRIDE + 4 * ks
+    const int xoff_b = cl * GX_STRIDE + rb * GX_COLS + 2 * kl + 2;
 
     f32x16 acc[4][2][2];
 #pragma unroll
@@ -563,97 +536,132 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][mi][ni][r] = 0.f;
+    float dbacc[2] = {0.f, 0.f};
+    const bool want_db = nt == 0 && wave == 0;                      // wave-uniform
+
+    struct Raw { float2 y0[2], y1[2]; float2 a0[2], a1[2], a2[2], b0[2], b1[2], b2[2]; };
+    auto load_raw = [&](int buf, int ks, Raw& r) {
+        const float* __restrict__ py = &pY[buf][0];
+        const float* __restrict__ px = &pX[buf][0];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int yo = yoff + q * 32 * GY_STRIDE + 4 * ks;
+            r.y0[q] = *reinterpret_cast<const float2*>(py + yo);
+            r.y1[q] = *reinterpret_cast<const float2*>(py + yo + GC);
+            const int xa_ = xoff_a + q * 32 * GX_STRIDE + 4 * ks, xb_ = xoff_b + q * 32 * GX_STRIDE + 4 * ks;
+            r.a0[q] = *reinterpret_cast<const float2*>(px + xa_);
+            r.a1[q] = *reinterpret_cast<const float2*>(px + xa_ + 2);
+            r.a2[q] = *reinterpret_cast<const float2*>(px + xa_ + 4);
+            r.b0[q] = *reinterpret_cast<const float2*>(px + xb_);
+            r.b1[q] = *reinterpret_cast<const float2*>(px + xb_ + 2);
+            r.b2[q] = *reinterpret_cast<const float2*>(px + xb_ + 4);
+        }
+    };
+    auto mma_step = [&](const Raw& r) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (want_db) dbacc[q] += (r.y0[q].x + r.y0[q].y) + (r.y1[q].x + r.y1[q].y);
+            const float t0 = fmaf(yb_c, r.y1[q].x, ya_c * r.y0[q].x), t1 = fmaf(yb_c, r.y1[q].y, ya_c * r.y0[q].y);
+            a[q][0] = t0; a[q][1] = t0 + t1; a[q][2] = t0 - t1; a[q][3] = -t1;
+            const float x0 = fmaf(xs_c, r.b0[q].y, r.a0[q].y), x1 = fmaf(xs_c, r.b1[q].x, r.a1[q].x);
+            const float x2 = fmaf(xs_c, r.b1[q].y, r.a1[q].y), x3 = fmaf(xs_c, r.b2[q].x, r.a2[q].x);
+            b[q][0] = x0 - x2; b[q][1] = x1 + x2; b[q][2] = x2 - x1; b[q][3] = x1 - x3;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[j][mi][ni], 0, 0, 0);
+    };
 
     if (nchunks > 0) {
-        issue_dma(rbeg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fetch(rbeg);
+        stash(rbeg, 0);
         __syncthreads();
-        read_patches(0);
-        if (nchunks > 1) issue_dma(rbeg + 1, 1);
-        transform_store(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int cur = chunk & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // patches(chunk + 1) of this wave have landed
-            __syncthreads();   // operands(chunk) + patches(chunk+1) complete; everyone is done with operand buffer cur ^ 1
-            float a[4][2][2], b[4][2][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int row = ((4 * wave + j) * GT + 2 * kk + (lane >> 5)) * 64 + (lane & 31);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        a[j][q][kk] = sDM[cur][row + q * 32];
-                        b[j][q][kk] = sVV[cur][row + q * 32];
-                    }
-                }
             const bool more = chunk + 1 < nchunks;
-            read_patches(cur ^ 1);                       // chunk + 1 (last chunk: stale data, result unused)
-            __builtin_amdgcn_sched_barrier(0);
-            if (chunk + 2 < nchunks) issue_dma(rbeg + chunk + 2, cur);   // patch buffer `cur` was consumed one iteration ago
-            const float dbkeep = dbacc;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][kk], b[j][ni][kk],
-                                                                                  acc[j][mi][ni], 0, 0, 0);
-            transform_store(cur ^ 1);
-            if (!more) dbacc = dbkeep;                   // the stale transform of the last iteration must not count
-#pragma unroll
-            for (int g = 0; g < 32; ++g) {               // one MFMA : ~3 other instructions
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
+            if (more) fetch(rbeg + chunk + 1);               // lands while this chunk's 64 MFMAs run
+            Raw r0, r1;
+            load_raw(cur, 0, r0);
+            load_raw(cur, 1, r1);
+            mma_step(r0);
+            load_raw(cur, 2, r0);
+            mma_step(r1);
+            load_raw(cur, 3, r1);
+            mma_step(r0);
+            mma_step(r1);
+            if (more) stash(rbeg + chunk + 1, cur ^ 1);      // buffer cur ^ 1 was last read before the previous barrier
+            __syncthreads();
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- slab: dU_xi[co][ci] partials of this workgroup's region range
+    // ---- slab [split][xi][ci][co]: co innermost, so the four consecutive rows a lane holds in acc[..][4g .. 4g+3] are
+    // one 16-byte store (a dword store per accumulator register made the 256 KB epilogue store-issue bound)
     float* __restrict__ out = p.slab + (long)split * 16 * p.M * p.K;
+    const bool m_vec = (p.M & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xi = 4 * wave + j;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int ci = c0 + ni * 32 + (lane & 31);
+            if (ci >= p.K) continue;
+            float* __restrict__ col = out + ((long)xi * p.K + ci) * p.M;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (co < p.M && ci < p.K) out[((long)xi * p.M + co) * p.K + ci] = acc[j][mi][ni][r];
+                for (int g = 0; g < 4; ++g) {
+                    const int co = m0 + mi * 32 + 8 * g + 4 * (lane >> 5);
+                    if (m_vec && co + 3 < p.M) {
+                        f32x4 v = {acc[j][mi][ni][4 * g], acc[j][mi][ni][4 * g + 1], acc[j][mi][ni][4 * g + 2],
+                                   acc[j][mi][ni][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(col + co) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < p.M) col[co + e] = acc[j][mi][ni][4 * g + e];
+                    }
                 }
         }
     }
-    // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0 only)
+    // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0, wave 0)
     if (nt == 0) {
-        float* __restrict__ red = &sDM[0][0];
-        red[tq * 64 + ch] = dbacc;
+        if (wave == 0) { sDb[lane] = dbacc[0]; sDb[64 + lane] = dbacc[1]; }
         __syncthreads();
-        if (tid < 64 && m0 + tid < p.M)
-            p.dbslab[(long)split * p.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        if (tid < 64 && m0 + tid < p.M) {
+            const int q = tid >> 5, c = tid & 31;
+            p.dbslab[(long)split * p.M + m0 + tid] = sDb[q * 64 + c] + sDb[q * 64 + 32 + c];
+        }
     }
 }
 
-// dW[co][ci][3][3] = G^T (sum_splits dU) G;  db[co] = sum_splits dbslab
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
+// Stage 1: u[e] = sum_s slab[s][e] over the 16*M*K elements (fixed order; 16-byte loads, four splits in flight).
+__global__ void wino_slab_sum_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ u, long n4, int S) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = slab[i];
+        int s = 1;
+        for (; s + 3 < S; s += 4) {
+            const f32x4 a = slab[(long)s * n4 + i], b = slab[(long)(s + 1) * n4 + i], c = slab[(long)(s + 2) * n4 + i],
+                        d = slab[(long)(s + 3) * n4 + i];
+            acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
+        }
+        for (; s < S; ++s) acc = acc + slab[(long)s * n4 + i];
+        u[i] = acc;
+    }
+}
+
+// Stage 2: dW[co][ci][3][3] = G^T u G with u[xi][ci][co];  db[co] = sum_splits dbslab
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ usum, const float* __restrict__ dbslab,
                                          float* __restrict__ dW, float* __restrict__ db, int M, int K, int S) {
     const long total = (long)M * K;
-    const long per = 16 * total;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i / M), co = (int)(i - (long)ci * M);          // reads coalesced along co
         float u[4][4];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            float acc = 0.f;
-            for (int s = 0; s < S; ++s) acc += slab[(long)s * per + (long)xi * total + i];
-            u[xi >> 2][xi & 3] = acc;
-        }
+        for (int xi = 0; xi < 16; ++xi) u[xi >> 2][xi & 3] = usum[(long)xi * total + i];
         // G^T u: rows a = 0..2 from i = 0..3 with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
         float t[3][4];
 #pragma unroll
@@ -662,7 +670,7 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const f
             t[1][j] = 0.5f * (u[1][j] - u[2][j]);
             t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
         }
-        float* __restrict__ o = dW + i * 9;
+        float* __restrict__ o = dW + ((long)co * K + ci) * 9;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
@@ -679,20 +687,22 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const f
     }
 }
 
-// Number of region splits (= slabs) the launch will use: slab = S*16*M*K floats, dbslab = S*M floats.
+// Number of region splits the launch will use.  The caller provides slab = (S + 1)*16*M*K floats (S partial slabs + the
+// summed one) and dbslab = S*M floats.
 C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long regions = (long)nimg * (H / GR) * (W / GC);
     const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 64);
     long S = 256 / tiles;                       // one workgroup per CU (256 accumulator registers): one resident round
     if (S < 1) S = 1;
-    const long maxS = (regions + 31) / 32;      // >= 32 regions (128 tiles) per split
+    if (S > 64) S = 64;                         // slab traffic: every split writes (and stage 1 re-reads) 64 KB per tile
+    const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     const long per = (regions + S - 1) / S;
     return (int)((regions + per - 1) / per);
 }
 
-// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 8 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
+// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 16 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
 C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
                                 int M, int K, int nimg, int H, int W, int reflect, void* stream) {
     C2M_ENTER();
@@ -713,7 +723,15 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(c2m_grid((long)M * K, 256)), dim3(256), 0, s, slab, dbslab, dW, db,
+    const long n = 16L * M * K;
+    float* usum = slab + (long)S * n;
+    if ((n & 3) == 0) {
+        hipLaunchKernelGGL(wino_slab_sum_kernel, dim3(c2m_grid(n / 4, 256)), dim3(256), 0, s, (const f32x4*)slab,
+                           (f32x4*)usum, n / 4, S);
+    } else {
+        return (int)hipErrorInvalidValue;       // M*K is a multiple of 4 for every layer the host routes here (checked there)
+    }
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(c2m_grid((long)M * K, 256)), dim3(256), 0, s, usum, dbslab, dW, db,
                        M, K, S);
     return (int)hipGetLastError();
 }

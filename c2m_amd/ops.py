@@ -59,9 +59,9 @@ def _f(t):
 _geom_cache = {}
 _conv_bf16 = False
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
-# The Winograd WEIGHT gradient is parity-green but not yet faster than the direct wgrad kernel (both operands go through an
-# LDS transform and it is instruction-issue bound; 52-115 vs 67-95 TF/s), so it only runs when forced (tests) or asked for.
-_WINO_WGRAD = os.environ.get("C2M_WINOGRAD_WGRAD", "off")      # "off" | "on" | "force"
+# Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
+# the direct kernel, "off", "force" (tests: every eligible shape).
+_WINO_WGRAD = os.environ.get("C2M_WINOGRAD_WGRAD", "auto")      # "auto" | "off" | "force"
 
 
 def set_conv_precision(precision):
@@ -306,8 +306,10 @@ class _ConvPlan:
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
-            if Hi % 2 == 0 and Wi % 8 == 0 and (_WINO_WGRAD == "force" or (
-                    _WINO_WGRAD == "on" and Cin >= 48 and Cout >= 48 and N * (Hi // 2) * (Wi // 8) >= 4096)):
+            wg_tiles = _cdiv(Cin, 64) * _cdiv(Cout, 64)
+            if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
+                    _WINO_WGRAD == "auto" and wg_tiles >= 4 and 4096 * wg_tiles <= 1.35 * Cin * Cout
+                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 256 // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
@@ -644,7 +646,7 @@ class _ConvFn(torch.autograd.Function):
                            "reflect fold")
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad:
             S = pl.wino_wg_splits
-            slab = torch.empty(S * 16 * Cout * Cin, device=x.device, dtype=torch.float32)
+            slab = torch.empty((S + 1) * 16 * Cout * Cin, device=x.device, dtype=torch.float32)
             dbslab = torch.empty(S * Cout, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)

@@ -120,6 +120,7 @@ WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3
     ((3, 40, 24, 48), 70, (3, 3), 1, 1, "reflect"),      # channels not multiples of 8 / 64: zero-padded U, partial M tile
     ((2, 16, 10, 20), 8, (3, 3), 1, 1, "zeros"),         # partial 8x16 regions on both axes
     ((3, 40, 6, 48), 70, (3, 3), 1, 1, "zeros"),         # Winograd wgrad: partial channel tiles, 27 regions over 2 splits
+    ((2, 130, 16, 32), 136, (3, 3), 1, 1, "reflect"),    # Winograd wgrad: every region touches the border, 3 x 3 channel tiles
     ((2, 64, 32, 64), 96, (3, 3), 1, 1, "reflect"),      # Winograd wgrad: several chunks per workgroup, reflected patches
 ]
 
@@ -144,11 +145,11 @@ def test_conv_winograd_forced(case, monkeypatch):
         xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
         y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
         pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
-        assert pl.wino_fwd and pl.wino_dgrad and pl.wino_wgrad == (xs[2] % 2 == 0 and xs[3] % 8 == 0)
+        assert pl.wino_fwd and pl.wino_dgrad and pl.wino_wgrad == (xs[2] % 2 == 0 and xs[3] % 16 == 0)
         (y * g(go)).sum().backward()
         rel_close(y, yr, 2e-5, "winograd fwd")
         rel_close(xg.grad, xr.grad, 5e-5, "winograd dgrad")
-        rel_close(wg.grad, wr.grad, 1e-4, "wgrad (Winograd where H % 2 == 0 and W % 8 == 0, else the direct kernel)")
+        rel_close(wg.grad, wr.grad, 1e-4, "wgrad (Winograd where H % 2 == 0 and W % 16 == 0, else the direct kernel)")
         rel_close(bg.grad, br.grad, 1e-4, "bias grad", floor=1e-3 * float(go.abs().sum()) / cout)
     finally:
         ops._geom_cache.clear()
