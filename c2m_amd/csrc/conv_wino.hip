@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     const bool want_db = nt == 0 && wave == 0;                      // wave-uniform
 
     struct Raw { float2 y0[2], y1[2]; float2 a0[2], a1[2], a2[2], b0[2], b1[2], b2[2]; };
+    struct Frag { float a[2][4], b[2][4]; };
     auto load_raw = [&](int buf, int ks, Raw& r) {
         const float* __restrict__ py = &pY[buf][0];
         const float* __restrict__ px = &pX[buf][0];
@@ -557,47 +558,80 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             r.b2[q] = *reinterpret_cast<const float2*>(px + xb_ + 4);
         }
     };
-    auto mma_step = [&](const Raw& r) {
-        float a[2][4], b[2][4];
+    auto transform = [&](const Raw& r, Frag& f, bool count_db) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (want_db) dbacc[q] += (r.y0[q].x + r.y0[q].y) + (r.y1[q].x + r.y1[q].y);
+            if (count_db) dbacc[q] += (r.y0[q].x + r.y0[q].y) + (r.y1[q].x + r.y1[q].y);
             const float t0 = fmaf(yb_c, r.y1[q].x, ya_c * r.y0[q].x), t1 = fmaf(yb_c, r.y1[q].y, ya_c * r.y0[q].y);
-            a[q][0] = t0; a[q][1] = t0 + t1; a[q][2] = t0 - t1; a[q][3] = -t1;
+            f.a[q][0] = t0; f.a[q][1] = t0 + t1; f.a[q][2] = t0 - t1; f.a[q][3] = -t1;
             const float x0 = fmaf(xs_c, r.b0[q].y, r.a0[q].y), x1 = fmaf(xs_c, r.b1[q].x, r.a1[q].x);
             const float x2 = fmaf(xs_c, r.b1[q].y, r.a1[q].y), x3 = fmaf(xs_c, r.b2[q].x, r.a2[q].x);
-            b[q][0] = x0 - x2; b[q][1] = x1 + x2; b[q][2] = x2 - x1; b[q][3] = x1 - x3;
+            f.b[q][0] = x0 - x2; f.b[q][1] = x1 + x2; f.b[q][2] = x2 - x1; f.b[q][3] = x1 - x3;
         }
+    };
+    auto mma = [&](const Frag& f) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[j][mi][ni], 0, 0, 0);
+                    acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[j][mi][ni], 0, 0, 0);
     };
+    // One software-pipelined k-step: the 16 MFMAs of step g run on the fragments prepared during step g-1 while the raw
+    // values of step g+1 are read (first MFMA gaps) and transformed (later gaps).  16 ds_read_b64 + ~34 VALU per 16 MFMAs.
+// scheduling pipeline of one k-step (A/B on the bench layers: +2...4 % over the compiler's own order): first MFMA, the 16
+// raw reads of the next step, then the transform VALU spread over the remaining MFMA gaps
+#ifndef WG_NO_SGB
+#define WG_SCHED                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#else
+#define WG_SCHED
+#endif
+#define WG_STEP(RBUF, RKS, FCUR, FNEXT, DB)                                      \
+    do {                                                                          \
+        Raw rw;                                                                   \
+        load_raw(RBUF, RKS, rw);                                                  \
+        mma(FCUR);                                                                \
+        transform(rw, FNEXT, DB);                                                 \
+        WG_SCHED                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
 
     if (nchunks > 0) {
         fetch(rbeg);
         stash(rbeg, 0);
         __syncthreads();
+        Frag fa, fb;
+        {
+            Raw rw;
+            load_raw(0, 0, rw);
+            transform(rw, fa, want_db);
+        }
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int cur = chunk & 1;
             const bool more = chunk + 1 < nchunks;
-            if (more) fetch(rbeg + chunk + 1);               // lands while this chunk's 64 MFMAs run
-            Raw r0, r1;
-            load_raw(cur, 0, r0);
-            load_raw(cur, 1, r1);
-            mma_step(r0);
-            load_raw(cur, 2, r0);
-            mma_step(r1);
-            load_raw(cur, 3, r1);
-            mma_step(r0);
-            mma_step(r1);
-            if (more) stash(rbeg + chunk + 1, cur ^ 1);      // buffer cur ^ 1 was last read before the previous barrier
-            __syncthreads();
+            if (more) fetch(rbeg + chunk + 1);               // lands during k-steps 0 and 1
+            WG_STEP(cur, 1, fa, fb, want_db);                // MFMAs of k-step 0
+            WG_STEP(cur, 2, fb, fa, want_db);                // k-step 1
+            WG_STEP(cur, 3, fa, fb, want_db);                // k-step 2: the last raw reads of buffer cur are issued here,
+            if (more) stash(rbeg + chunk + 1, cur ^ 1);      // before the barrier; buffer cur ^ 1 was last read before the
+            __syncthreads();                                 // previous barrier
+            // k-step 3 + the first raw values of the next chunk (last chunk: stale LDS data, transformed and dropped --
+            // keeps the accumulators out of a conditional path)
+            WG_STEP(cur ^ 1, 0, fb, fa, want_db && more);
         }
     }
+#undef WG_STEP
+#undef WG_SCHED
     // ---- slab [split][xi][ci][co]: co innermost, so the four consecutive rows a lane holds in acc[..][4g .. 4g+3] are
     // one 16-byte store (a dword store per accumulator register made the 256 KB epilogue store-issue bound)
     float* __restrict__ out = p.slab + (long)split * 16 * p.M * p.K;
@@ -694,7 +728,6 @@ C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 64);
     long S = 256 / tiles;                       // one workgroup per CU (256 accumulator registers): one resident round
     if (S < 1) S = 1;
-    if (S > 64) S = 64;                         // slab traffic: every split writes (and stage 1 re-reads) 64 KB per tile
     const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;

@@ -308,7 +308,7 @@ class _ConvPlan:
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
             wg_tiles = _cdiv(Cin, 64) * _cdiv(Cout, 64)
             if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
-                    _WINO_WGRAD == "auto" and wg_tiles >= 4 and 4096 * wg_tiles <= 1.35 * Cin * Cout
+                    _WINO_WGRAD == "auto" and wg_tiles >= 2 and 4096 * wg_tiles <= 1.35 * Cin * Cout
                     and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 256 // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
