@@ -19,12 +19,12 @@ def pad_triple(padding):
     raise ValueError(f"padding {padding}")
 
 
-def conv_module(x, conv, act=None, padding=None, padding_mode=None):
+def conv_module(x, conv, act=None, padding=None, padding_mode=None, dgrad_channels=None):
     """Run an nn.Conv2d / nn.Conv3d container through the implicit-GEMM kernel."""
     pad = conv.padding if padding is None else padding
     mode = conv.padding_mode if padding_mode is None else padding_mode
     return ops.conv(x, conv.weight, conv.bias, stride=tuple(conv.stride), padding=tuple(pad) if not isinstance(pad, int) else pad,
-                    padding_mode=mode, act=act)
+                    padding_mode=mode, act=act, dgrad_channels=dgrad_channels)
 
 
 def batch_norm_module(x, bn, act=None):

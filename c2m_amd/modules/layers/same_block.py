@@ -58,8 +58,10 @@ class SameBlock3d(nn.Module):
         self.use_norm = use_norm
         self._pad3 = pad_triple(padding)
 
-    def forward(self, x):
+    def forward(self, x, dgrad_channels=None):
+        """dgrad_channels: see ops.conv (x = cat([features, a tensor without grad]))."""
         if not self.use_norm:
-            return conv_module(x, self.conv, act="lrelu", padding=self._pad3, padding_mode="reflect")
-        y = conv_module(x, self.conv, padding=self._pad3, padding_mode="reflect")
+            return conv_module(x, self.conv, act="lrelu", padding=self._pad3, padding_mode="reflect",
+                               dgrad_channels=dgrad_channels)
+        y = conv_module(x, self.conv, padding=self._pad3, padding_mode="reflect", dgrad_channels=dgrad_channels)
         return batch_norm_module(y, self.norm, act="lrelu")

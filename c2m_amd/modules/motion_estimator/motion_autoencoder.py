@@ -142,5 +142,7 @@ class DenseMotionDecoder(nn.Module):
                 out = self.fuse_convs[fuse_i](torch.cat([out, sf], 1))
                 fuse_i += 1
         out = self.final_up_block(out)
-        out = fold_time(self.final_fuse(torch.cat([out, sparse_motion], dim=1)))
+        # the rastered sparse motion carries no gradient: the data gradient of final_fuse is only needed for `out`'s channels
+        keep = None if sparse_motion.requires_grad else out.shape[1]
+        out = fold_time(self.final_fuse(torch.cat([out, sparse_motion], dim=1), dgrad_channels=keep))
         return {"dense_motion": unfold_time(self.flow(out), T), "occlusion": unfold_time(self.occlusion(out), T)}

@@ -278,7 +278,7 @@ def _geom(**kw):
 class _ConvPlan:
     """Everything shape-dependent for one conv layer geometry (cached): gather tables + geom arrays."""
 
-    def __init__(self, xs, ws, stride, pad, reflect, device, bf16=False):
+    def __init__(self, xs, ws, stride, pad, reflect, device, bf16=False, dgrad_rows=None):
         L = _lib.lib()
         self.bf16 = bf16
         nd = len(xs) - 2
@@ -297,6 +297,10 @@ class _ConvPlan:
         if 4 * N * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo) >= 2 ** 31:
             raise ValueError("tensor too large: the gather uses 32-bit byte offsets (< 2 GiB per tensor)")
         self.dims = (N, Cin, Cout, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw)
+        # dgrad_rows: only the first dgrad_rows input channels need a gradient (the rest of a concatenated input is a
+        # tensor without grad, e.g. the rastered sparse motion in front of final_fuse): the data-gradient GEMM then has
+        # dM rows instead of Cin -- 32 instead of 34 there, which is one 32-row MFMA tile instead of a half-empty 64
+        dM = self.dM = int(dgrad_rows) if dgrad_rows and tuple(stride) == (1, 1, 1) and 0 < dgrad_rows < Cin else Cin
         self.stride, self.pad, self.reflect = stride, pad, reflect
         self.out_shape = (N, Cout, To, Ho, Wo) if nd == 3 else (N, Cout, Ho, Wo)
         taps = kt * kh * kw
@@ -324,8 +328,8 @@ class _ConvPlan:
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
             dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
             dfit = Hd * Wd >= 0.65 * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16     # 34x66 (70 % fill) still wins: 115-121 vs 89-92 TF/s
-            if _WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and Cin >= 48 and
-                                    dregions * _cdiv(Cin, 64) >= 256):
+            if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and Cin >= 48 and
+                                                   dregions * _cdiv(Cin, 64) >= 256)):
                 self.wino_dgrad = True
                 o = -2 if reflect else -1
                 self.wino_dgrad_geom = np.array(
@@ -399,13 +403,13 @@ class _ConvPlan:
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
                     if not bf16 and (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
-                            _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, Cin):
+                            _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, dM):
                         cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
                     ctab, cnch, cntg = _kstep_table(Cout, coffs, osp, cck)
                     cnk = cnch * cntg
                     npix = N * Qt * Qy * Qx
-                    geom = _geom(M=Cin, nk=cnk, lda=cnk * 16, Npix=npix, To=Qt, Ho=Qy, Wo=Qx, Ti=To, Hi=Ho, Wi=Wo, st=1,
+                    geom = _geom(M=dM, nk=cnk, lda=cnk * 16, Npix=npix, To=Qt, Ho=Qy, Wo=Qx, Ti=To, Hi=Ho, Wi=Wo, st=1,
                                  sh=1, sw=1, in_sn=Cout * osp, in_st=Ho * Wo, in_sh=Wo, out_sn=Cin * Tp * Hp * Wp,
                                  out_sc=Tp * Hp * Wp, out_st=st * Hp * Wp, out_sh=sh * Wp, out_sw=sw,
                                  out_off=offt * Hp * Wp + offy * Wp + offx, reflect=0, is3d=is3d, ns=16 // cck,
@@ -420,14 +424,14 @@ class _ConvPlan:
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
-        S = min(L.c2m_conv_igemm_splits(Cin, c["nk"], c["npix"]) for c in self.classes) if self.classes else 1
+        S = min(L.c2m_conv_igemm_splits(dM, c["nk"], c["npix"]) for c in self.classes) if self.classes else 1
         if S > 1:
             for c in self.classes:
                 if _cdiv(c["nk"], _cdiv(c["nk"], S)) != S:
                     S = 1
                     break
         if any(c["patch"] for c in self.classes):        # stride-1 3x3: a single class
-            S = _patch_splits(L, Cin, Cout, self.classes[0]["npix"])
+            S = _patch_splits(L, dM, Cout, self.classes[0]["npix"])
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
@@ -435,6 +439,7 @@ class _ConvPlan:
         # (2 * Cout * K * output pixels -- FlopCounterMode's count).  Reflect-padded layers LAUNCH over the
         # padded domain; every launch is credited with its share of the forward count, not with the padded volume.
         self.fwd_flops = 2.0 * Cout * self.K * N * osp
+        self.dgrad_flops = self.fwd_flops * dM / Cin
         self.dgrad_work = float(sum(c["taps"] * c["npix"] for c in self.classes)) or 1.0
         # ---- class batching: the stride parity classes of a k % s == 0 conv share every dimension (same taps per
         # class, same Q extents) and differ only in weights, tap table and output origin -> ONE launch
@@ -473,11 +478,12 @@ class _ConvPlan:
                 self.dgrad_splits = SB
 
 
-def _plan(x, w, stride, pad, reflect):
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index, _conv_bf16)
+def _plan(x, w, stride, pad, reflect, dgrad_rows=None):
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index, _conv_bf16, dgrad_rows)
     pl = _geom_cache.get(key)
     if pl is None:
-        pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device, _conv_bf16)
+        pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device, _conv_bf16,
+                                          dgrad_rows)
         if _conv_bf16:                     # geom[34] = operand precision, read by c2m_conv_igemm / c2m_conv_wgrad
             pl.fwd_geom[34] = pl.wg_geom[34] = 1
             for c in pl.classes:
@@ -534,10 +540,10 @@ def _packed(w, frozen, kind, build):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, reflect, act):
+    def forward(ctx, x, w, b, stride, pad, reflect, act, dgrad_rows=None):
         _dev(x, w, b)
         x, w = _f(x), _f(w)
-        pl = _plan(x, w, stride, pad, reflect)
+        pl = _plan(x, w, stride, pad, reflect, dgrad_rows)
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
         ctx.frozen_w = not ctx.needs_input_grad[1]
@@ -614,7 +620,7 @@ class _ConvFn(torch.autograd.Function):
                     tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
                            pl.reflect, S)
                     _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
-                                      pl.fwd_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
+                                      pl.dgrad_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
                                       lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
                                                                None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
                                                                _stream()), tag,
@@ -632,7 +638,7 @@ class _ConvFn(torch.autograd.Function):
                     w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
                         w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
-                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.fwd_flops * c["taps"] * c["npix"] / pl.dgrad_work,
+                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
                                   lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
                                                            _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
                                   4 * (gy.numel() + w.numel() + x.numel()) // len(pl.classes)), "conv_igemm dgrad")
@@ -644,6 +650,8 @@ class _ConvFn(torch.autograd.Function):
                 fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
                 _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
                            "reflect fold")
+            if pl.dM < Cin:
+                gx[:, pl.dM:].zero_()            # channels declared gradient-free by the caller (dgrad_rows)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad:
             S = pl.wino_wg_splits
             slab = torch.empty((S + 1) * 16 * Cout * Cin, device=x.device, dtype=torch.float32)
@@ -667,11 +675,13 @@ class _ConvFn(torch.autograd.Function):
                                                        _gp(pl.wg_geom), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None):
-    """conv2d (4-D x) / conv3d (5-D x) with zero or reflect padding folded into the gather; bias + activation fused."""
+def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgrad_channels=None):
+    """conv2d (4-D x) / conv3d (5-D x) with zero or reflect padding folded into the gather; bias + activation fused.
+    dgrad_channels: the caller guarantees that only x[:, :dgrad_channels] needs a gradient (x is a concatenation whose tail
+    carries no grad); the data gradient of the tail is returned as zeros instead of being computed."""
     nd = x.dim() - 2
     stride3, pad3 = _triple(stride, nd), _pad3(padding, nd)
     reflect = padding_mode == "reflect" and any(pad3)
@@ -684,8 +694,8 @@ def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None):
     k = _chunks_for_2gib(x.shape, w.shape, stride3, pad3)
     if k > 1:
         size = _cdiv(n, k)
-        return torch.cat([_ConvFn.apply(xc, w, b, stride3, pad3, reflect, act) for xc in x.split(size)], 0)
-    return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act)
+        return torch.cat([_ConvFn.apply(xc, w, b, stride3, pad3, reflect, act, dgrad_channels) for xc in x.split(size)], 0)
+    return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act, dgrad_channels)
 
 
 _MAX_TENSOR_BYTES = int(0.9 * 2 ** 31)      # 10 % margin: the Winograd data gradient rounds its padded domain up to whole tiles

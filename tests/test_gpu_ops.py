@@ -617,3 +617,24 @@ def test_conv_batch_chunking_for_tensors_over_2gib(case, monkeypatch):
     with pytest.raises(ValueError):
         monkeypatch.setattr(ops, "_MAX_TENSOR_BYTES", 1024)
         ops.conv(g(x), g(w), None, stride=stride, padding=pad, padding_mode=mode)
+
+
+@pytest.mark.parametrize("shape,cout,k,pad,mode", [((2, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), "reflect"),
+                                                   ((3, 20, 12, 24), 16, (3, 3), 1, "zeros")])
+def test_conv_dgrad_channels_skips_the_gradient_free_tail(shape, cout, k, pad, mode):
+    """final_fuse's input is cat([features (32), rastered sparse motion (2, no grad)]): with dgrad_channels the data
+    gradient is computed for the leading channels only (a 32-row GEMM instead of 34 rows on a 64-row tile) and must equal
+    the leading channels of the full data gradient; the tail comes back as zeros; the weight gradient is unaffected."""
+    keep = shape[1] - 2
+    x, w = rnd(31, *shape), rnd(32, cout, shape[1], *k, scale=0.1)
+    go = None
+    res = []
+    for dc in (None, keep):
+        xg, wg = g(x).requires_grad_(True), g(w).requires_grad_(True)
+        y = ops.conv(xg, wg, None, stride=1, padding=pad, padding_mode=mode, dgrad_channels=dc)
+        go = g(rnd(33, *y.shape)) if go is None else go
+        (y * go).sum().backward()
+        res.append((y.detach(), xg.grad, wg.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    rel_close(res[1][1][:, :keep], res[0][1][:, :keep], 1e-6, "leading channels of the data gradient")
+    assert float(res[1][1][:, keep:].abs().max()) == 0.0
