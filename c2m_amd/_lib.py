@@ -21,6 +21,8 @@ _SIGS = {
     "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
     "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
     "c2m_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "c2m_pack_weights_bf16_patch_bytes": (c_long, [c_int, c_int]),
+    "c2m_pack_weights_bf16_patch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "c2m_wino_upack_floats": (c_long, [c_int, c_int]),
     "c2m_wino_filter_transform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "c2m_conv_wino": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),

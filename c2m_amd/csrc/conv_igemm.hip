@@ -578,6 +578,271 @@ static int launch_patch(const ConvP& p, int splits, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ LDS patch, bf16
+// The bf16 form of the kernel above (BASELINE configs[2-4]): v_mfma_f32_32x32x16_bf16 is 16x the fp32 MFMA rate, so the
+// kernel lives or dies by operand delivery.  Per 16-channel chunk
+//   * the (8+2) x 34 input patch is gathered ONCE from the fp32 NCHW activations (24 coalesced dword loads per thread),
+//     rounded to bf16 (RNE) in registers and stored as [pixel][16 channels] (32 B per pixel): the B fragment of ANY of the
+//     9 taps is then one conflict-free ds_read_b128 at a pixel offset -- no per-tap gather, no per-tap conversion;
+//   * the weights arrive pre-packed in bf16 as [chunk][tap][row][16 channels] (c2m_pack_weights_bf16_patch): one 16-byte
+//     load + one ds_write_b128 per 512 MACs of MFMA work, and the A fragment is one ds_read_b128;
+//   * one barrier per chunk (72 MFMAs per wave at BM = 128), next chunk's global loads in flight during the MFMAs.
+// Tile: BM output channels x (8 rows x 32 columns); wave w owns rows 2w, 2w+1 for all BM channels (MI = BM/32, NI = 2).
+template <int BM>
+__global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) {
+    constexpr int TR = 8, PH = TR + 2, PW = 34, NPIX = PH * PW;           // 340 patch pixels
+    constexpr int MI = BM / 32, NI = 2;
+    constexpr int A_UNITS = 9 * BM * 2;                                    // 16-byte units per chunk: [tap][half][row]
+    constexpr int APT = (A_UNITS + 255) / 256;
+    // LDS: double-buffered weight image + patch (73.7 + 21.8 KB at BM = 128: one workgroup per CU, one barrier per chunk;
+    // a single-buffered weight image with two workgroups per CU and two barriers per chunk measured 20 % slower).
+    // Both images keep the two 8-channel halves in separate planes ([half][pixel], [tap][half][row]): the 32 lanes of a
+    // ds_read_b128 half-wave then read 512 contiguous bytes (interleaved halves were a 2-way bank conflict on every read).
+    __shared__ uint4 sA[2][A_UNITS];
+    __shared__ uint4 sP[2][NPIX * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM;
+    const int tiles_x = (p.Wo + 31) / 32, tiles_y = (p.Ho + TR - 1) / TR;
+    int tb = blockIdx.x;
+    const int tx = tb % tiles_x; tb /= tiles_x;
+    const int ty = tb % tiles_y; const int img = tb / tiles_y;            // img = n*To + ot (2-D planes)
+    const int oy0 = ty * TR, ox0 = tx * 32;
+    const int n_img = img / p.To, t_img = img % p.To;
+
+    // ---- patch gather: three rounds of (pixel, 8-channel half); the half is wave-uniform in every round
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const unsigned img_byte = (unsigned)(n_img * (int)p.in_sn + t_img * (int)p.in_st) * 4u;
+    const int ppix[3] = {tid, tid, 256 + (tid & 127)};
+    const int phalf[3] = {0, 1, wave >> 1};
+    unsigned pvo[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int e = ppix[r];
+        const int row = e / PW, col = e % PW;
+        int iy = oy0 + p.iy0 + row, ix = ox0 + p.ix0 + col;
+        bool ok = e < NPIX;
+        if (p.reflect) {
+            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+        }
+        ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        pvo[r] = ok ? img_byte + (unsigned)(iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
+    }
+    struct Stage { float pv[3][8]; };
+    auto fetch_patch = [&](int chunk, float (&pv)[3][8]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // channels beyond Cin only meet zero weights (the packed rows are zero-padded); they read finite data or 0
+                const int soff = (chunk * 16 + phalf[r] * 8 + j) * p.in_sc * 4;
+                pv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvo[r], soff, 0));
+            }
+    };
+    auto stash_patch = [&](int buf, const float (&pv)[3][8]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            bf16x8 q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = (__bf16)pv[r][j];
+            if (r < 2 || ppix[r] < NPIX) sP[buf][phalf[r] * NPIX + ppix[r]] = __builtin_bit_cast(uint4, q);
+        }
+    };
+    // ---- weights: global [chunk][tap][Mpad rows][2 halves] 16-byte units -> LDS [tap][half][row]
+    const uint4* __restrict__ Ab = reinterpret_cast<const uint4*>(p.A);
+    const long mpad2 = (long)p.lda * 2;                                    // lda = padded row count of the packed matrix
+    long aoff[APT];
+    int adst[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int u = tid + i * 256;
+        const int tap = u / (BM * 2), rem = u % (BM * 2);
+        aoff[i] = (long)tap * mpad2 + (long)m0 * 2 + rem;
+        adst[i] = (tap * 2 + (rem & 1)) * BM + (rem >> 1);
+    }
+    auto fetch_a = [&](int chunk, uint4 (&av)[APT]) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i)
+            if (A_UNITS % 256 == 0 || tid + i * 256 < A_UNITS) av[i] = Ab[(long)chunk * 9 * mpad2 + aoff[i]];
+    };
+    auto stash_a = [&](int buf, const uint4 (&av)[APT]) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i)
+            if (A_UNITS % 256 == 0 || tid + i * 256 < A_UNITS) sA[buf][adst[i]] = av[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int pbase[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pbase[j] = (lane >> 5) * NPIX + (wave * NI + j) * PW + (lane & 31);
+    const int abase = (lane >> 5) * BM + (lane & 31);
+
+    const int chunk_beg = blockIdx.z * p.ksteps_per_split;
+    int chunk_end = chunk_beg + p.ksteps_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
+    // The activation gather (HBM / Infinity Cache) runs TWO chunks ahead of its LDS store (two register sets): one chunk of
+    // MFMAs (~1.1 us) does not cover its loaded latency (~2.2 us per chunk with every CU fetching at once).  The weight
+    // image comes from L2 and runs one chunk ahead (a second set of 36 registers would not fit the 256 VGPRs).
+    Stage s0, s1;
+    uint4 av[APT];
+    const int nck = chunk_end - chunk_beg;
+    fetch_a(chunk_beg, av);
+    fetch_patch(chunk_beg, s0.pv);
+    stash_a(0, av);
+    stash_patch(0, s0.pv);
+    __syncthreads();
+    // vmcnt retires in order: the weight loads of chunk c+1 are issued BEFORE the patch loads of chunk c+2 / c+3, so
+    // waiting for them at the end of chunk c leaves the deep patch loads in flight
+    if (nck > 1) fetch_patch(chunk_beg + 1, s0.pv);
+    if (nck > 1) fetch_a(chunk_beg + 1, av);
+    if (nck > 2) fetch_patch(chunk_beg + 2, s1.pv);
+    // fragments are read one tap ahead of the MFMAs that use them (two register sets): with one wave per SIMD nothing else
+    // hides the LDS latency -- reading them right before use left the matrix pipe idle for most of every tap
+    struct Frag { bf16x8 a[MI], b[NI]; };
+    auto read_frag = [&](int buf, int tap, Frag& f) {
+        const int toff = p.pty[tap / 3] * PW + p.ptx[tap % 3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) f.a[i] = __builtin_bit_cast(bf16x8, sA[buf][tap * 2 * BM + i * 32 + abase]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) f.b[j] = __builtin_bit_cast(bf16x8, sP[buf][pbase[j] + toff]);
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NPAIR = MI * NI < MI + NI ? MI * NI : MI + NI;
+    int cur = 0;
+    Frag f0, f1;
+    read_frag(0, 0, f0);
+#define PB_TAP(T, FC, FN)                                                          \
+        read_frag(cur, (T) + 1, FN);                                               \
+        mma(FC);                                                                   \
+        _Pragma("unroll") for (int g_ = 0; g_ < NPAIR; ++g_) {                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+        }                                                                          \
+        if (MI * NI > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - NPAIR, 0);   \
+        if (MI + NI > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI - NPAIR, 0);   \
+        __builtin_amdgcn_sched_barrier(0);
+    // one chunk: 9 taps from buffer cur; then the staged next chunk (set SC) goes to buffer cur ^ 1 and SC is refilled
+    // with the chunk after next + 1
+#define PB_CHUNK(SC)                                                               \
+    do {                                                                           \
+        PB_TAP(0, f0, f1) PB_TAP(1, f1, f0) PB_TAP(2, f0, f1) PB_TAP(3, f1, f0)    \
+        PB_TAP(4, f0, f1) PB_TAP(5, f1, f0) PB_TAP(6, f0, f1) PB_TAP(7, f1, f0)    \
+        mma(f0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        if (chunk + 1 < chunk_end) { stash_a(cur ^ 1, av); stash_patch(cur ^ 1, SC.pv); }   \
+        __syncthreads();                                                           \
+        if (chunk + 2 < chunk_end) fetch_a(chunk + 2, av);                         \
+        if (chunk + 3 < chunk_end) fetch_patch(chunk + 3, SC.pv);                  \
+        cur ^= 1;                                                                  \
+        read_frag(cur, 0, f0);                                                     \
+        ++chunk;                                                                   \
+    } while (0)
+    int chunk = chunk_beg;
+    while (chunk < chunk_end) {
+        PB_CHUNK(s0);
+        if (chunk < chunk_end) PB_CHUNK(s1);
+    }
+#undef PB_CHUNK
+#undef PB_TAP
+
+    // ---- epilogue (same mapping as the fp32 patch kernel)
+    const bool direct = gridDim.z == 1;
+    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
+    // Vector path: a dword store per accumulator register (128 per wave) is store-ISSUE bound (~5 B/clk/CU: 27k cycles for
+    // the 128 KB tile against 37k cycles of MFMAs at Cin = 256).  The tile goes through LDS instead (the weight buffers are
+    // free now): [channel][64 pixels] per wave, 64 channels at a time, read back as float4 along the pixels and stored with
+    // 16-byte stores (32 per wave instead of 128), still full 128-byte row segments per channel.
+    if (!p.Y2 && p.out_sw == 1 && (p.Wo & 3) == 0 && (p.out_off & 3) == 0 && (p.out_sc & 3) == 0 && (p.out_sn & 3) == 0 &&
+        (p.slab_stride & 3) == 0 && ((uintptr_t)p.Y & 15) == 0 && BM >= 64) {
+        float* __restrict__ T = reinterpret_cast<float*>(&sA[0][0]) + wave * (64 * 64);     // 16 KB per wave
+        float* __restrict__ yimg = Yb + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st;
+#pragma unroll
+        for (int h = 0; h < MI / 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cl = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float v = acc[2 * h + q][jj][r];
+                        if (direct) {
+                            const int row = m0 + h * 64 + cl;
+                            if (p.bias && row < p.M) v += p.bias[row];
+                            v = c2m_act(v, p.act, p.slope);
+                        }
+                        T[cl * 64 + jj * 32 + (lane & 31)] = v;
+                    }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int cl = it * 4 + (lane >> 4), px = (lane & 15) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(&T[cl * 64 + px]);
+                const int row = m0 + h * 64 + cl;
+                const int oy = oy0 + wave * NI + (px >> 5), ox = ox0 + (px & 31);
+                if (row < p.M && oy < p.Ho && ox < p.Wo) {
+                    // non-temporal: the 100+ MB output would otherwise push the input patches out of L2 / Infinity Cache
+                    // while they are still being gathered (+4...12 % on the configs[2] layers)
+                    f32x4 vv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(yimg + (long)row * p.out_sc + (long)oy * p.out_sh + ox));
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int oy = oy0 + wave * NI + j, ox = ox0 + (lane & 31);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        float* __restrict__ yb = Yb + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
+                                 (long)ox * p.out_sw;
+        long row_stride = p.out_sc;
+        if (p.Y2) {
+            const int tp = t_img * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
+                      xp = ox * p.ps_x + p.po_x - p.lo_x;
+            if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+                yb = p.Y2 + (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                row_stride = p.y2_sc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) {
+                    float v = acc[i][j][r];
+                    if (direct) {
+                        if (p.bias) v += p.bias[row];
+                        v = c2m_act(v, p.act, p.slope);
+                    }
+                    yb[(long)row * row_stride] = v;
+                }
+            }
+    }
+}
+
+template <int BM>
+static int launch_patch_bf16(const ConvP& p, int splits, hipStream_t s) {
+    const long tiles = (long)(p.Npix / (p.Ho * p.Wo)) * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
+    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM), splits);
+    hipLaunchKernelGGL((conv_patch3x3_bf16_kernel<BM>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
 // out[i] = act( sum_z slab[z][i] + bias[(i / chan_stride) % M] ), fixed order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                      const float* __restrict__ bias, long total, int S, long chan_stride, int M, int act,
@@ -712,7 +977,6 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;
     if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
-        if (g[34] == 1) return (int)hipErrorInvalidValue;  // fp32 only
         if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
         p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
         for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
@@ -720,6 +984,13 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         if (p.nchunks * 9 != p.nk) return (int)hipErrorInvalidValue;
         p.ksteps_per_split = c2m_cdiv(p.nchunks, splits);           // chunks per split
         if (c2m_cdiv(p.nchunks, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;
+        if (g[34] == 1) {
+            // bf16: A = c2m_pack_weights_bf16_patch output, lda = its padded row count (a multiple of 128)
+            if (p.lda % 128 != 0 || p.lda < p.M) return (int)hipErrorInvalidValue;
+            if (p.M <= 32)      return launch_patch_bf16<32>(p, splits, s);
+            else if (p.M <= 64) return launch_patch_bf16<64>(p, splits, s);
+            else                return launch_patch_bf16<128>(p, splits, s);
+        }
         if (p.M <= 32)      return launch_patch<32, 256, 1, 4>(p, splits, s);
         else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, splits, s);
         else                return launch_patch<128, 128, 2, 2>(p, splits, s);
@@ -1889,6 +2160,43 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         const int c = chunk * CK + ch, tap = tg * NS + slot;
         orow[k] = (c < q.C && tap < taps) ? wr[c * q.s_c + toff[tap]] : 0.f;
     }
+}
+
+// bf16 weights of the bf16 LDS-patch kernel: out[chunk][tap][row (padded to Mpad)][16 channels] in bf16, RNE; rows >= M
+// and channels >= C are zero.  3x3 taps only; forward (flip = 0): tap = ky*3+kx of w[m][c][ky][kx] addressed through
+// s_m / s_c as in c2m_pack_weights; data gradient (flip = 1): the tap index is reversed (rotated filter).
+__global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint4* __restrict__ out, int M, int C, int Mpad,
+                                               long s_m, long s_c, int flip, long units) {
+    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        const int half = (int)(u & 1); long r = u >> 1;
+        const int m = (int)(r % Mpad); r /= Mpad;
+        const int tap = (int)(r % 9); const int chunk = (int)(r / 9);
+        const int st = flip ? 8 - tap : tap;
+        bf16x8 q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 16 + half * 8 + j;
+            q[j] = (__bf16)((m < M && c < C) ? w[m * s_m + c * s_c + st] : 0.f);
+        }
+        out[u] = __builtin_bit_cast(uint4, q);
+    }
+}
+
+// out: ceil(C/16) * 9 * Mpad * 32 bytes with Mpad = ceil(M/128)*128.  g[]: 0 M, 1 C, 2 s_m, 3 s_c, 4 flip.
+C2M_API long c2m_pack_weights_bf16_patch_bytes(int M, int C) {
+    return (long)c2m_cdiv(C, 16) * 9 * (c2m_cdiv(M, 128) * 128) * 32;
+}
+
+C2M_API int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, void* stream) {
+    C2M_ENTER();
+    const int M = (int)g[0], C = (int)g[1];
+    if (M <= 0 || C <= 0) return 0;
+    if ((((uintptr_t)out) & 15) != 0) return (int)hipErrorInvalidValue;
+    const int Mpad = c2m_cdiv(M, 128) * 128;
+    const long units = (long)c2m_cdiv(C, 16) * 9 * Mpad * 2;
+    hipLaunchKernelGGL(pack_weights_bf16_patch_kernel, dim3(c2m_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (uint4*)out, M, C, Mpad, (long)g[2], (long)g[3], (int)g[4], units);
+    return (int)hipGetLastError();
 }
 
 // g[]: 0 M, 1 C, 2 CK, 3 KT, 4 KH, 5 KW, 6 st, 7 sh, 8 sw, 9 s_m, 10 s_c;  out holds st*sh*sw * M rows of

@@ -213,6 +213,28 @@ def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
     return Wo >= 32 and Ho >= rows and (_ceil(Wo, 32) * _ceil(Ho, rows)) <= 1.15 * Wo * Ho
 
 
+def _patch_bf16_ok(C, stride, Ho, Wo, M):
+    """bf16 LDS-patch kernel (8 rows x 32 columns per workgroup): 3x3 stride-1.  Where it beats the bf16 gather kernel
+    (per-shape A/B of BASELINE configs[2], gpurun_out/r02/table_cfg2*.txt): deep reductions (>= 128 channels: the weight
+    image of a chunk is re-streamed per 256 pixels, which only pays with many chunks) or few output rows (<= 64), and
+    tiles that do not hang far over the (padded) domain; <= 4 output rows stay on the vector-ALU kernels."""
+    if tuple(stride) != (1, 1, 1) or M <= 4 or C < 12 or Wo < 32 or Ho < 8 or _ceil(C, 16) > 1.25 * C:
+        return False
+    fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
+    if C < 128:
+        return M <= 64 and fill <= 1.2
+    return fill <= 1.15 or (fill <= 1.4 and C >= 256)
+
+
+def _pack_bf16_patch(w, M, C, s_m, s_c):
+    """c2m_pack_weights_bf16_patch: contiguous native 3x3 weights -> bf16 [chunk][tap][Mpad][16]."""
+    L = _lib.lib()
+    out = torch.empty(L.c2m_pack_weights_bf16_patch_bytes(M, C), device=w.device, dtype=torch.uint8)
+    g = np.array([M, C, s_m, s_c, 0], dtype=np.int64)
+    _lib.check(L.c2m_pack_weights_bf16_patch(_p(w), _p(out), _gp(g), _stream()), "pack_weights_bf16_patch")
+    return out
+
+
 def _patch_splits(L, M, C, npix):
     """Split-K count for the patch kernel: whole 16-channel chunks per split, every split non-empty."""
     nch = _cdiv(C, 16)
@@ -338,7 +360,8 @@ class _ConvPlan:
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
-        if not bf16 and (kt, kh, kw) == (1, 3, 3) and _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout):
+        if (kt, kh, kw) == (1, 3, 3) and (_patch_bf16_ok(Cin, stride, Ho, Wo, Cout) if bf16 else
+                                          _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout)):
             self.fwd_patch, self.ck = True, 16
             ck = 16
         ns = 16 // ck
@@ -359,6 +382,8 @@ class _ConvPlan:
             self.fwd_geom[35] = kw                # row-major square tap set, dx ascending (thin row-blocked kernel)
         if self.fwd_patch:
             _set_patch(self.fwd_geom, -ph, -pw, (0, 1, 2), (0, 1, 2))
+            if bf16:
+                self.fwd_geom[2] = _ceil(Cout, 128)       # lda = padded row count of the bf16 weight image
         # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
         self.J = L.c2m_conv_wgrad_rows(Cout, nk + 1)
         wtab, _, _ = _kstep_table(Cin, offs, in_sc, ck, extra_groups=self.J // 16 - nk - 1, ones_group=True)
@@ -402,8 +427,9 @@ class _ConvPlan:
                     ctaps = At * Ay * Ax
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
-                    if not bf16 and (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
-                            _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, dM):
+                    if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
+                            (_patch_bf16_ok(Cout, (1, 1, 1), Qy, Qx, dM) if bf16 else
+                             _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, dM)):
                         cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
                     ctab, cnch, cntg = _kstep_table(Cout, coffs, osp, cck)
@@ -421,6 +447,8 @@ class _ConvPlan:
                         geom[35] = -Ax            # data gradient: tap offsets run q - arange(A): dx descending
                     if cpatch:
                         _set_patch(geom, qy - 2, qx - 2, (2, 1, 0), (2, 1, 0))
+                        if bf16:
+                            geom[2] = _ceil(dM, 128)
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
@@ -558,7 +586,10 @@ class _ConvFn(torch.autograd.Function):
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
             return y
-        A = _packed(w, ctx.frozen_w, ("fwd", pl.ck), lambda: _pack_native(w, Cout, Cin, pl.ck, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
+        if pl.fwd_patch and pl.bf16:
+            A = _packed(w, ctx.frozen_w, ("fwd-bf16-patch",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 9))
+        else:
+            A = _packed(w, ctx.frozen_w, ("fwd", pl.ck), lambda: _pack_native(w, Cout, Cin, pl.ck, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
         y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
         S = pl.fwd_splits
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
@@ -629,12 +660,14 @@ class _ConvFn(torch.autograd.Function):
                                "conv_igemm dgrad (batched classes)")
             kt, kh, kw = pl.dims[9:12]
             Aall = None
-            if cb is None and pl.classes_packable:      # every parity class present, equal taps: one pack launch
+            if cb is None and pl.classes_packable and not (pl.bf16 and all(c["patch"] for c in pl.classes)):
                 Aall = _packed(w, ctx.frozen_w, ("dgrad-all", pl.classes[0]["ck"], pl.stride), lambda: _pack_native(
                     w, Cin, Cout, pl.classes[0]["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
             for ci, c in enumerate(pl.classes if cb is None else ()):
                 rt, ry, rx = c["r"]
-                A = Aall[ci * Cin:] if Aall is not None else _packed(
+                A = _packed(w, ctx.frozen_w, ("dgrad-bf16-patch", pl.dM), lambda: _pack_bf16_patch(
+                    w, pl.dM, Cout, 9, Cin * 9)) if (c["patch"] and pl.bf16) else \
+                    Aall[ci * Cin:] if Aall is not None else _packed(
                     w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
                         w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
                 tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)

@@ -70,6 +70,11 @@ int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, floa
  *      9 row stride, 10 channel stride of the source (elements).  Replaces the reshape/permute/copy chain that
  *      aten::convolution does internally on its weights (no reference line of its own).                          */
 int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stream);
+/* bf16 weight image of the bf16 LDS-patch kernel (3x3 stride-1 layers in bf16 mode, BASELINE configs[2-4]):
+ * out[chunk][tap][row padded to a multiple of 128][16 channels] bf16.  g[] = {M, C, s_m, s_c, flip}; flip = 1 for the
+ * data gradient (rotated taps).  Pass the result as A to c2m_conv_igemm with geom[2] (lda) = the padded row count. */
+long c2m_pack_weights_bf16_patch_bytes(int M, int C);
+int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, void* stream);
 
 /* Winograd F(2x2,3x3) form of the 3x3 stride-1 layers (conv_wino.hip; same reference call sites as above: vgg.py:92-137,
  * spade_block.py:47-49, residual_block.py:13-71, up_block.py:9-13): 2.25x fewer MFMA FLOPs, fp32, bias/activation fused.

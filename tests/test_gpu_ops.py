@@ -60,6 +60,7 @@ CONV_CASES = [
     ((2, 4, 1, 2, 4), 4, (1, 3, 3), (1, 1, 1), (0, 1, 1), "reflect"),
     ((2, 6, 5, 6, 8), 4, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
     ((1, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
+    ((1, 40, 24, 64), 200, (3, 3), 1, 1, "reflect"),    # bf16 LDS-patch kernel: 2 row blocks of 128, padded last chunk
 ]
 
 
