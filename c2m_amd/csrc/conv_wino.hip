@@ -255,6 +255,80 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     constexpr int QS = 4 * 16 * 32 + 16;             // q stride: +16 floats keeps the two column parities on different banks
     float* __restrict__ sR = sV;                     // [q][w][16 cout][32 tiles] per pass (16 of the 64 couts)
     const int m0 = mt * 64;
+    // 16-byte stores (round 2): a thread owns FOUR consecutive x of one output row and two of the 16 output channels of a
+    // pass, so a pass is 2 store instructions per thread instead of 8 dword stores -- the store path of a CU takes ~5 B/clk
+    // in dword stores, which made the epilogue 8 % (K = 256) to 30 % (K = 64) of the kernel.
+    const bool vec_ok = (p.Wo & 3) == 0 && (p.out_sh & 3) == 0 && (p.out_sc & 3) == 0 && (p.out_sn & 3) == 0 &&
+                        (p.out_off & 3) == 0 && (((unsigned long)p.Y) & 15) == 0 &&
+                        (((unsigned long)p.Y2) & 3) == 0;
+    if (vec_ok) {
+        const int e4 = tid & 3, ey = (tid >> 2) & 7, cg = tid >> 5;
+        const int oy = oy0 + ey, ox = ox0 + 4 * e4;
+        const bool inb = oy < p.Ho && ox < p.Wo;
+        const bool top = (ey & 1) == 0;
+        // target of the 4-pixel group: all interior -> Y2, all outside the interior -> Y, straddling -> per pixel
+        int mode = 0;                                 // 0: Y (vector), 1: Y2 (vector), 2: mixed (scalar per pixel)
+        float* __restrict__ yb0 = p.Y + p.out_off + (long)img * p.out_sn + (long)oy * p.out_sh + ox;
+        long cs0 = p.out_sc;
+        float* __restrict__ yb1 = yb0;
+        long cs1 = cs0;
+        const int yi = oy - p.lo_y, xi = ox - p.lo_x;
+        if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y) {
+            const bool in0 = (unsigned)xi < (unsigned)p.ext_x, in1 = (unsigned)(xi + 1) < (unsigned)p.ext_x,
+                       in2 = (unsigned)(xi + 2) < (unsigned)p.ext_x, in3 = (unsigned)(xi + 3) < (unsigned)p.ext_x;
+            yb1 = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
+            cs1 = p.y2_sc;
+            // the interior is shifted by the pad against the padded domain, so its 16-byte stores are only dword aligned
+            // (fine for global_store_dwordx4); groups that straddle the interior's edge are stored per pixel
+            mode = (in0 && in3) ? 1 : ((in0 || in1 || in2 || in3) ? 2 : 0);
+        }
+        const int tile0 = (ey >> 1) * 8 + 2 * e4;
+        const int ro = top ? 0 : 3 * 16 * 32;        // row combined with r1, r2: r0 (top) or r3 (bottom)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = hf * 8 + rr;
+                    const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);        // 0..15 within the half
+                    sR[0 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
+                    sR[1 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int co = cg + 8 * it;
+                    const int cout = m0 + mi * 32 + hf * 16 + co;
+                    float v[4];
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const float* __restrict__ rr_ = sR + (dx & 1) * QS + co * 32 + tile0 + (dx >> 1);
+                        const float r1 = rr_[1 * 16 * 32], r2 = rr_[2 * 16 * 32], rx = rr_[ro];
+                        v[dx] = top ? (rx + r1) + r2 : (r1 - r2) - rx;
+                    }
+                    if (inb && cout < p.M) {
+                        const float bb = p.bias ? p.bias[cout] : 0.f;
+#pragma unroll
+                        for (int dx = 0; dx < 4; ++dx) v[dx] = c2m_act(v[dx] + bb, p.act, p.slope);
+                        if (mode == 2) {
+#pragma unroll
+                            for (int dx = 0; dx < 4; ++dx) {
+                                if ((unsigned)(xi + dx) < (unsigned)p.ext_x) yb1[(long)cout * cs1 + dx] = v[dx];
+                                else yb0[(long)cout * cs0 + dx] = v[dx];
+                            }
+                        } else {
+                            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                            const f32x4u vv = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4u*>((mode ? yb1 : yb0) + (long)cout * (mode ? cs1 : cs0)) = vv;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int ex = tid & 15, ey = (tid >> 4) & 7, c0 = tid >> 7;
     const int oy = oy0 + ey, ox = ox0 + ex;
     const bool inb = oy < p.Ho && ox < p.Wo;
