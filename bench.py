@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--check-grads", action="store_true",
                     help="after the run, verify that every rank holds bit-identical (all-reduced) gradients "
                          "(always on when N > 1)")
+    ap.add_argument("--graph", action="store_true",
+                    help="side measurement: capture zero_grad + forward + backward into a HIP graph and time replays (single "
+                         "GPU only; no per-kernel events, so no roofline object)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     args = ap.parse_args()
@@ -235,21 +238,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step(batch)
-    if step.reducer is not None:
-        step.reducer.reset_measurements()
-    barrier()
-    prof = None if args.no_roofline else ops.ConvProfiler()
-    t0 = time.perf_counter()
-    if prof is not None:
-        prof.__enter__()
-    for _ in range(args.steps):
-        step(batch)
-    if prof is not None:
-        prof.__exit__(None, None, None)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    import contextlib
+    if args.graph and distributed:
+        raise SystemExit("bench.py: --graph is a single-GPU side measurement")
+    gctx = torch.cuda.stream(step.graph_stream) if args.graph else contextlib.nullcontext()
+    with gctx:                                  # with --graph every step (eager warm-up included) runs on the capture stream
+        for _ in range(args.warmup):
+            step(batch)
+        if args.graph:
+            args.no_roofline = True
+            step.capture(batch)
+            step(batch)
+        if step.reducer is not None:
+            step.reducer.reset_measurements()
+        barrier()
+        prof = None if args.no_roofline else ops.ConvProfiler()
+        t0 = time.perf_counter()
+        if prof is not None:
+            prof.__enter__()
+        for _ in range(args.steps):
+            step(batch)
+        if prof is not None:
+            prof.__exit__(None, None, None)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,6 +282,7 @@ def main():
                                + "random-init weights", "global_batch": world * clips,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "rccl_ranks": world if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
+        "hip_graph": bool(args.graph),
         "achieved_tflops_algorithmic": round(tflop_per_step * world / step_s, 2),
     }
     if step.reducer is not None:

@@ -68,3 +68,16 @@ __device__ __forceinline__ float c2m_act(float v, int act, float slope) {
         default: return v;
     }
 }
+
+// Zero-fill of a workspace region as a KERNEL (grid-stride, 16-byte stores where aligned).  hipMemsetAsync becomes a memset
+// NODE when the stream is being captured into a HIP graph; a plain kernel node keeps every captured step kernel-only.
+__global__ static void c2m_zero_words_kernel(unsigned* __restrict__ p, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+static inline hipError_t c2m_zero_async(void* p, long bytes, hipStream_t s) {
+    const long n = bytes / 4;                       // workspaces are word arrays
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(c2m_zero_words_kernel, dim3(c2m_grid(n, 256)), dim3(256), 0, s, (unsigned*)p, n);
+    return hipGetLastError();
+}

@@ -233,7 +233,7 @@ C2M_API int c2m_occlusion_splat(const float* flow, long sb, long sc, long st, in
     int* cursor = offset + nimg * HW;
     int* keys = cursor + nimg * HW;
     float* vals = (float*)(keys + nimg * HW * 4);
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * nimg * HW, s);
+    hipError_t e = c2m_zero_async(count, sizeof(int) * nimg * HW, s);
     if (e != hipSuccess) return (int)e;
     SplatP p{flow, sb, sc, st, T, H, W, nimg};
     const long work = nimg * HW * 4;

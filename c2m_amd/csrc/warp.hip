@@ -303,7 +303,7 @@ C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* 
         int* keys = cursor + px;
         float* vals = (float*)(keys + px * 4);
         ws += px * 4 * 3 + px * 4 * 4 * 2;
-        hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * px, s);
+        hipError_t e = c2m_zero_async(count, sizeof(int) * px, s);
         if (e != hipSuccess) return (int)e;
         WarpInvP p{flow, occ, N, H, W};
         const int g1 = c2m_grid(px, 256);
@@ -638,7 +638,8 @@ C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, l
 // ------------------------------------------------------------------------------------------- RoIAlign
 // torchvision.ops.roi_align(aligned=False, sampling_ratio=-1) as called at appearance_encoder.py:67-69.
 // feat [N,C,H,W]; boxes [K,5] = (batch index, x1, y1, x2, y2) on the DEVICE (no host round trip for the adaptive
-// sampling grid); out [K,C,PH,PW].  Backward scatters with float atomics like torchvision's own kernel.
+// sampling grid); out [K,C,PH,PW].  torchvision's backward scatters with float atomics; ours GATHERS per feature pixel in a
+// fixed (box, sample row, sample column) order (roi_align_bwd_gather_kernel below): no atomics, bit-repeatable.
 struct RoiSample { int yl, yh, xl, xh; float w1, w2, w3, w4; bool ok; };
 
 __device__ __forceinline__ RoiSample roi_sample(float y, float x, int H, int W) {
@@ -654,10 +655,8 @@ __device__ __forceinline__ RoiSample roi_sample(float y, float x, int H, int W) 
     return s;
 }
 
-template <bool BWD>
 __global__ void roi_align_kernel(const float* __restrict__ feat, const float* __restrict__ boxes,
-                                 float* __restrict__ out_or_gfeat, const float* __restrict__ gout, int K, int C, int H,
-                                 int W, int PH, int PW, float scale) {
+                                 float* __restrict__ out_or_gfeat, int K, int C, int H, int W, int PH, int PW, float scale) {
     const long total = (long)K * C * PH * PW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int pw = (int)(i % PW); long r = i / PW;
@@ -672,27 +671,18 @@ __global__ void roi_align_kernel(const float* __restrict__ feat, const float* __
         const float cnt = fmaxf((float)(gh * gw), 1.f);
         const long plane = ((long)b * C + c) * H * W;
         float acc = 0.f;
-        const float g = BWD ? gout[i] / cnt : 0.f;
         for (int iy = 0; iy < gh; ++iy) {
             const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
             for (int ix = 0; ix < gw; ++ix) {
                 const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
                 const RoiSample s = roi_sample(y, x, H, W);
                 if (!s.ok) continue;
-                if (BWD) {
-                    float* __restrict__ gf = out_or_gfeat + plane;
-                    atomicAdd(gf + (long)s.yl * W + s.xl, g * s.w1);
-                    atomicAdd(gf + (long)s.yl * W + s.xh, g * s.w2);
-                    atomicAdd(gf + (long)s.yh * W + s.xl, g * s.w3);
-                    atomicAdd(gf + (long)s.yh * W + s.xh, g * s.w4);
-                } else {
-                    const float* __restrict__ f = feat + plane;
-                    acc += s.w1 * f[(long)s.yl * W + s.xl] + s.w2 * f[(long)s.yl * W + s.xh] +
-                           s.w3 * f[(long)s.yh * W + s.xl] + s.w4 * f[(long)s.yh * W + s.xh];
-                }
+                const float* __restrict__ f = feat + plane;
+                acc += s.w1 * f[(long)s.yl * W + s.xl] + s.w2 * f[(long)s.yl * W + s.xh] +
+                       s.w3 * f[(long)s.yh * W + s.xl] + s.w4 * f[(long)s.yh * W + s.xh];
             }
         }
-        if (!BWD) out_or_gfeat[i] = acc / cnt;
+        out_or_gfeat[i] = acc / cnt;
     }
 }
 
@@ -701,18 +691,85 @@ C2M_API int c2m_roi_align_fwd(const float* feat, const float* boxes, float* out,
     C2M_ENTER();
     const long total = (long)K * C * PH * PW;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(roi_align_kernel<false>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat,
-                       boxes, out, (const float*)nullptr, K, C, H, W, PH, PW, spatial_scale);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, boxes, out, K, C,
+                       H, W, PH, PW, spatial_scale);
     return (int)hipGetLastError();
 }
 
-// gfeat must be zero-initialised by the caller
-C2M_API int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int K, int C, int H, int W, int PH,
+// 1-D part of roi_sample for one coordinate: which of the (at most two) taps of sample coordinate v is pixel `p`, and with
+// which weight.  Returns the number of terms (0..2; 2 when the clamped taps coincide on the last pixel).
+__device__ __forceinline__ int roi_taps_1d(float v, int S, int p, float (&w)[2]) {
+    if (v < -1.0f || v > (float)S) return 0;
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= S - 1) { hi = lo = S - 1; v = (float)lo; } else hi = lo + 1;
+    const float l = v - (float)lo, h = 1.f - l;
+    int n = 0;
+    if (lo == p) w[n++] = h;
+    if (hi == p) w[n++] = l;
+    return n;
+}
+
+// d(feat)[b,c,y,x] = sum over the boxes of image b, the sample rows that touch y and the sample columns that touch x of
+// (gout[k,c,ph,pw] / count) * (wy * wx), in ascending (k, sample row, sample column) order.  One thread per feature pixel and
+// channel chunk (blockIdx.y); every element of gfeat is written (no zero-init).
+template <int CH>
+__global__ void roi_align_bwd_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ gout,
+                                            float* __restrict__ gfeat, int N, int K, int C, int H, int W, int PH, int PW,
+                                            float scale) {
+    const long total = (long)N * H * W;
+    const int c0 = blockIdx.y * CH;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); long r = i / W;
+        const int y = (int)(r % H); const int n = (int)(r / H);
+        float acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float* __restrict__ bx = boxes + (long)k * 5;
+            if ((int)bx[0] != n) continue;
+            const float x1 = bx[1] * scale, y1 = bx[2] * scale, x2 = bx[3] * scale, y2 = bx[4] * scale;
+            const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+            const float bh = rh / (float)PH, bw = rw / (float)PW;
+            const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+            const float cnt = fmaxf((float)(gh * gw), 1.f);
+            for (int ty = 0; ty < PH * gh; ++ty) {
+                const int ph = ty / gh, iy = ty - ph * gh;
+                float wy[2];
+                const int ny = roi_taps_1d(y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh, H, y, wy);
+                if (ny == 0) continue;
+                for (int tx = 0; tx < PW * gw; ++tx) {
+                    const int pw = tx / gw, ix = tx - pw * gw;
+                    float wx[2];
+                    const int nx = roi_taps_1d(x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W, x, wx);
+                    if (nx == 0) continue;
+                    const float* __restrict__ gk = gout + (((long)k * C + c0) * PH + ph) * PW + pw;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (c0 + c < C) {
+                            const float g = gk[(long)c * PH * PW] / cnt;
+                            for (int a = 0; a < ny; ++a)
+                                for (int b = 0; b < nx; ++b) acc[c] += g * (wy[a] * wx[b]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (c0 + c < C) gfeat[(((long)n * C + c0 + c) * H + y) * W + x] = acc[c];
+    }
+}
+
+// gfeat [N,C,H,W]: every element is written (no zero-initialisation needed)
+C2M_API int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int N, int K, int C, int H, int W, int PH,
                               int PW, float spatial_scale, void* stream) {
     C2M_ENTER();
-    const long total = (long)K * C * PH * PW;
-    if (total <= 0) return 0;
-    hipLaunchKernelGGL(roi_align_kernel<true>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)nullptr, boxes, gfeat, gout, K, C, H, W, PH, PW, spatial_scale);
+    const long total = (long)N * H * W;
+    if (total <= 0 || C <= 0) return 0;
+    constexpr int CH = 8;
+    dim3 grid(c2m_grid(total, 256), c2m_cdiv(C, CH));
+    hipLaunchKernelGGL((roi_align_bwd_gather_kernel<CH>), grid, dim3(256), 0, (hipStream_t)stream, boxes, gout, gfeat, N, K,
+                       C, H, W, PH, PW, spatial_scale);
     return (int)hipGetLastError();
 }

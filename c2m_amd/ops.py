@@ -922,8 +922,8 @@ class _RoiAlignFn(torch.autograd.Function):
     def backward(ctx, gout):
         (boxes,) = ctx.saved_tensors
         N, C, H, W, K, ph, pw, scale = ctx.cfg
-        gfeat = torch.zeros(N, C, H, W, device=gout.device, dtype=torch.float32)
-        _lib.check(_lib.lib().c2m_roi_align_bwd(_p(boxes), _p(_f(gout)), _p(gfeat), K, C, H, W, ph, pw, scale, _stream()),
+        gfeat = torch.empty(N, C, H, W, device=gout.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_roi_align_bwd(_p(boxes), _p(_f(gout)), _p(gfeat), N, K, C, H, W, ph, pw, scale, _stream()),
                    "roi_align_bwd")
         return gfeat, None, None, None, None
 

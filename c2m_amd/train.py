@@ -43,6 +43,49 @@ class TrainStep:
         self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb, buffers=list(c2m.buffers()),
                                        force_collectives=force_collectives, measure=measure_comm) if distributed else None
 
+    # ---- HIP-graph replay of zero_grad + forward + backward (single GPU, static batch) ---------------------------------------
+    def capture(self, data, warmup=3):
+        """Capture one update WITHOUT the optimizer steps into a HIP graph for the static batch `data`; afterwards
+        `__call__(data)` with the same object replays the graph (one launch instead of ~1200) and then runs the optimizers
+        eagerly (their bias-correction scalars are host-computed kernel arguments and change every step).
+
+        New data for a captured step must be copied INTO the tensors of `data` (static addresses).  Not available with the
+        gradient reducer: its RCCL launches would have to be captured too.  Everything on the captured path is kernel nodes
+        only: the one hipMemsetAsync per splat / warp-inversion of round 1 was a memset NODE whose replay faulted ("write
+        access to a read-only page" on the second replay, ROCm 7.2) and is a zero-fill kernel now; the reference's NaN
+        checks (host syncs) are deferred to after the replay (`utils.check_deferred_nan`)."""
+        if self.reducer is not None:
+            raise RuntimeError("TrainStep.capture: graph capture of the RCCL gradient reducer is not supported")
+        dev = next(self.c2m.parameters()).device
+        # An AccumulateGrad node lives on the stream it was created on and stays alive while ANY autograd graph refers to it
+        # (nn.utils.spectral_norm, for one, keeps `module.weight = weight_orig / sigma` -- a tensor with grad_fn -- from one
+        # forward to the next).  After eager steps on ANOTHER stream the capture would need cross-stream syncs, which are
+        # illegal while capturing (segfault in capture_end on ROCm 7.2).  So: run every eager step that precedes a capture
+        # under `with torch.cuda.stream(step.graph_stream)` (bench.py --graph does), or capture before the first eager step.
+        side = self.graph_stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        run_opt, self.run_optimizers = self.run_optimizers, False
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                       # plans, caches and allocator state settle outside the capture
+                    self._eager(data)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                outputs = self._eager(data)
+        finally:
+            self.run_optimizers = run_opt
+        self._graph, self._graph_data, self._graph_out = graph, data, outputs
+        return self
+
+    @property
+    def graph_stream(self):
+        """The (non-default) stream captures are recorded on; eager steps that precede a capture must run on it too."""
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream(device=next(self.c2m.parameters()).device)
+        return self._graph_stream
+
     def zero_grad(self):
         if self.reducer is not None:
             self.reducer.zero_grad()
@@ -52,6 +95,15 @@ class TrainStep:
 
     def __call__(self, data):
         """One update; returns (generated dict, generator loss dict incl. total_gen, D loss dict)."""
+        if getattr(self, "_graph", None) is not None and data is self._graph_data:
+            self._graph.replay()
+            if self.run_optimizers:
+                for o in self.optimizers:
+                    o.step()
+            return self._graph_out
+        return self._eager(data)
+
+    def _eager(self, data):
         self.zero_grad()
         generated, loss_g, loss_d_img, loss_d_vid = self.c2m(data)
         total = None

@@ -48,11 +48,25 @@ def resize_video(video, scale_factor, mode="nearest", is_flow=False):
     return _unfold(F.interpolate(flat, size=size, mode=mode), t)
 
 
+_deferred_nan_checks = []
+
+
 def isnan(x, input_tensor=None):
-    """Raises ValueError on NaN like the reference (utils.py:375-379) -- one host sync per call."""
+    """Raises ValueError on NaN like the reference (utils.py:375-379) -- one host sync per call.  While the current stream is
+    being captured into a HIP graph a host sync is illegal: the check is deferred (`check_deferred_nan()` after the replay)."""
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        _deferred_nan_checks.append((x, input_tensor))
+        return x
     if torch.any(torch.isnan(x)):
         raise ValueError(f"Value is nan {x}, input tensor is {input_tensor}")
     return x
+
+
+def check_deferred_nan():
+    """NaN checks registered during a graph capture, evaluated on the graph's (static) output tensors after a replay."""
+    for x, input_tensor in _deferred_nan_checks:
+        if torch.any(torch.isnan(x)):
+            raise ValueError(f"Value is nan {x}, input tensor is {input_tensor}")
 
 
 def get_rank():

@@ -134,11 +134,12 @@ int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, in
 int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
 int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
 /* torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), appearance_encoder/appearance_encoder.py:67-69.
- * boxes [K,5] = (batch, x1, y1, x2, y2) stay on the device; the backward needs a zeroed gfeat (float atomics).   */
+ * boxes [K,5] = (batch, x1, y1, x2, y2) stay on the device; the backward gathers per feature pixel in a fixed order (no
+ * float atomics, no zero-initialisation of gfeat [N,C,H,W]).                                                       */
 int c2m_roi_align_fwd(const float* feat, const float* boxes, float* out, int K, int C, int H, int W, int PH, int PW,
                       float spatial_scale, void* stream);
-int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int K, int C, int H, int W, int PH, int PW,
-                      float spatial_scale, void* stream);
+int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int N, int K, int C, int H, int W, int PH,
+                      int PW, float spatial_scale, void* stream);
 /* VGG-19 max pools (layers/vgg.py, torchvision features 4/9/18/27).                                           */
 int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
 int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
