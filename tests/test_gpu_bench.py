@@ -73,3 +73,27 @@ def test_two_rank_rehearsal_on_one_gpu_gradients_identical():
     assert r["n_gpus"] == 2 and r["value"] > 0 and "bit-identical" in r["grad_sync"] and "2 rank" in r["grad_sync"]
     assert r["allreduce_bytes_per_step"] > 4e8
     assert r["config"]["global_batch"] == 2 and r["config"]["parallelism"] == "dp2"
+
+
+@pytest.mark.parametrize("config,expect", [(2, ("256x512", "bf16", "full adversarial")), (3, ("128x256", "bf16", "full adversarial")),
+                                           (4, ("256x512", "2 windows", "full adversarial"))])
+def test_bench_baseline_config_presets(config, expect):
+    """`--config K` runs BASELINE.json configs[K] (here at batch 1 to stay short): resolution, bf16 conv mode, both
+    discriminators + the four Adam steps, and for configs[4] two 7-frame windows per stream sample."""
+    out = subprocess.run([sys.executable, "bench.py", "--config", str(config), "--batch", "1", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    assert r["dtype"] == "bf16" and r["value"] > 0 and f"configs[{config}]" in r["config"]["workload"]
+    for frag in expect:
+        assert frag in r["config"]["workload"], (frag, r["config"]["workload"])
+    assert r["config"]["global_batch"] == (2 if config == 4 else 1)
+    assert r["roofline"]["peak"] == 2500.0 and 0 < r["roofline"]["frac"] < 1
+
+
+def test_bench_graph_side_measurement():
+    out = subprocess.run([sys.executable, "bench.py", "--graph", "--batch", "1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    assert r["hip_graph"] is True and r["value"] > 0 and "roofline" not in r
