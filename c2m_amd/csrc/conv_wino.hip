@@ -16,6 +16,7 @@
 // combination (over j) happens in registers, the row combination (over i = waves) through LDS in the epilogue, which also
 // applies bias + activation and writes coalesced NCHW rows.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -505,16 +506,20 @@ constexpr int GY_STRIDE = GR * GC + 4;               // 36: dY patch [co][2][16]
 constexpr int GX_COLS = GC + 8;                      // 24: image columns ox0-4 .. ox0+19 as six aligned 16-B units
 constexpr int GX_STRIDE = 4 * GX_COLS + 4;           // 100: X patch [ci][4][24] + 4 pad
 constexpr int GY_UNITS = 64 * GR * (GC / 4) / 256;   // 2 float4 per thread and chunk
-constexpr int GX_UNITS = 64 * 4 * (GX_COLS / 4) / 256;   // 6
 
-__global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
+// NI = 32-wide input-channel tiles per workgroup: NI = 2 -> 64 x 64 channels, 256 accumulator registers, one workgroup per
+// CU; NI = 1 -> 64 x 32 channels, 128 accumulators, two workgroups per CU (their barriers / refills / epilogues overlap).
+template <int NI>
+__global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(const WinoWgP p) {
+    constexpr int NCI = 32 * NI;
+    constexpr int GX_UNITS = NCI * 4 * (GX_COLS / 4) / 256;        // 6 (NI = 2) / 3 float4 per thread and chunk
     __shared__ float pY[2][64 * GY_STRIDE];
-    __shared__ float pX[2][64 * GX_STRIDE];
+    __shared__ float pX[2][NCI * GX_STRIDE];
     __shared__ float sDb[2 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
-    const int m0 = mt * 64, c0 = nt * 64;
+    const int m0 = mt * 64, c0 = nt * NCI;
     const int HW = p.H * p.W;
     const int rbeg = split * p.per_split;
     int rend = rbeg + p.per_split; rend = rend < p.regions ? rend : p.regions;
@@ -601,20 +606,20 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     const int xoff_a = cl * GX_STRIDE + ra * GX_COLS + 2 * kl + 2;  // + q * 32 * GX_STRIDE + 4 * ks
     const int xoff_b = cl * GX_STRIDE + rb * GX_COLS + 2 * kl + 2;
 
-    f32x16 acc[4][2][2];
+    f32x16 acc[4][2][NI];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][mi][ni][r] = 0.f;
     float dbacc[2] = {0.f, 0.f};
     const bool want_db = nt == 0 && wave == 0;                      // wave-uniform
 
-    struct Raw { float2 y0[2], y1[2]; float2 a0[2], a1[2], a2[2], b0[2], b1[2], b2[2]; };
-    struct Frag { float a[2][4], b[2][4]; };
+    struct Raw { float2 y0[2], y1[2]; float2 a0[NI], a1[NI], a2[NI], b0[NI], b1[NI], b2[NI]; };
+    struct Frag { float a[2][4], b[NI][4]; };
     auto load_raw = [&](int buf, int ks, Raw& r) {
         const float* __restrict__ py = &pY[buf][0];
         const float* __restrict__ px = &pX[buf][0];
@@ -623,6 +628,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             const int yo = yoff + q * 32 * GY_STRIDE + 4 * ks;
             r.y0[q] = *reinterpret_cast<const float2*>(py + yo);
             r.y1[q] = *reinterpret_cast<const float2*>(py + yo + GC);
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
             const int xa_ = xoff_a + q * 32 * GX_STRIDE + 4 * ks, xb_ = xoff_b + q * 32 * GX_STRIDE + 4 * ks;
             r.a0[q] = *reinterpret_cast<const float2*>(px + xa_);
             r.a1[q] = *reinterpret_cast<const float2*>(px + xa_ + 2);
@@ -638,6 +646,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
             if (count_db) dbacc[q] += (r.y0[q].x + r.y0[q].y) + (r.y1[q].x + r.y1[q].y);
             const float t0 = fmaf(yb_c, r.y1[q].x, ya_c * r.y0[q].x), t1 = fmaf(yb_c, r.y1[q].y, ya_c * r.y0[q].y);
             f.a[q][0] = t0; f.a[q][1] = t0 + t1; f.a[q][2] = t0 - t1; f.a[q][3] = -t1;
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
             const float x0 = fmaf(xs_c, r.b0[q].y, r.a0[q].y), x1 = fmaf(xs_c, r.b1[q].x, r.a1[q].x);
             const float x2 = fmaf(xs_c, r.b1[q].y, r.a1[q].y), x3 = fmaf(xs_c, r.b2[q].x, r.a2[q].x);
             f.b[q][0] = x0 - x2; f.b[q][1] = x1 + x2; f.b[q][2] = x2 - x1; f.b[q][3] = x1 - x3;
@@ -649,13 +660,23 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[j][mi][ni], 0, 0, 0);
     };
     // One software-pipelined k-step: the 16 MFMAs of step g run on the fragments prepared during step g-1 while the raw
     // values of step g+1 are read (first MFMA gaps) and transformed (later gaps).  16 ds_read_b64 + ~34 VALU per 16 MFMAs.
 // scheduling pipeline of one k-step (A/B on the bench layers: +2...4 % over the compiler's own order): first MFMA, the 16
 // raw reads of the next step, then the transform VALU spread over the remaining MFMA gaps
+#define WG_SCHED1                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #ifndef WG_NO_SGB
 #define WG_SCHED                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
@@ -676,7 +697,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
         load_raw(RBUF, RKS, rw);                                                  \
         mma(FCUR);                                                                \
         transform(rw, FNEXT, DB);                                                 \
-        WG_SCHED                                                                  \
+        if constexpr (NI == 2) { WG_SCHED } else { WG_SCHED1 }                    \
         __builtin_amdgcn_sched_barrier(0);                                        \
     } while (0)
 
@@ -706,6 +727,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     }
 #undef WG_STEP
 #undef WG_SCHED
+#undef WG_SCHED1
     // ---- slab [split][xi][ci][co]: co innermost, so the four consecutive rows a lane holds in acc[..][4g .. 4g+3] are
     // one 16-byte store (a dword store per accumulator register made the 256 KB epilogue store-issue bound)
     float* __restrict__ out = p.slab + (long)split * 16 * p.M * p.K;
@@ -714,7 +736,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const WinoWgP p) {
     for (int j = 0; j < 4; ++j) {
         const int xi = 4 * wave + j;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const int ci = c0 + ni * 32 + (lane & 31);
             if (ci >= p.K) continue;
             float* __restrict__ col = out + ((long)xi * p.K + ci) * p.M;
@@ -797,10 +819,21 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ usum, const f
 
 // Number of region splits the launch will use.  The caller provides slab = (S + 1)*16*M*K floats (S partial slabs + the
 // summed one) and dbslab = S*M floats.
+// input-channel tile of the launch: 64 (NI = 2, one workgroup per CU) or 32 (NI = 1, two per CU)
+static int wino_wg_ni(int M, int K) {
+    const char* force = getenv("C2M_WINO_WG_NI");                  // A/B hook (tools/ab_wino_wgrad.py, tests)
+    if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
+    (void)M; (void)K;
+    // A/B on the bench layers (one box, tools/ab_wino_wgrad.py): the 64 x 32 tile with two workgroups per CU is 8...13 %
+    // faster than the 64 x 64 tile with one (152-182 vs 138-163 algorithmic TF/s) on every eligible shape
+    return 1;
+}
+
 C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long regions = (long)nimg * (H / GR) * (W / GC);
-    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 64);
-    long S = 256 / tiles;                       // one workgroup per CU (256 accumulator registers): one resident round
+    const int ni = wino_wg_ni(M, K);
+    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 32 * ni);
+    long S = (ni == 1 ? 512 : 256) / tiles;     // one resident round: 256 CUs x (1 | 2) workgroups
     if (S < 1) S = 1;
     const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
     if (S > maxS) S = maxS;
@@ -825,9 +858,11 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     p.regions = nimg * (H / GR) * (W / GC);
     const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
     p.per_split = c2m_cdiv(p.regions, S);
-    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 64));
+    const int ni = wino_wg_ni(M, K);
+    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 32 * ni));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wino_wgrad_kernel, grid, dim3(256), 0, s, p);
+    if (ni == 1) hipLaunchKernelGGL(conv_wino_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
+    else         hipLaunchKernelGGL(conv_wino_wgrad_kernel<2>, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long n = 16L * M * K;

@@ -332,10 +332,10 @@ class _ConvPlan:
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
-            wg_tiles = _cdiv(Cin, 64) * _cdiv(Cout, 64)
+            wg_tiles = _cdiv(Cin, 32) * _cdiv(Cout, 64)           # workgroup tile: 64 output x 32 input channels
             if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
-                    _WINO_WGRAD == "auto" and wg_tiles >= 2 and 4096 * wg_tiles <= 1.35 * Cin * Cout
-                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 256 // wg_tiles))):
+                    _WINO_WGRAD == "auto" and wg_tiles >= 4 and 2048 * wg_tiles <= 1.35 * Cin * Cout
+                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 512 // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
