@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) b[kk][j] = sB[cur][krow][wn * TN + j * 32 + (lane & 31)];
             }
+#ifdef C2M_IGEMM_SERIAL_FRAGS
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
@@ -347,6 +349,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             }
+#ifndef C2M_IGEMM_SERIAL_FRAGS
+            // fragment reads two k-pairs ahead of the MFMAs that use them: only the first reads of a K-step are waited for
+            {
+                constexpr int NMF = (BK / 2) * MI * NI, RPM = (MI + NI + MI * NI - 1) / (MI * NI);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+                for (int g = 0; g < NMF; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_tile(cur ^ 1);

@@ -51,6 +51,20 @@ constexpr int CKW = 8;                       // channels per chunk
 constexpr int PELEMS = CKW * PH * PW;        // 1440
 constexpr int PLOADS = (PELEMS + 255) / 256; // 6
 
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// v_pk_add_f32 with operand swizzles: p = (x0, x1), q = (x2, x3)
+static __device__ __forceinline__ f32x2 pk_a(f32x2 p, f32x2 q) {       // (x0 - x2, x1 + x2)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(p), "v"(q));
+    return d;
+}
+static __device__ __forceinline__ f32x2 pk_b(f32x2 p, f32x2 q) {       // (x2 - x1, x1 - x3)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(q));
+    return d;
+}
+
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     __shared__ float sP[3][PLOADS * 256];           // input patch [k][PH][PW], filled by LDS-DMA two chunks ahead
     __shared__ float sV[2 * 16 * CKW * 32];         // V[buf][xi][k][tile] (double buffered); reused by the epilogue
@@ -107,6 +121,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     // 1 KB contiguous (per-lane-contiguous 128-byte records made the texture addresser the bottleneck: 64 lines per load)
     const float* __restrict__ ubase = p.U + (((long)mt * 4 + wave) * 8 * 64 + lane) * 4;
     const long ustride = (long)p.mtiles * 4 * 64 * 32;      // floats per chunk
+    const unsigned long uaddr = (unsigned long)p.U;
+    const u32x4 urs = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+    const unsigned uvo = (unsigned)((((mt * 4 + wave) * 8 * 64) + lane) * 16);
     f32x4 ua[8];
     auto load_u = [&](int chunk) {
         const f32x4* __restrict__ q = reinterpret_cast<const f32x4*>(ubase + chunk * ustride);
@@ -185,7 +202,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 b[j][kk] = sV[cur * (16 * CKW * 32) + ((4 * wave + j) * CKW + 2 * kk + (lane >> 5)) * 32 + (lane & 31)];
-        const float* q = ubase + (more ? chunk + 1 : chunk) * ustride;
+        // U(chunk + 1) by buffer loads: one VGPR offset for all eight, the chunk in the scalar offset, i * 1 KB as the
+        // immediate -- a global_load needs a 64-bit VALU add per address, and tools/micro/mfma_issue.hip prices a VALU
+        // between MFMAs at 2.5 ... 5 MFMA-pipe cycles and a global load above a buffer load
+        const int usoff0 = (int)((more ? chunk + 1 : chunk) * ustride * 4), usoff1 = usoff0 + 4096;
         auto mfma_pair = [&](int g) {                  // g = kk * 4 + j
             const int kk = g >> 2, j = g & 3;
 #pragma unroll
@@ -200,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
             mfma_pair(g);
 #pragma unroll
             for (int i = 2 * g; i < 2 * g + 2; ++i)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(unext[i]) : "v"(q + i * 256) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                             : "=&v"(unext[i]) : "v"(uvo), "s"(urs), "s"(i < 4 ? usoff0 : usoff1), "n"((i & 3) * 1024) : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         // patch(chunk + 2) -- always issued, so the iteration is one basic block and the requests sit between MFMAs; past
@@ -220,17 +241,50 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        float d[4][4];
-        read_d(pnext, d);                               // (last chunk: stale but in-bounds data, result unused)
+        // Input transform of chunk + 1 (unconditional: one basic block; last chunk: stale but in-bounds data, result unused)
+        // in packed fp32: V = B^T d B is 32 adds, i.e. 16 v_pk_add_f32 -- the row part needs the op_sel / neg forms the
+        // compiler does not emit, hence pk_a / pk_b.  A VALU between MFMAs costs 2.5 ... 5 matrix-pipe cycles
+        // (tools/micro/mfma_issue.hip), and in each gap the LDS writes of the previous row go first: a VALU behind an MFMA
+        // waits for the pipe and holds back what is queued behind it, an LDS instruction does not.
+        f32x2 dr[4][2];
 #pragma unroll
-        for (int g = 4 + PLOADS / 2; g < 16; ++g) mfma_pair(g);
-        transform_store(d, cur ^ 1);                    // unconditional: one basic block, so it can interleave
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int g = 0; g < 9; ++g) {                  // 2 MFMA : 4 VALU : 2 LDS writes (18 MFMAs)
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            for (int h = 0; h < 2; ++h) dr[a][h] = *reinterpret_cast<const f32x2*>(&sP[pnext][pbase + a * PW + 2 * h]);
+        float* __restrict__ vdst = sV + (cur ^ 1) * (16 * CKW * 32) + tk * 32 + tn;
+        f32x2 xr_[4][2], o01, o23;
+        auto row = [&](int i) {
+            o01 = pk_a(xr_[i][0], xr_[i][1]);          // (x0 - x2, x1 + x2)
+            o23 = pk_b(xr_[i][0], xr_[i][1]);          // (x2 - x1, x1 - x3)
+        };
+        auto put = [&](int i) {
+            vdst[(4 * i + 0) * CKW * 32] = o01.x; vdst[(4 * i + 1) * CKW * 32] = o01.y;
+            vdst[(4 * i + 2) * CKW * 32] = o23.x; vdst[(4 * i + 3) * CKW * 32] = o23.y;
+        };
+        static_assert(4 + PLOADS / 2 == 7, "nine MFMA pairs are left for the transform");
+        mfma_pair(7);
+        xr_[0][0] = dr[0][0] - dr[2][0]; xr_[0][1] = dr[0][1] - dr[2][1];
+        xr_[1][0] = dr[1][0] + dr[2][0]; xr_[1][1] = dr[1][1] + dr[2][1];
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(8);
+        xr_[2][0] = dr[2][0] - dr[1][0]; xr_[2][1] = dr[2][1] - dr[1][1];
+        xr_[3][0] = dr[1][0] - dr[3][0]; xr_[3][1] = dr[1][1] - dr[3][1];
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(9);
+        row(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            mfma_pair(9 + i);
+            put(i - 1);
+            row(i);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        mfma_pair(13);
+        put(3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(14);
+        mfma_pair(15);
         // the 8 U loads are older than the 6 DMA loads issued after them
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #pragma unroll
@@ -837,6 +891,7 @@ C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     if (S < 1) S = 1;
     const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
     if (S > maxS) S = maxS;
+    if (const char* f = getenv("C2M_WINO_WG_SPLITS")) { const long v = atol(f); if (v > 0) S = v < regions ? v : regions; }
     if (S < 1) S = 1;
     const long per = (regions + S - 1) / S;
     return (int)((regions + per - 1) / per);
