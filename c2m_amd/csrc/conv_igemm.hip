@@ -532,7 +532,6 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) b[kk][j] = sP[pcur][pbase[j] + kk * 2 * PCH + toff];
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
@@ -540,6 +539,15 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            {   // fragment reads two k-pairs ahead of their MFMAs (only the first reads of a tap are waited for)
+                constexpr int NMF = (BK / 2) * MI * NI, RPM = (MI + NI + MI * NI - 1) / (MI * NI);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+#pragma unroll
+                for (int g = 0; g < NMF; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) store_a(cur ^ 1);
             __syncthreads();

@@ -48,8 +48,9 @@ struct WinoP {
 constexpr int WR = 8, WC = 16;               // output region rows / cols
 constexpr int PH = WR + 2, PW = WC + 2;      // input patch
 constexpr int CKW = 8;                       // channels per chunk
-constexpr int PELEMS = CKW * PH * PW;        // 1440
-constexpr int PLOADS = (PELEMS + 255) / 256; // 6
+constexpr int PPOS = PH * PW;                // 180 patch positions per channel: thread tid < 180 owns position tid
+constexpr int PCS = 192;                     // channel stride of the patch in LDS = three 64-lane DMA rows
+constexpr int PBUF = CKW * PCS;              // one patch buffer
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -66,7 +67,7 @@ static __device__ __forceinline__ f32x2 pk_b(f32x2 p, f32x2 q) {       // (x2 - 
 }
 
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
-    __shared__ float sP[3][PLOADS * 256];           // input patch [k][PH][PW], filled by LDS-DMA two chunks ahead
+    __shared__ float sP[3][PBUF];                   // input patch [k][PH][PW] (+pad), filled by LDS-DMA two chunks ahead
     __shared__ float sV[2 * 16 * CKW * 32];         // V[buf][xi][k][tile] (double buffered); reused by the epilogue
 #ifdef WINO_OCC1
     __shared__ float sDummy[20000];
@@ -81,21 +82,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     const int oy0 = ry * WR, ox0 = rx * WC;
     const int mt = blockIdx.y;
 
-    // ---- patch addresses of this thread (fixed over the K loop)
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    // ---- patch addresses of this thread (fixed over the K loop).  A chunk's patch is 8 channels x 3 DMA rows of 64 patch
+    // positions (180 used); wave w fetches the three rows of channels 2w and 2w + 1, so a lane owns the three positions
+    // lane, 64 + lane, 128 + lane and the channel rides in the scalar offset of the DMA: the reflect / bounds arithmetic
+    // is done for 3 addresses per thread instead of 6 (and no div / mod by the channel size); a VALU next to the MFMAs of
+    // the other resident workgroup costs 2.5 ... 5 matrix-pipe cycles (tools/micro/mfma_issue.hip).
     const unsigned img_byte = (unsigned)(img * (int)p.in_sn) * 4u;
-    unsigned pvo[PLOADS];
+    unsigned pvo[3];
 #pragma unroll
-    for (int i = 0; i < PLOADS; ++i) {
-        const int e = tid + i * 256;
-        const int k = e / (PH * PW), r = (e % (PH * PW)) / PW, c = e % PW;
+    for (int sg = 0; sg < 3; ++sg) {
+        const int pos = sg * 64 + lane;
+        const int r = pos / PW, c = pos % PW;
         int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + c;
         if (p.reflect) {
             iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
             ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
         }
-        const bool ok = e < PELEMS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        pvo[i] = ok ? img_byte + (unsigned)(k * p.in_sc + iy * p.in_sh + ix) * 4u : WINO_OOB;
+        const bool ok = pos < PPOS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        pvo[sg] = ok ? img_byte + (unsigned)(iy * p.in_sh + ix) * 4u : WINO_OOB;
     }
     // The LDS-DMA is issued through inline asm and TWO chunks ahead (three patch buffers).  hipcc makes the first MFMA
     // after an LDS-DMA wait until every VMEM operation older than the U-fragment loads has completed; with the builtin and
@@ -107,15 +111,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     const unsigned long xaddr = (unsigned long)p.X;
     const u32x4 rs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
     const unsigned sp_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&sP[0][0];
+    // DMA row j = 0..5 of this wave: channel 2 * wave + j / 3, positions 64 * (j % 3) + lane -> 64 consecutive floats of
+    // sP[buf][k].  The scalar offset is outside the hardware's range check, so a channel beyond K (last chunk) gets zero
+    // records instead (every lane reads 0)
+    auto dma_row = [&](int chunk, int j, int buf, bool live) {
+        const int k = 2 * wave + j / 3, sg = j % 3;
+        const int ch = chunk * CKW + k;
+        u32x4 rsk = rs;
+        rsk[2] = (live && ch < p.K) ? p.x_bytes : 0u;
+        const unsigned dst = sp_lds + (unsigned)((buf * PBUF + k * PCS + sg * 64) * 4);
+        const int soff = ch * p.in_sc * 4;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                     :: "s"(dst), "v"(pvo[sg]), "s"(rsk), "s"(soff) : "memory");
+    };
     auto load_patch = [&](int chunk, int buf) {
-        // channels beyond K only meet zero filter coefficients; beyond the tensor they read 0
-        const int soff = chunk * CKW * p.in_sc * 4;
 #pragma unroll
-        for (int i = 0; i < PLOADS; ++i) {
-            const unsigned dst = sp_lds + (unsigned)((buf * PLOADS * 256 + wave * 64 + i * 256) * 4);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(pvo[i]), "s"(rs), "s"(soff) : "memory");
-        }
+        for (int j = 0; j < 6; ++j) dma_row(chunk, j, buf, true);
     };
     // ---- U fragments: 8 float4 per lane and chunk, [i = j*2 + mi][lane][kk 0..3]: every load instruction of a wave reads
     // 1 KB contiguous (per-lane-contiguous 128-byte records made the texture addresser the bottleneck: 64 lines per load)
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     // input-transform role of this thread: tile n (ty, tx), channel k of the chunk
     const int tn = tid & 31, tk = tid >> 5;
     const int ty = tn >> 3, tx = tn & 7;
-    const int pbase = tk * (PH * PW) + (2 * ty) * PW + 2 * tx;
+    const int pbase = tk * PCS + (2 * ty) * PW + 2 * tx;
     // V = B^T d B of this thread's (channel, tile) from patch buffer `pb` into V buffer `vb`
     auto read_d = [&](int pb, float (&d)[4][4]) {
 #pragma unroll
@@ -225,20 +236,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // patch(chunk + 2) -- always issued, so the iteration is one basic block and the requests sit between MFMAs; past
-        // the last chunk every lane's offset is out of range (the loads return 0 into a patch buffer nobody reads)
+        // the last chunk they carry zero records (the loads return 0 into a patch buffer nobody reads)
         const bool pre = chunk + 2 < p.nchunks;
-        const int soff = pre ? (chunk + 2) * CKW * p.in_sc * 4 : 0;
         const int dbuf = pnext == 2 ? 0 : pnext + 1;
 #pragma unroll
-        for (int g = 4; g < 4 + PLOADS / 2; ++g) {
+        for (int g = 4; g < 7; ++g) {
             mfma_pair(g);
-#pragma unroll
-            for (int i = 2 * (g - 4); i < 2 * (g - 4) + 2; ++i) {
-                const unsigned dst = sp_lds + (unsigned)((dbuf * PLOADS * 256 + wave * 64 + i * 256) * 4);
-                const unsigned vo = pre ? pvo[i] : WINO_OOB;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
-            }
+            dma_row(chunk + 2, 2 * (g - 4), dbuf, pre);
+            dma_row(chunk + 2, 2 * (g - 4) + 1, dbuf, pre);
             __builtin_amdgcn_sched_barrier(0);
         }
         // Input transform of chunk + 1 (unconditional: one basic block; last chunk: stale but in-bounds data, result unused)
@@ -261,7 +266,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
             vdst[(4 * i + 0) * CKW * 32] = o01.x; vdst[(4 * i + 1) * CKW * 32] = o01.y;
             vdst[(4 * i + 2) * CKW * 32] = o23.x; vdst[(4 * i + 3) * CKW * 32] = o23.y;
         };
-        static_assert(4 + PLOADS / 2 == 7, "nine MFMA pairs are left for the transform");
         mfma_pair(7);
         xr_[0][0] = dr[0][0] - dr[2][0]; xr_[0][1] = dr[0][1] - dr[2][1];
         xr_[1][0] = dr[1][0] + dr[2][0]; xr_[1][1] = dr[1][1] + dr[2][1];
@@ -299,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     }
     if (chunk < p.nchunks) iteration(chunk, ua, ub);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) DMAs of the last iterations must not outlive the block's LDS
-    static_assert(PLOADS == 6, "the DMA issue slots assume six patch loads per thread");
     __syncthreads();
 
     // ---- inverse transform.  Column part in registers: R_i[q] = sum_j M[i][j] A[j][q], A = [[1,0],[1,1],[1,-1],[0,-1]]
