@@ -559,20 +559,30 @@ struct WinoWgP {
 };
 
 constexpr int GR = 2, GC = 16, GT = 8;               // region rows, cols, tiles (one chunk: 4 k-steps of 2 tiles)
-constexpr int GY_STRIDE = GR * GC + 4;               // 36: dY patch [co][2][16] + 4 pad (16-B units stay aligned)
-constexpr int GX_COLS = GC + 8;                      // 24: image columns ox0-4 .. ox0+19 as six aligned 16-B units
-constexpr int GX_STRIDE = 4 * GX_COLS + 4;           // 100: X patch [ci][4][24] + 4 pad
+// LDS patches.  Lane (cl = lane & 31, kl = lane >> 5) reads float2 at [cl * stride + even offset]: with stride / 2 odd the
+// 32 lanes of a ds_read_b64 pass hit 32 distinct bank pairs (strides 36 / 100 of the first version: lanes cl and cl + 16
+// collided on every read).
+constexpr int GY_STRIDE = GR * GC + 2;               // 34: dY patch [co][2][16] + 2 pad
+constexpr int GX_COLS = GC + 4;                      // 20: image columns ox0-1 .. ox0+18 as five 16-byte units (4-B aligned)
+constexpr int GX_STRIDE = 4 * GX_COLS + 6;           // 86: X patch [ci][4][20] + 6 pad
 constexpr int GY_UNITS = 64 * GR * (GC / 4) / 256;   // 2 float4 per thread and chunk
+
+// v_pk_add_f32 form the compiler does not emit: (t.x + t.y, t.x - t.y)
+static __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 t) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(t));
+    return d;
+}
 
 // NI = 32-wide input-channel tiles per workgroup: NI = 2 -> 64 x 64 channels, 256 accumulator registers, one workgroup per
 // CU; NI = 1 -> 64 x 32 channels, 128 accumulators, two workgroups per CU (their barriers / refills / epilogues overlap).
 template <int NI>
 __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(const WinoWgP p) {
     constexpr int NCI = 32 * NI;
-    constexpr int GX_UNITS = NCI * 4 * (GX_COLS / 4) / 256;        // 6 (NI = 2) / 3 float4 per thread and chunk
+    constexpr int GX_TOTAL = NCI * 4 * (GX_COLS / 4);              // 640 (NI = 1) / 1280 units per chunk
+    constexpr int GX_UNITS = (GX_TOTAL + 255) / 256;               // 3 / 5 float4 per thread and chunk
     __shared__ float pY[2][64 * GY_STRIDE];
     __shared__ float pX[2][NCI * GX_STRIDE];
-    __shared__ float sDb[2 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
@@ -586,12 +596,21 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
 
-    // Raw patches are fetched as aligned 16-byte units into registers one chunk ahead and stored with ds_write_b128
-    // (an LDS-DMA piece costs the issuing wave 60-185 cycles and these waves are MFMA-issue bound; 8 plain loads + 8 LDS
-    // stores per chunk cost it ~200).  dY unit u = tid + i*256: (co, row, quarter).  X unit: (ci, r, q), r = input rows
-    // oy0-1 .. oy0+2, q = columns ox0-4+4q ..: the halo columns ox0-1 and ox0+16 are element 3 of unit 0 and element 0 of
-    // unit 5.  At the left / right image edge those two units are loaded from the neighbouring inside unit and the
-    // reflected element (x[1] resp. x[W-2]) is moved into place in registers; zero padding loads out of range (= 0).
+    // Raw patches are fetched as 16-byte units into registers one chunk ahead and stored with ds_write_b64 pairs (an
+    // LDS-DMA piece costs the issuing wave 60-185 cycles and these waves are MFMA-issue bound).
+    // dY unit u = tid + i*256: (co, row, quarter), 16-byte aligned.
+    // X unit u: (ci, r, q): input row oy0-1+r, image columns ox0-1+4q .. ox0+2+4q (4-byte aligned loads), so the patch
+    // column j of tile t is local column 2t + j: every lane reads its four values as two aligned float2.  The unit's
+    // offset relative to the region origin is a per-thread constant (xbase), the origin is wave-uniform (roff, SALU): per
+    // chunk a unit costs ONE VALU add.  Padding only matters in regions at the image border (wave-uniform flags):
+    //   rows    r = 0 / r = 3 of a top / bottom region: reflect -> two rows inwards (rowfix), zeros -> out of range
+    //   column  -1 (element 0 of unit q = 0, left region): the unit is loaded 4 bytes higher (columns 0..3; a 16-byte access
+    //           that starts in front of the tensor would be out of range as a whole) and shifted in registers:
+    //           (column 1 | 0, column 0, 1, 2)
+    //   column  W (element 1 of unit q = 4, right region): the unit is loaded 12 bytes lower (columns W-4..W-1) and turned
+    //           round in registers: (W-1, W-2 | 0)
+    // The first version redid the reflect / bounds arithmetic per unit and chunk: ~45 VALU next to 32 MFMAs, and a VALU
+    // costs 2.5 ... 5 matrix-pipe cycles (tools/micro/mfma_issue.hip).
     unsigned yvo[GY_UNITS]; int ydst[GY_UNITS];
 #pragma unroll
     for (int i = 0; i < GY_UNITS; ++i) {
@@ -600,16 +619,21 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         yvo[i] = m0 + co < p.M ? (unsigned)((m0 + co) * HW + row * p.W + q * 4) * 4u : WINO_OOB;
         ydst[i] = co * GY_STRIDE + row * GC + q * 4;
     }
-    int xch[GX_UNITS], xr[GX_UNITS], xq[GX_UNITS], xdst[GX_UNITS];
+    unsigned xbase[GX_UNITS]; int xdst[GX_UNITS], rowfix[GX_UNITS], cfix[GX_UNITS];
 #pragma unroll
     for (int i = 0; i < GX_UNITS; ++i) {
         const int u = tid + i * 256;
-        const int ci = u / 24, rem = u % 24;
-        xr[i] = rem / 6; xq[i] = rem % 6;
-        xch[i] = c0 + ci < p.K ? (c0 + ci) * HW : -1;
-        xdst[i] = ci * GX_STRIDE + xr[i] * GX_COLS + xq[i] * 4;
+        const int ci = u / 20, rem = u % 20;
+        const int r = rem / 5, q = rem % 5;
+        const bool live = u < GX_TOTAL && c0 + ci < p.K;
+        xbase[i] = live ? (unsigned)(((c0 + ci) * HW + (r - 1) * p.W + 4 * q - 1) * 4) : WINO_OOB;
+        rowfix[i] = !live ? 0 : (r == 0 ? 2 * p.W * 4 : (r == 3 ? -2 * p.W * 4 : 0));
+        cfix[i] = !live ? 0 : (q == 0 ? 4 : (q == 4 ? -12 : 0));       // > 0: holds column -1;  < 0: holds column W
+        xdst[i] = u < GX_TOTAL ? ci * GX_STRIDE + r * GX_COLS + q * 4 : -1;
     }
     f32x4 gy[GY_UNITS], gx[GX_UNITS];
+    float dbacc[GY_UNITS] = {};
+    const bool want_db = nt == 0;                                   // workgroup-uniform
     auto fetch = [&](int region) {
         const int rx = region % regions_x; int t = region / regions_x;
         const int ry = t % regions_y; const int img = t / regions_y;
@@ -618,33 +642,57 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
 #pragma unroll
         for (int i = 0; i < GY_UNITS; ++i)
             gy[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, yvo[i], ysoff, 0));
-        const unsigned ximg = (unsigned)((long)img * p.x_sn * 4);
+        const unsigned roff = (unsigned)(((long)img * p.x_sn + (long)oy0 * p.W + ox0) * 4);
+        const bool top = ry == 0, bot = ry == regions_y - 1, left = rx == 0, right = rx == regions_x - 1; // wave-uniform
 #pragma unroll
         for (int i = 0; i < GX_UNITS; ++i) {
-            int iy = oy0 - 1 + xr[i], ix = ox0 - 4 + 4 * xq[i];
-            bool ok = xch[i] >= 0;
+            unsigned vo = xbase[i] + roff;
+            if (left) vo += (unsigned)(cfix[i] > 0 ? cfix[i] : 0);
+            if (right) vo += (unsigned)(cfix[i] < 0 ? cfix[i] : 0);
             if (p.reflect) {
-                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
-                ix = ix < 0 ? 0 : ix; ix = ix >= p.W ? p.W - 4 : ix;          // edge halo: neighbouring inside unit
+                if (top) vo += (unsigned)(rowfix[i] > 0 ? rowfix[i] : 0);
+                if (bot) vo += (unsigned)(rowfix[i] < 0 ? rowfix[i] : 0);
             } else {
-                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                if (top) vo = rowfix[i] > 0 ? WINO_OOB : vo;
+                if (bot) vo = rowfix[i] < 0 ? WINO_OOB : vo;
             }
-            const unsigned vo = ok ? ximg + (unsigned)(xch[i] + iy * p.W + ix) * 4u : WINO_OOB;
-            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
-            gx[i] = v;
+            gx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
         }
     };
     auto stash = [&](int region, int buf) {
         const int rx = region % regions_x;
-        const bool left = p.reflect && rx == 0, right = p.reflect && rx == regions_x - 1;     // wave-uniform
+        const bool left = rx == 0, right = rx == regions_x - 1;                                            // wave-uniform
 #pragma unroll
-        for (int i = 0; i < GY_UNITS; ++i) *reinterpret_cast<f32x4*>(&pY[buf][ydst[i]]) = gy[i];
+        for (int i = 0; i < GY_UNITS; ++i) {
+            float* __restrict__ d = &pY[buf][ydst[i]];
+            *reinterpret_cast<float2*>(d) = float2{gy[i][0], gy[i][1]};
+            *reinterpret_cast<float2*>(d + 2) = float2{gy[i][2], gy[i][3]};
+        }
+        // bias gradient: the plain sum of dY.  Each thread stages the same two output channels in every chunk, so it sums
+        // its own 16-byte units here (input-channel tile 0 only) and the eight threads of a channel are combined once at
+        // the end -- inside the k-steps the sum cost every wave ~30 VALU per step (if-converted, never skipped)
+        if (want_db) {
+#pragma unroll
+            for (int i = 0; i < GY_UNITS; ++i) dbacc[i] += (gy[i][0] + gy[i][1]) + (gy[i][2] + gy[i][3]);
+        }
 #pragma unroll
         for (int i = 0; i < GX_UNITS; ++i) {
             f32x4 v = gx[i];
-            if (left && xq[i] == 0) v[3] = v[1];            // column -1 -> column 1 (unit holds columns 0..3)
-            if (right && xq[i] == 5) v[0] = v[2];           // column W -> column W-2 (unit holds columns W-4..W-1)
-            *reinterpret_cast<f32x4*>(&pX[buf][xdst[i]]) = v;
+            if (left) {
+                const bool e = cfix[i] > 0;             // loaded columns 0..3 -> (column -1, 0, 1, 2)
+                const f32x4 w = {p.reflect ? v[1] : 0.f, v[0], v[1], v[2]};
+                v[0] = e ? w[0] : v[0]; v[1] = e ? w[1] : v[1]; v[2] = e ? w[2] : v[2]; v[3] = e ? w[3] : v[3];
+            }
+            if (right) {
+                const bool e = cfix[i] < 0;             // loaded columns W-4..W-1 -> (column W-1, W, ..)
+                const float w0 = v[3], w1 = p.reflect ? v[2] : 0.f;
+                v[0] = e ? w0 : v[0]; v[1] = e ? w1 : v[1];
+            }
+            if (GX_TOTAL % 256 == 0 || xdst[i] >= 0) {
+                float* __restrict__ d = &pX[buf][xdst[i]];
+                *reinterpret_cast<float2*>(d) = float2{v[0], v[1]};
+                *reinterpret_cast<float2*>(d + 2) = float2{v[2], v[3]};
+            }
         }
     };
 
@@ -658,10 +706,8 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     const float xs_c = wave == 1 ? 1.f : -1.f;
     const int cl = lane & 31, kl = lane >> 5;
     const int yoff = cl * GY_STRIDE + 2 * kl;                       // + q * 32 * GY_STRIDE + 4 * ks (+ GC for row 1)
-    // patch column 2t+j (j = 0..3; patch column 0 = image column ox0-1) = local column 2t+3+j: read the three aligned
-    // pairs from local column 2t+2 and use elements 1..4
-    const int xoff_a = cl * GX_STRIDE + ra * GX_COLS + 2 * kl + 2;  // + q * 32 * GX_STRIDE + 4 * ks
-    const int xoff_b = cl * GX_STRIDE + rb * GX_COLS + 2 * kl + 2;
+    const int xoff_a = cl * GX_STRIDE + ra * GX_COLS + 2 * kl;      // + q * 32 * GX_STRIDE + 4 * ks: local column 2t, t = 2ks + kl
+    const int xoff_b = cl * GX_STRIDE + rb * GX_COLS + 2 * kl;
 
     f32x16 acc[4][2][NI];
 #pragma unroll
@@ -672,89 +718,91 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][mi][ni][r] = 0.f;
-    float dbacc[2] = {0.f, 0.f};
-    const bool want_db = nt == 0 && wave == 0;                      // wave-uniform
 
-    struct Raw { float2 y0[2], y1[2]; float2 a0[NI], a1[NI], a2[NI], b0[NI], b1[NI], b2[NI]; };
+    struct Raw { f32x2 y0[2], y1[2]; f32x2 a0[NI], a1[NI], b0[NI], b1[NI]; };
     struct Frag { float a[2][4], b[NI][4]; };
     auto load_raw = [&](int buf, int ks, Raw& r) {
+#ifdef WG_DIAG_NOLDS        // timing diagnostics only: no LDS reads
+        {
+            const f32x2 c = {1.f + ks, 2.f + buf};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { r.y0[q] = c; r.y1[q] = c; }
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { r.a0[q] = c; r.a1[q] = c; r.b0[q] = c; r.b1[q] = c; }
+            return;
+        }
+#endif
         const float* __restrict__ py = &pY[buf][0];
         const float* __restrict__ px = &pX[buf][0];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int yo = yoff + q * 32 * GY_STRIDE + 4 * ks;
-            r.y0[q] = *reinterpret_cast<const float2*>(py + yo);
-            r.y1[q] = *reinterpret_cast<const float2*>(py + yo + GC);
+            r.y0[q] = *reinterpret_cast<const f32x2*>(py + yo);
+            r.y1[q] = *reinterpret_cast<const f32x2*>(py + yo + GC);
         }
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int xa_ = xoff_a + q * 32 * GX_STRIDE + 4 * ks, xb_ = xoff_b + q * 32 * GX_STRIDE + 4 * ks;
-            r.a0[q] = *reinterpret_cast<const float2*>(px + xa_);
-            r.a1[q] = *reinterpret_cast<const float2*>(px + xa_ + 2);
-            r.a2[q] = *reinterpret_cast<const float2*>(px + xa_ + 4);
-            r.b0[q] = *reinterpret_cast<const float2*>(px + xb_);
-            r.b1[q] = *reinterpret_cast<const float2*>(px + xb_ + 2);
-            r.b2[q] = *reinterpret_cast<const float2*>(px + xb_ + 4);
+            r.a0[q] = *reinterpret_cast<const f32x2*>(px + xa_);
+            r.a1[q] = *reinterpret_cast<const f32x2*>(px + xa_ + 2);
+            r.b0[q] = *reinterpret_cast<const f32x2*>(px + xb_);
+            r.b1[q] = *reinterpret_cast<const f32x2*>(px + xb_ + 2);
         }
     };
-    auto transform = [&](const Raw& r, Frag& f, bool count_db) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (count_db) dbacc[q] += (r.y0[q].x + r.y0[q].y) + (r.y1[q].x + r.y1[q].y);
-            const float t0 = fmaf(yb_c, r.y1[q].x, ya_c * r.y0[q].x), t1 = fmaf(yb_c, r.y1[q].y, ya_c * r.y0[q].y);
-            f.a[q][0] = t0; f.a[q][1] = t0 + t1; f.a[q][2] = t0 - t1; f.a[q][3] = -t1;
-        }
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const float x0 = fmaf(xs_c, r.b0[q].y, r.a0[q].y), x1 = fmaf(xs_c, r.b1[q].x, r.a1[q].x);
-            const float x2 = fmaf(xs_c, r.b1[q].y, r.a1[q].y), x3 = fmaf(xs_c, r.b2[q].x, r.a2[q].x);
-            f.b[q][0] = x0 - x2; f.b[q][1] = x1 + x2; f.b[q][2] = x2 - x1; f.b[q][3] = x1 - x3;
-        }
-    };
-    auto mma = [&](const Frag& f) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[j][mi][ni], 0, 0, 0);
-    };
-    // One software-pipelined k-step: the 16 MFMAs of step g run on the fragments prepared during step g-1 while the raw
-    // values of step g+1 are read (first MFMA gaps) and transformed (later gaps).  16 ds_read_b64 + ~34 VALU per 16 MFMAs.
-// scheduling pipeline of one k-step (A/B on the bench layers: +2...4 % over the compiler's own order): first MFMA, the 16
-// raw reads of the next step, then the transform VALU spread over the remaining MFMA gaps
-#define WG_SCHED1                                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#ifndef WG_NO_SGB
-#define WG_SCHED                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#else
-#define WG_SCHED
+    // Transforms in packed fp32 (the first version: 22 scalar VALU per k-step at NI = 1):
+    //   dY: t = ya * row0 + yb * row1, then (t0, t0 + t1, t0 - t1, -t1)
+    //   X:  (x0, x1) = a0 + xs * b0, (x2, x3) = a1 + xs * b1, then (x0 - x2, x1 + x2, x2 - x1, x1 - x3)
+    auto transform_y = [&](const Raw& r, Frag& f, int q) {
+#ifdef WG_DIAG_NOXFORM      // timing diagnostics only (wrong results)
+        f.a[q][0] = r.y0[q].x; f.a[q][1] = r.y0[q].y; f.a[q][2] = r.y1[q].x; f.a[q][3] = r.y1[q].y;
+        return;
 #endif
-#define WG_STEP(RBUF, RKS, FCUR, FNEXT, DB)                                      \
+        const f32x2 t = ya_c * r.y0[q] + yb_c * r.y1[q];
+        const f32x2 sd = pk_sum_diff(t);
+        f.a[q][0] = t.x; f.a[q][1] = sd.x; f.a[q][2] = sd.y; f.a[q][3] = -t.y;
+    };
+    auto transform_x = [&](const Raw& r, Frag& f, int q) {
+#ifdef WG_DIAG_NOXFORM
+        f.b[q][0] = r.a0[q].x; f.b[q][1] = r.a0[q].y; f.b[q][2] = r.b1[q].x; f.b[q][3] = r.b1[q].y;
+        return;
+#endif
+        const f32x2 x01 = r.a0[q] + xs_c * r.b0[q], x23 = r.a1[q] + xs_c * r.b1[q];
+        const f32x2 o01 = pk_a(x01, x23), o23 = pk_b(x01, x23);
+        f.b[q][0] = o01.x; f.b[q][1] = o01.y; f.b[q][2] = o23.x; f.b[q][3] = o23.y;
+    };
+    auto transform = [&](const Raw& r, Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) transform_y(r, f, q);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) transform_x(r, f, q);
+    };
+    auto mma_j = [&](const Frag& f, int j) {           // the 2 * NI MFMAs of frequency column j
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[j][mi][ni], 0, 0, 0);
+    };
+    // One k-step: the MFMAs of step g on the fragments prepared during step g-1, the transform of step g+1 from raw
+    // values READ DURING STEP g-1, and the raw reads of step g+2.  The order inside the step is pinned (sched_barrier),
+    // since the packed forms are inline asm the scheduler cannot classify: after each MFMA group the LDS reads first (they
+    // do not hold up the in-order wave), VALU last -- a VALU behind an MFMA waits for the matrix pipe and delays
+    // everything queued behind it (tools/micro/mfma_issue.hip).
+#define WG_STEP(RBUF, RKS, FCUR, FNEXT)                                          \
     do {                                                                          \
-        Raw rw;                                                                   \
-        load_raw(RBUF, RKS, rw);                                                  \
-        mma(FCUR);                                                                \
-        transform(rw, FNEXT, DB);                                                 \
-        if constexpr (NI == 2) { WG_SCHED } else { WG_SCHED1 }                    \
+        Raw rn;                                                                   \
+        mma_j(FCUR, 0);                                                           \
+        load_raw(RBUF, RKS, rn);                                                  \
+        transform_y(rw, FNEXT, 0);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        mma_j(FCUR, 1);                                                           \
+        transform_y(rw, FNEXT, 1);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        mma_j(FCUR, 2);                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < NI; ++q_) transform_x(rw, FNEXT, q_); \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        mma_j(FCUR, 3);                                                           \
+        rw = rn;                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                        \
     } while (0)
 
@@ -763,28 +811,31 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         stash(rbeg, 0);
         __syncthreads();
         Frag fa, fb;
-        {
-            Raw rw;
-            load_raw(0, 0, rw);
-            transform(rw, fa, want_db);
-        }
+        Raw rw;
+        load_raw(0, 0, rw);
+        transform(rw, fa);
+        load_raw(0, 1, rw);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int cur = chunk & 1;
             const bool more = chunk + 1 < nchunks;
+#ifndef WG_DIAG_NOFETCH
             if (more) fetch(rbeg + chunk + 1);               // lands during k-steps 0 and 1
-            WG_STEP(cur, 1, fa, fb, want_db);                // MFMAs of k-step 0
-            WG_STEP(cur, 2, fb, fa, want_db);                // k-step 1
-            WG_STEP(cur, 3, fa, fb, want_db);                // k-step 2: the last raw reads of buffer cur are issued here,
+#endif
+            WG_STEP(cur, 2, fa, fb);                         // MFMAs of k-step 0, transform of 1, raw reads of 2
+            WG_STEP(cur, 3, fb, fa);                         // k-step 1: the last raw reads of buffer cur are issued here,
+#ifndef WG_DIAG_NOFETCH
             if (more) stash(rbeg + chunk + 1, cur ^ 1);      // before the barrier; buffer cur ^ 1 was last read before the
+#endif
+#ifndef WG_DIAG_NOBAR
             __syncthreads();                                 // previous barrier
-            // k-step 3 + the first raw values of the next chunk (last chunk: stale LDS data, transformed and dropped --
-            // keeps the accumulators out of a conditional path)
-            WG_STEP(cur ^ 1, 0, fb, fa, want_db && more);
+#endif
+            // k-steps 2 and 3 + the first two raw sets of the next chunk (last chunk: stale LDS data, transformed and
+            // dropped -- keeps the accumulators out of a conditional path)
+            WG_STEP(cur ^ 1, 0, fa, fb);
+            WG_STEP(cur ^ 1, 1, fb, fa);
         }
     }
 #undef WG_STEP
-#undef WG_SCHED
-#undef WG_SCHED1
     // ---- slab [split][xi][ci][co]: co innermost, so the four consecutive rows a lane holds in acc[..][4g .. 4g+3] are
     // one 16-byte store (a dword store per accumulator register made the 256 KB epilogue store-issue bound)
     float* __restrict__ out = p.slab + (long)split * 16 * p.M * p.K;
@@ -814,13 +865,15 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
                 }
         }
     }
-    // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0, wave 0)
-    if (nt == 0) {
-        if (wave == 0) { sDb[lane] = dbacc[0]; sDb[64 + lane] = dbacc[1]; }
-        __syncthreads();
-        if (tid < 64 && m0 + tid < p.M) {
-            const int q = tid >> 5, c = tid & 31;
-            p.dbslab[(long)split * p.M + m0 + tid] = sDb[q * 64 + c] + sDb[q * 64 + 32 + c];
+    // ---- bias gradient partial: sum of dY over this workgroup's regions (input-channel tile 0); unit u = tid + i*256
+    // belongs to channel u >> 3, so eight consecutive lanes are combined (fixed order) and lane 0 of the group writes
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < GY_UNITS; ++i) {
+            float v = dbacc[i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            const int co = (tid + i * 256) >> 3;
+            if ((tid & 7) == 0 && m0 + co < p.M) p.dbslab[(long)split * p.M + m0 + co] = v;
         }
     }
 }
