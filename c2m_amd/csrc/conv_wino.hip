@@ -673,21 +673,26 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         // the end -- inside the k-steps the sum cost every wave ~30 VALU per step (if-converted, never skipped)
         if (want_db) {
 #pragma unroll
-            for (int i = 0; i < GY_UNITS; ++i) dbacc[i] += (gy[i][0] + gy[i][1]) + (gy[i][2] + gy[i][3]);
+            for (int i = 0; i < GY_UNITS; ++i) {
+                // one dependent chain per unit, fenced: the SLP vectoriser otherwise pairs the two units' adds into
+                // v_pk_add_f32 through eight v_mov shuffles
+                float t = gy[i][0] + gy[i][1];
+                asm volatile("" : "+v"(t));
+                t += gy[i][2];
+                t += gy[i][3];
+                dbacc[i] += t;
+            }
         }
 #pragma unroll
         for (int i = 0; i < GX_UNITS; ++i) {
             f32x4 v = gx[i];
-            if (left) {
-                const bool e = cfix[i] > 0;             // loaded columns 0..3 -> (column -1, 0, 1, 2)
-                const f32x4 w = {p.reflect ? v[1] : 0.f, v[0], v[1], v[2]};
-                v[0] = e ? w[0] : v[0]; v[1] = e ? w[1] : v[1]; v[2] = e ? w[2] : v[2]; v[3] = e ? w[3] : v[3];
-            }
-            if (right) {
-                const bool e = cfix[i] < 0;             // loaded columns W-4..W-1 -> (column W-1, W, ..)
-                const float w0 = v[3], w1 = p.reflect ? v[2] : 0.f;
-                v[0] = e ? w0 : v[0]; v[1] = e ? w1 : v[1];
-            }
+            // selects only (the lane masks cfix > 0 / < 0 are loop invariants in SGPRs, combined with the region flags by
+            // SALU): branches around these few moves cost more VALU copies than they saved
+            const bool el = left & (cfix[i] > 0);       // loaded columns 0..3 -> (column -1, 0, 1, 2)
+            const bool er = right & (cfix[i] < 0);      // loaded columns W-4..W-1 -> (column W-1, W, ..)
+            const float l0 = p.reflect ? v[1] : 0.f, r0 = v[3], r1 = p.reflect ? v[2] : 0.f;
+            const f32x4 w = {el ? l0 : (er ? r0 : v[0]), el ? v[0] : (er ? r1 : v[1]), el ? v[1] : v[2], el ? v[2] : v[3]};
+            v = w;
             if (GX_TOTAL % 256 == 0 || xdst[i] >= 0) {
                 float* __restrict__ d = &pX[buf][xdst[i]];
                 *reinterpret_cast<float2*>(d) = float2{v[0], v[1]};
@@ -815,25 +820,30 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         load_raw(0, 0, rw);
         transform(rw, fa);
         load_raw(0, 1, rw);
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int cur = chunk & 1;
-            const bool more = chunk + 1 < nchunks;
-#ifndef WG_DIAG_NOFETCH
-            if (more) fetch(rbeg + chunk + 1);               // lands during k-steps 0 and 1
-#endif
-            WG_STEP(cur, 2, fa, fb);                         // MFMAs of k-step 0, transform of 1, raw reads of 2
-            WG_STEP(cur, 3, fb, fa);                         // k-step 1: the last raw reads of buffer cur are issued here,
-#ifndef WG_DIAG_NOFETCH
-            if (more) stash(rbeg + chunk + 1, cur ^ 1);      // before the barrier; buffer cur ^ 1 was last read before the
-#endif
-#ifndef WG_DIAG_NOBAR
-            __syncthreads();                                 // previous barrier
-#endif
-            // k-steps 2 and 3 + the first two raw sets of the next chunk (last chunk: stale LDS data, transformed and
-            // dropped -- keeps the accumulators out of a conditional path)
-            WG_STEP(cur ^ 1, 0, fa, fb);
-            WG_STEP(cur ^ 1, 1, fb, fa);
+        // the chunk loop is written for buffer 0 and buffer 1 explicitly: with a run-time buffer index every k-step spent
+        // four VALU on LDS addresses right behind its first MFMA; as constants they are the offset fields of the reads
+#define WG_CHUNK(CUR)                                                                                  \
+        {                                                                                              \
+            const bool more = chunk + 1 < nchunks;                                                     \
+            if (more) fetch(rbeg + chunk + 1);               /* lands during k-steps 0 and 1 */        \
+            WG_STEP(CUR, 2, fa, fb);                         /* MFMAs of k-step 0, transform of 1, raw reads of 2 */ \
+            WG_STEP(CUR, 3, fb, fa);                         /* k-step 1: the last raw reads of buffer CUR */ \
+            if (more) stash(rbeg + chunk + 1, (CUR) ^ 1);    /* buffer CUR ^ 1 was last read before the previous barrier */ \
+            __syncthreads();                                                                           \
+            /* k-steps 2 and 3 + the first two raw sets of the next chunk (last chunk: stale LDS data, transformed and */ \
+            /* dropped -- keeps the accumulators out of a conditional path) */                         \
+            WG_STEP((CUR) ^ 1, 0, fa, fb);                                                             \
+            WG_STEP((CUR) ^ 1, 1, fb, fa);                                                             \
         }
+        int chunk = 0;
+        for (; chunk + 1 < nchunks; chunk += 2) {
+            WG_CHUNK(0)
+            ++chunk;
+            WG_CHUNK(1)
+            --chunk;
+        }
+        if (chunk < nchunks) WG_CHUNK(0)
+#undef WG_CHUNK
     }
 #undef WG_STEP
     // ---- slab [split][xi][ci][co]: co innermost, so the four consecutive rows a lane holds in acc[..][4g .. 4g+3] are
@@ -929,15 +939,10 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ usum, const f
 
 // Number of region splits the launch will use.  The caller provides slab = (S + 1)*16*M*K floats (S partial slabs + the
 // summed one) and dbslab = S*M floats.
-// input-channel tile of the launch: 64 (NI = 2, one workgroup per CU) or 32 (NI = 1, two per CU)
-static int wino_wg_ni(int M, int K) {
-    const char* force = getenv("C2M_WINO_WG_NI");                  // A/B hook (tools/ab_wino_wgrad.py, tests)
-    if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
-    (void)M; (void)K;
-    // A/B on the bench layers (one box, tools/ab_wino_wgrad.py): the 64 x 32 tile with two workgroups per CU is 8...13 %
-    // faster than the 64 x 64 tile with one (152-182 vs 138-163 algorithmic TF/s) on every eligible shape
-    return 1;
-}
+// Input-channel tile of the launch: 32 (NI = 1: 64 x 32 channels, 128 accumulators, two workgroups per CU).  The 64 x 64
+// tile with one workgroup per CU (NI = 2) was 8...13 % slower on every eligible shape (tools/ab_wino_wgrad.py, first
+// version of the kernel) and is no longer instantiated.
+static int wino_wg_ni(int M, int K) { (void)M; (void)K; return 1; }
 
 C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long regions = (long)nimg * (H / GR) * (W / GC);
@@ -972,8 +977,7 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     const int ni = wino_wg_ni(M, K);
     dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 32 * ni));
     hipStream_t s = (hipStream_t)stream;
-    if (ni == 1) hipLaunchKernelGGL(conv_wino_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
-    else         hipLaunchKernelGGL(conv_wino_wgrad_kernel<2>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(conv_wino_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long n = 16L * M * K;

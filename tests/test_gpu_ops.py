@@ -126,17 +126,12 @@ WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3
 ]
 
 
-@pytest.mark.parametrize("wg_tile", ["64x32", "64x64"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_{c[5]}")
-def test_conv_winograd_forced(case, wg_tile, monkeypatch):
+def test_conv_winograd_forced(case, monkeypatch):
     """Winograd F(2x2,3x3) kernel on EVERY 3x3 stride-1 pad-1 shape of the suite, whatever the auto heuristic would
     pick: forward, zero-pad data gradient, reflect data gradient over the padded domain (two-target epilogue)."""
     monkeypatch.setattr(ops, "_WINO", "force")
     monkeypatch.setattr(ops, "_WINO_WGRAD", "force")
-    if wg_tile == "64x64":      # the one-workgroup-per-CU tile of the weight-gradient kernel (the default is 64x32, two per CU)
-        if not (case[0][2] % 2 == 0 and case[0][3] % 16 == 0):
-            pytest.skip("shape not eligible for the Winograd weight gradient: nothing tile-dependent to test")
-        monkeypatch.setenv("C2M_WINO_WG_NI", "2")
     ops._geom_cache.clear()
     try:
         xs, cout, k, stride, pad, mode = case
