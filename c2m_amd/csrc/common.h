@@ -58,6 +58,25 @@ __device__ __forceinline__ double block_sum_256_d(double v, double* smem /* >= 4
     return smem[0] + smem[1] + smem[2] + smem[3];
 }
 
+// XCD-aware work order.  Workgroups of a launch are handed to the 8 XCDs round-robin by linear id and every XCD has its own
+// L2, so tiles that re-read the same operand panel should be neighbours on ONE XCD: a 1-D launch of gx*gy*gz workgroups,
+// XCD x takes the contiguous range [x*q + min(x, r), ...) of the work list (q, r = total / 8, total % 8: bijective for any
+// total), and the work list runs over dimension `fast` first (0: x, 1: y), z last.
+struct C2mBlock { unsigned x, y, z, nz; };
+__device__ __forceinline__ unsigned c2m_xcd_item() {
+    const unsigned L = blockIdx.x, total = gridDim.x;
+    const unsigned q = total >> 3, r = total & 7u, x = L & 7u, j = L >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+__device__ __forceinline__ C2mBlock c2m_xcd_block(unsigned gx, unsigned gy, int fast) {
+    const unsigned w = c2m_xcd_item();
+    C2mBlock b;
+    if (fast == 1) { b.y = w % gy; const unsigned t = w / gy; b.x = t % gx; b.z = t / gx; }
+    else           { b.x = w % gx; const unsigned t = w / gx; b.y = t % gy; b.z = t / gy; }
+    b.nz = gridDim.x / (gx * gy);
+    return b;
+}
+
 enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 3 };
 
 __device__ __forceinline__ float c2m_act(float v, int act, float slope) {

@@ -112,9 +112,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int cls = p.ncls > 1 ? (int)blockIdx.z / p.splits : 0;
-    const int split = p.ncls > 1 ? (int)blockIdx.z - cls * p.splits : (int)blockIdx.z;
+    // XCD-aware order (common.h): the row tiles of one pixel tile gather the same pixels, neighbouring pixel tiles share taps
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Npix + BN - 1) / BN, (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM, n0 = blk.x * BN;
+    const int cls = p.ncls > 1 ? (int)blk.z / p.splits : 0;
+    const int split = p.ncls > 1 ? (int)blk.z - cls * p.splits : (int)blk.z;
     const float* __restrict__ Acls = p.A + cls * p.a_cls;
     const int4* __restrict__ ktab = p.ktab + cls * p.ktab_cls;
     const int kt_beg = split * p.ksteps_per_split;
@@ -427,10 +429,11 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.y * BM;
-    // tile -> (image, tile row, tile col)
+    // tile -> (image, tile row, tile col); XCD-aware order (common.h): row tiles of a pixel tile fastest
     const int tiles_x = (p.Wo + 31) / 32, tiles_y = (p.Ho + TR - 1) / TR;
-    int tb = blockIdx.x;
+    const C2mBlock blk = c2m_xcd_block((unsigned)((p.Npix / (p.Ho * p.Wo)) * tiles_y * tiles_x), (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM;
+    int tb = blk.x;
     const int tx = tb % tiles_x; tb /= tiles_x;
     const int ty = tb % tiles_y; const int img = tb / tiles_y;        // img = n*To + ot (2-D planes)
     const int oy0 = ty * TR, ox0 = tx * 32;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     for (int j = 0; j < NI; ++j) pbase[j] = (lane >> 5) * PCH + (wn * NI + j) * PW + (lane & 31);
 
     // split-K over whole channel chunks (gridDim.z); ksteps_per_split holds CHUNKS per split for this kernel
-    const int chunk_beg = blockIdx.z * p.ksteps_per_split;
+    const int chunk_beg = blk.z * p.ksteps_per_split;
     int chunk_end = chunk_beg + p.ksteps_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
     load_patch(chunk_beg, 0);
     load_a(chunk_beg * 9);
@@ -557,8 +560,8 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     }
 
     // ---- epilogue
-    const bool direct = gridDim.z == 1;
-    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
+    const bool direct = blk.nz == 1;
+    float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int oy = oy0 + wn * NI + j, ox = ox0 + (lane & 31);
@@ -595,7 +598,7 @@ template <int BM, int BN, int WGM, int WGN>
 static int launch_patch(const ConvP& p, int splits, hipStream_t s) {
     constexpr int TR = BN / 32;
     const long tiles = (long)(p.Npix / (p.Ho * p.Wo)) * ((p.Ho + TR - 1) / TR) * ((p.Wo + 31) / 32);
-    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM), splits);
+    dim3 grid((unsigned)(tiles * c2m_cdiv(p.M, BM) * splits));
     hipLaunchKernelGGL((conv_patch3x3_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
@@ -625,9 +628,10 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM;
     const int tiles_x = (p.Wo + 31) / 32, tiles_y = (p.Ho + TR - 1) / TR;
-    int tb = blockIdx.x;
+    const C2mBlock blk = c2m_xcd_block((unsigned)((p.Npix / (p.Ho * p.Wo)) * tiles_y * tiles_x), (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM;
+    int tb = blk.x;
     const int tx = tb % tiles_x; tb /= tiles_x;
     const int ty = tb % tiles_y; const int img = tb / tiles_y;            // img = n*To + ot (2-D planes)
     const int oy0 = ty * TR, ox0 = tx * 32;
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
     for (int j = 0; j < NI; ++j) pbase[j] = (lane >> 5) * NPIX + (wave * NI + j) * PW + (lane & 31);
     const int abase = (lane >> 5) * BM + (lane & 31);
 
-    const int chunk_beg = blockIdx.z * p.ksteps_per_split;
+    const int chunk_beg = blk.z * p.ksteps_per_split;
     int chunk_end = chunk_beg + p.ksteps_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
     // The activation gather (HBM / Infinity Cache) runs TWO chunks ahead of its LDS store (two register sets): one chunk of
     // MFMAs (~1.1 us) does not cover its loaded latency (~2.2 us per chunk with every CU fetching at once).  The weight
@@ -782,8 +786,8 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
 #undef PB_TAP
 
     // ---- epilogue (same mapping as the fp32 patch kernel)
-    const bool direct = gridDim.z == 1;
-    float* __restrict__ Yb = p.Y + (long)blockIdx.z * p.slab_stride;
+    const bool direct = blk.nz == 1;
+    float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
     // Vector path: a dword store per accumulator register (128 per wave) is store-ISSUE bound (~5 B/clk/CU: 27k cycles for
     // the 128 KB tile against 37k cycles of MFMAs at Cin = 256).  The tile goes through LDS instead (the weight buffers are
     // free now): [channel][64 pixels] per wave, 64 channels at a time, read back as float4 along the pixels and stored with
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
 template <int BM>
 static int launch_patch_bf16(const ConvP& p, int splits, hipStream_t s) {
     const long tiles = (long)(p.Npix / (p.Ho * p.Wo)) * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
-    dim3 grid((unsigned)tiles, c2m_cdiv(p.M, BM), splits);
+    dim3 grid((unsigned)(tiles * c2m_cdiv(p.M, BM) * splits));
     hipLaunchKernelGGL((conv_patch3x3_bf16_kernel<BM>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
@@ -911,7 +915,7 @@ template <int KW> static int launch_thin_rows(const ConvP& p, int ns, int ntg, i
 
 template <int BM, int BN, int WGM, int WGN>
 static int launch_igemm(const ConvP& p, int ns, int splits, hipStream_t s, bool bf16) {
-    dim3 grid(c2m_cdiv(p.Npix, BN), c2m_cdiv(p.M, BM), splits * p.ncls);
+    dim3 grid((unsigned)c2m_cdiv(p.Npix, BN) * c2m_cdiv(p.M, BM) * splits * p.ncls);
     constexpr int U = (BM == 128) ? C2M_IGEMM_U : 1;
     if (bf16) {
         constexpr int UB = C2M_BF16_U;
@@ -1091,8 +1095,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    // XCD-aware order (common.h): all tiles of a pixel split read the same pixels -> one XCD, back to back
+    const C2mBlock blk = c2m_xcd_block((unsigned)p.J / BN, (unsigned)(p.M + BM - 1) / BM, 0);
+    const int m0 = blk.y * BM, j0 = blk.x * BN;
+    const int split = blk.z;
     const int pbeg = split * p.pix_per_split;
     int pend = pbeg + p.pix_per_split; pend = pend < p.Npix ? pend : p.Npix;
     const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
@@ -1994,16 +2000,17 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
         return launch_wgrad_reduce(total2, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Sthin);
     }
     const bool bf16 = g[34] == 1;
+    const dim3 grid1(grid.x * grid.y * grid.z);       // 1-D launch, decoded XCD-aware in the kernel (common.h)
 #define C2M_WG(BMv, BNv, WGMv, WGNv)                                                                                  \
     do {                                                                                                              \
         if (bf16) {                                                                                                   \
-            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1, true>), grid, dim3(256), 0, s, p); \
-            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2, true>), grid, dim3(256), 0, s, p); \
-            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4, true>), grid, dim3(256), 0, s, p); \
+            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1, true>), grid1, dim3(256), 0, s, p); \
+            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2, true>), grid1, dim3(256), 0, s, p); \
+            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4, true>), grid1, dim3(256), 0, s, p); \
         } else {                                                                                                      \
-            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1>), grid, dim3(256), 0, s, p); \
-            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2>), grid, dim3(256), 0, s, p); \
-            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4>), grid, dim3(256), 0, s, p); \
+            if (NS == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 1>), grid1, dim3(256), 0, s, p); \
+            else if (NS == 2) hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 2>), grid1, dim3(256), 0, s, p); \
+            else              hipLaunchKernelGGL((conv_wgrad_kernel<BMv, BNv, WGMv, WGNv, 4>), grid1, dim3(256), 0, s, p); \
         }                                                                                                             \
     } while (0)
     if (p.M <= 32)      C2M_WG(32, 128, 1, 4);

@@ -76,11 +76,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int regions_x = (p.Wo + WC - 1) / WC, regions_y = (p.Ho + WR - 1) / WR;
-    int rb = blockIdx.x;
+    // XCD-aware work order: workgroups are handed to the 8 XCDs round-robin by linear id, each XCD has its own L2.  Work
+    // item w = region * mtiles + mt (the m-tiles of a region read the SAME input patch, neighbouring regions share its
+    // halo); XCD x gets the contiguous range of items [x*q + min(x, r), ...) so those re-reads hit its L2 instead of
+    // going out to the fabric once per m-tile (the launch used to read X mtiles times: 3-6x the tensor).
+    int rb, mt;
+    {
+        const unsigned L = blockIdx.x, total = gridDim.x;
+        const unsigned q = total >> 3, r = total & 7u, x = L & 7u, j = L >> 3;
+        const unsigned w = x * q + (x < r ? x : r) + j;
+        mt = (int)(w % (unsigned)p.mtiles); rb = (int)(w / (unsigned)p.mtiles);
+    }
     const int rx = rb % regions_x; rb /= regions_x;
     const int ry = rb % regions_y; const int img = rb / regions_y;
     const int oy0 = ry * WR, ox0 = rx * WC;
-    const int mt = blockIdx.y;
 
     // ---- patch addresses of this thread (fixed over the K loop).  A chunk's patch is 8 channels x 3 DMA rows of 64 patch
     // positions (180 used); wave w fetches the three rows of channels 2w and 2w + 1, so a lane owns the three positions
@@ -526,8 +535,8 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.nchunks = c2m_cdiv(p.K, CKW);
     p.mtiles = c2m_cdiv(p.M, 64);
     const long regions = (long)p.nimg * c2m_cdiv(p.Ho, WR) * c2m_cdiv(p.Wo, WC);
-    if (regions > 0x7fffffffL) return (int)hipErrorInvalidValue;
-    dim3 grid((unsigned)regions, (unsigned)p.mtiles);
+    if (regions * p.mtiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)(regions * p.mtiles));
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
@@ -585,7 +594,18 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     __shared__ float pX[2][NCI * GX_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
+    // XCD-aware work order (see conv_wino_kernel): item w = split * tiles + tile.  All channel tiles of a split read the
+    // same pixels -- dY once per input-channel tile, X once per output-channel tile -- so a split's tiles run on ONE XCD,
+    // back to back, and the re-reads hit its L2 (a split's pixels x all channels is a few MB)
+    int split, mt, nt;
+    {
+        const unsigned L = blockIdx.x, total = gridDim.x;
+        const unsigned q = total >> 3, r = total & 7u, x = L & 7u, j = L >> 3;
+        const unsigned w = x * q + (x < r ? x : r) + j;
+        const unsigned mtiles = (unsigned)(p.M + 63) / 64, ntiles = (unsigned)(p.K + NCI - 1) / NCI;
+        const unsigned t = w % (mtiles * ntiles);
+        split = (int)(w / (mtiles * ntiles)); mt = (int)(t % mtiles); nt = (int)(t / mtiles);
+    }
     const int m0 = mt * 64, c0 = nt * NCI;
     const int HW = p.H * p.W;
     const int rbeg = split * p.per_split;
@@ -975,7 +995,7 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
     p.per_split = c2m_cdiv(p.regions, S);
     const int ni = wino_wg_ni(M, K);
-    dim3 grid(S, c2m_cdiv(M, 64), c2m_cdiv(K, 32 * ni));
+    dim3 grid((unsigned)S * c2m_cdiv(M, 64) * c2m_cdiv(K, 32 * ni));
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wino_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();

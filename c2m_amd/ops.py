@@ -333,8 +333,11 @@ class _ConvPlan:
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
             wg_tiles = _cdiv(Cin, 32) * _cdiv(Cout, 64)           # workgroup tile: 64 output x 32 input channels
+            # A/B against the direct kernel (tools/ab_wino_wgrad.py, AB_EXTRA=1 for the marginal shapes): the Winograd form
+            # wins 1.1-1.3x even on a half-empty 64-row tile (Cout = 32) as long as there are two tiles; 32 -> 32 loses
+            waste = 2048.0 * wg_tiles / (Cin * Cout)
             if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
-                    _WINO_WGRAD == "auto" and wg_tiles >= 4 and 2048 * wg_tiles <= 1.35 * Cin * Cout
+                    _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
                     and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 512 // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)

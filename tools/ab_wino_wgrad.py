@@ -12,6 +12,9 @@ SHAPES = [(40, 256, 16, 32, 256, "reflect"), (40, 128, 64, 128, 128, "reflect"),
           (40, 256, 16, 32, 128, "reflect"), (40, 128, 16, 32, 512, "reflect"), (40, 128, 64, 128, 64, "reflect"),
           (40, 256, 32, 64, 128, "reflect"), (40, 1536, 8, 16, 256, "reflect"), (40, 768, 16, 32, 128, "reflect"),
           (40, 64, 32, 64, 64, "reflect"), (40, 384, 32, 64, 64, "reflect"), (40, 192, 64, 128, 32, "reflect")]
+if os.environ.get("AB_EXTRA"):      # layers the auto rule currently leaves on the direct kernel
+    SHAPES = [(40, 32, 128, 256, 32, "reflect"), (40, 64, 128, 256, 32, "reflect"), (40, 32, 128, 256, 64, "reflect"),
+              (40, 96, 128, 256, 32, "reflect"), (40, 64, 64, 128, 64, "reflect"), (40, 128, 128, 256, 32, "reflect")]
 for shape in SHAPES[:int(os.environ.get('AB_SHAPES', len(SHAPES)))]:
     N, Cin, H, W, Cout, mode = shape
     res = {}
