@@ -77,6 +77,53 @@ __device__ __forceinline__ int spatial_off(const int4 tp, int ots, int oys, int 
 
 #define C2M_OOB 0x80000000u   // voffset beyond any tensor we accept (< 2 GiB): the buffer load returns 0
 
+// Fast epilogue of the MFMA conv kernels (single target, whole 32-row tiles inside M): every store is
+// buffer_store_dword(value, voff[j], rsrc(Y), soff(i, r)) -- the pixel part of the address is one VGPR per pixel column block
+// (0x80000000 = pixel outside the tensor: the hardware drops the store), the row part a scalar -- so an element costs the
+// bias add + activation and NO address arithmetic.  The generic form (64-bit multiply-add, a bias load and an activation
+// switch per element) was ~15 VALU per element: on the shallow layers (K = 288: 288 MFMAs per wave) the prologue and the
+// epilogue together executed 5 of the 6.2 VALU per MFMA that PMC counts for the 32-row kernels.
+template <int MI, int NI>
+__device__ __forceinline__ void c2m_store_tile_fast(const f32x16 (&acc)[MI][NI], float* __restrict__ ybase,
+                                                    const unsigned (&voff)[NI], const int row0, const long row_stride,
+                                                    const float* __restrict__ bias, const bool direct, const int act,
+                                                    const float slope, const int lane) {
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, 0x80000000u, 0x00020000);
+    const int rs4 = (int)row_stride * 4;
+    float bv[MI][16];
+    if (direct && bias) {
+        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 0x80000000u, 0x00020000);
+        const unsigned hb = (unsigned)(16 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bv[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    br, hb, (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * 4, 0));
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[i][r] = 0.f;
+    }
+    const int a = direct ? act : C2M_ACT_NONE;
+#define C2M_STORE_LOOP(EXPR)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
+            const int soff = (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * rs4;                                           \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                           \
+                float v = acc[i][j][r] + bv[i][r];                                                                     \
+                v = (EXPR);                                                                                            \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, voff[j], soff, 0);          \
+            }                                                                                                          \
+        }
+    if (a == C2M_ACT_NONE)       { C2M_STORE_LOOP(v) }
+    else if (a == C2M_ACT_RELU)  { C2M_STORE_LOOP(v > 0.f ? v : 0.f) }
+    else if (a == C2M_ACT_LRELU) { C2M_STORE_LOOP(v > 0.f ? v : v * slope) }
+    else                         { C2M_STORE_LOOP(c2m_act(v, a, slope)) }
+#undef C2M_STORE_LOOP
+}
+
 template <class P>
 __device__ __forceinline__ void decompose_pix(int pix, const P& p, int& n, int& ot, int& oy, int& ox) {
     ox = pix % p.Wo; int r = pix / p.Wo;
@@ -374,6 +421,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     const bool direct = p.splits == 1;
     float* __restrict__ Yb = p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
     const int po_t = p.po_c[cls][0], po_y = p.po_c[cls][1], po_x = p.po_c[cls][2];
+    {
+        const int row0 = __builtin_amdgcn_readfirstlane(m0 + wm * TM);
+        if (row0 + MI * 32 <= p.M) {
+            // two targets (reflect data gradient): a pixel goes either to the interior tensor Y2 or, on the pad ring, to Y;
+            // each target is one pass of stores with the other target's pixels out of range, and the ring pass is
+            // skipped by the waves that hold no ring pixel (most of them)
+            unsigned voff[NI], voff2[NI];
+            bool ring = false;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pix = n0 + wn * TN + j * 32 + (lane & 31);
+                int n, ot, oy, ox;
+                decompose_pix(pix < p.Npix ? pix : 0, p, n, ot, oy, ox);
+                const long e = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw +
+                               4L * (lane >> 5) * p.out_sc;
+                voff[j] = pix < p.Npix ? (unsigned)(e * 4) : 0x80000000u;
+                voff2[j] = 0x80000000u;
+                if (p.Y2) {
+                    const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y,
+                              xp = ox * p.ps_x + po_x - p.lo_x;
+                    if (pix < p.Npix && (unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y &&
+                        (unsigned)xp < (unsigned)p.ext_x) {
+                        const long e2 = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp +
+                                        4L * (lane >> 5) * p.y2_sc;
+                        voff2[j] = (unsigned)(e2 * 4);
+                        voff[j] = 0x80000000u;
+                    }
+                }
+                ring = ring || voff[j] != 0x80000000u;
+            }
+            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane);
+            if (!p.Y2 || __any(ring))
+                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane);
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int pix = n0 + wn * TN + j * 32 + (lane & 31);
@@ -562,6 +645,38 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     // ---- epilogue
     const bool direct = blk.nz == 1;
     float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
+    {
+        const int row0 = __builtin_amdgcn_readfirstlane(m0 + wm * TM);
+        if (row0 + MI * 32 <= p.M) {
+            unsigned voff[NI], voff2[NI];
+            bool ring = false;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int oy = oy0 + wn * NI + j, ox = ox0 + (lane & 31);
+                const bool in = oy < p.Ho && ox < p.Wo;
+                const long e = p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
+                               (long)ox * p.out_sw + 4L * (lane >> 5) * p.out_sc;
+                voff[j] = in ? (unsigned)(e * 4) : 0x80000000u;
+                voff2[j] = 0x80000000u;
+                if (p.Y2) {
+                    const int tp = t_img * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
+                              xp = ox * p.ps_x + p.po_x - p.lo_x;
+                    if (in && (unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y &&
+                        (unsigned)xp < (unsigned)p.ext_x) {
+                        const long e2 = (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp +
+                                        4L * (lane >> 5) * p.y2_sc;
+                        voff2[j] = (unsigned)(e2 * 4);
+                        voff[j] = 0x80000000u;
+                    }
+                }
+                ring = ring || voff[j] != 0x80000000u;
+            }
+            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane);
+            if (!p.Y2 || __any(ring))
+                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane);
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int oy = oy0 + wn * NI + j, ox = ox0 + (lane & 31);
