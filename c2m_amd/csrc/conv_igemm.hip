@@ -46,7 +46,7 @@ struct ConvP {
     int ps_t, ps_y, ps_x, po_t, po_y, po_x, lo_t, lo_y, lo_x, ext_t, ext_y, ext_x;
     long y2_sn, y2_sc, y2_st, y2_sh;
     // LDS-patch variant (3x3, stride 1): input origin of a tile = o + (iy0, ix0); per-tap offsets inside the patch
-    int iy0, ix0, pty[3], ptx[3], nchunks;
+    int iy0, ix0, pty[3], ptx[3], nchunks, cin;   // cin: input channels of the gathered tensor (LDS-patch kernels)
     int ksteps_per_split;
     int reflect, is3d;
     int act;
@@ -522,32 +522,48 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     const int oy0 = ty * TR, ox0 = tx * 32;
     const int n_img = img / p.To, t_img = img % p.To;
 
-    // ---- patch loads: this thread's PLOADS elements (fixed (channel, row, col) for the whole K loop)
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    // ---- patch loads.  The patch of a chunk is 16 channels x PCH positions, [c][row][col] dense in LDS.  A DMA row is 64
+    // consecutive positions of ONE channel: wave w fetches the PROWS rows of channels w, w+4, w+8, w+12, the channel rides in
+    // the scalar offset, so a lane owns the PROWS positions wr*64 + lane and the reflect / bounds arithmetic is done PROWS
+    // (6 at the 8-row tile) times per thread instead of once per fetched element (22 times: ~550 VALU in the prologue, a third
+    // of all VALU of a 288-deep layer; a VALU beside MFMAs costs matrix-pipe cycles, tools/micro/mfma_issue.hip).  The last
+    // row of a channel is partial: its lanes beyond PCH are switched off (EXEC), not sent out of range -- an out-of-range
+    // lane would write a zero into the next channel's first positions.
+    constexpr int PROWS = (PCH + 63) / 64;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long xaddr = (unsigned long)p.X;
+    const u32x4 xrs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const unsigned sp_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&sP[0][0];
     const unsigned img_byte = (unsigned)(n_img * (int)p.in_sn + t_img * (int)p.in_st) * 4u;
-    unsigned pvo[PLOADS];
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    unsigned pvo[PROWS];
 #pragma unroll
-    for (int i = 0; i < PLOADS; ++i) {
-        const int e = tid + i * 256;
-        const int c = e / PCH, r = (e % PCH) / PW, col = e % PW;
+    for (int wr = 0; wr < PROWS; ++wr) {
+        const int pos = wr * 64 + lane;
+        const int r = pos / PW, col = pos % PW;
         int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + col;
-        bool ok = e < PELEMS;
         if (p.reflect) {
             iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
             ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
-            ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;   // tiles hanging off the image
-        } else {
-            ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         }
-        pvo[i] = ok ? img_byte + (unsigned)(c * p.in_sc + iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
+        const bool ok = pos < PCH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;   // (tiles may hang off)
+        pvo[wr] = ok ? img_byte + (unsigned)(iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
     }
-    // global -> LDS directly (buffer_load ... lds): no staging registers, no ds_write pass; out-of-range lanes (pad
-    // pixels, the tail beyond PELEMS) read through the OOB offset and land as zeros.
     auto load_patch = [&](int chunk, int buf) {
-        const int soff = chunk * BK * p.in_sc * 4;
 #pragma unroll
-        for (int i = 0; i < PLOADS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, &sP[buf][wave * 64 + i * 256], 4, pvo[i], soff, 0, 0);
+        for (int ci = 0; ci < 4; ++ci) {
+            const int c = wave_s + 4 * ci, ch = chunk * BK + c;
+            u32x4 rsk = xrs;
+            rsk[2] = ch < p.cin ? p.x_bytes : 0u;       // channels past K: zero records (the scalar offset is not range-checked)
+            const int soff = ch * p.in_sc * 4;
+#pragma unroll
+            for (int wr = 0; wr < PROWS; ++wr) {
+                const unsigned dst = sp_lds + (unsigned)((buf * PLOADS * 256 + c * PCH + wr * 64) * 4);
+                if (wr * 64 + 64 <= PCH || wr * 64 + lane < PCH)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                                 :: "s"(dst), "v"(pvo[wr]), "s"(rsk), "s"(soff) : "memory");
+            }
+        }
     };
 
     // ---- weight side (same packed K order as the gather kernel with CK = 16: (chunk, tap, channel))
@@ -1122,7 +1138,8 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
         for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
         p.nchunks = p.nk / 9;
-        if (p.nchunks * 9 != p.nk) return (int)hipErrorInvalidValue;
+        p.cin = (int)g[28];
+        if (p.nchunks * 9 != p.nk || p.cin <= 0 || p.cin > p.nchunks * 16) return (int)hipErrorInvalidValue;
         p.ksteps_per_split = c2m_cdiv(p.nchunks, splits);           // chunks per split
         if (c2m_cdiv(p.nchunks, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;
         if (g[34] == 1) {
