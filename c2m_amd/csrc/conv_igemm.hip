@@ -2187,6 +2187,42 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __rest
     }
 }
 
+// W % 4 == 0: a thread owns four consecutive x.  Their direct sources are four consecutive floats of the padded row (one
+// 4-byte aligned 16-byte load); mirrored x sources exist only for elements within `pad` of a border and are added per
+// element.  Same per-element summation order as the scalar kernel ((t, y) sources outer, x sources inner).
+__global__ void reflect_fold_vec_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
+    const int W4 = f.W >> 2;
+    const long total4 = f.total >> 2;
+    for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+        const int x0 = (int)(i4 % W4) * 4; long r = i4 / W4;
+        const int y = (int)(r % f.H); r /= f.H;
+        const int t = (int)(r % f.T); const long nc = r / f.T;
+        int st[3], sy[3];
+        const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy);
+        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        const bool xband = f.pw > 0 && (x0 <= f.pw || x0 + 3 >= f.W - 1 - f.pw);     // some element has mirrored x sources
+        f32x4a acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < ny; ++b) {
+                const float* __restrict__ row = base + ((long)st[a] * Hp + sy[b]) * Wp;
+                f32x4a v = *reinterpret_cast<const f32x4u*>(row + x0 + f.pw);
+                if (xband) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int sx[3];
+                        const int nx = fold_sources(x0 + e, f.W, f.pw, sx);
+                        for (int c = 1; c < nx; ++c) v[e] += row[sx[c]];
+                    }
+                }
+                acc += v;
+            }
+        *reinterpret_cast<f32x4a*>(dX + i4 * 4) = acc;
+    }
+}
+
 // In-place variant for the two-target dgrad: dX already holds the direct term, add the mirrored pad-ring terms
 // (only pixels within `pad` of a border have any).  Generic form: every element looks for extra sources.
 __global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
@@ -2280,8 +2316,12 @@ C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int 
     C2M_ENTER();
     FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
     if (f.total <= 0) return 0;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream, dXpad, dX,
-                       f);
+    if ((W & 3) == 0 && ((uintptr_t)dX & 15) == 0)
+        hipLaunchKernelGGL(reflect_fold_vec_kernel, dim3(c2m_grid(f.total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           dXpad, dX, f);
+    else
+        hipLaunchKernelGGL(reflect_fold_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream, dXpad, dX,
+                           f);
     return (int)hipGetLastError();
 }
 

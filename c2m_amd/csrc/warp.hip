@@ -476,9 +476,12 @@ __global__ void upsample2x_bwd_pair_kernel(const float* __restrict__ gout, float
 // staged in LDS once with coalesced loads (the gather forms above fetch every gout element four times through the L1),
 // then each lane combines two outputs from 8-byte LDS reads.  Same weights as upsample2x_bwd_pixel (out-of-range window
 // elements are stored as 0 and carry weight 0).
-constexpr int UB_TY = 8, UB_TX = 64, UB_LR = 2 * UB_TY + 2, UB_LC = 2 * UB_TX + 2, UB_LS = UB_LC + 2;
+// UB_TX = 64 (two outputs per lane) for wide maps, 32 (one per lane) for the 32- and 48-wide ones.
+constexpr int UB_TY = 8, UB_LR = 2 * UB_TY + 2;
+template <int UB_TX>
 __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* __restrict__ gout, float* __restrict__ gin,
                                                                   int Hi, int Wi) {
+    constexpr int UB_LC = 2 * UB_TX + 2, UB_LS = UB_LC + 2;
     __shared__ __attribute__((aligned(8))) float tile[UB_LR][UB_LS];
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     const int tiles_x = (Wi + UB_TX - 1) / UB_TX, tiles_y = (Hi + UB_TY - 1) / UB_TY;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* _
         if (oy >= 0 && oy < Ho) { const Lerp q = lerp_src(oy, Hi, 0.5f, false); wy[d] = (q.i0 == y ? q.l0 : 0.0f) + (q.i1 == y ? q.l1 : 0.0f); }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < UB_TX / 32; ++h) {
         const int lx = l + 32 * h, x = x0 + lx;
         if (x >= Wi) continue;
         float wx[4];
@@ -541,11 +544,16 @@ C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, i
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    if (Wi >= 64 && Hi >= 8 && total * 4 < (1L << 31)) {
-        const long tiles = (long)c2m_cdiv(Wi, UB_TX) * c2m_cdiv(Hi, UB_TY) * NC;
+    if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31)) {
+        const int tx = Wi >= 64 ? 64 : 32;
+        const long tiles = (long)c2m_cdiv(Wi, tx) * c2m_cdiv(Hi, UB_TY) * NC;
         if (tiles < (1L << 31)) {
-            hipLaunchKernelGGL(upsample2x_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, gout, gin,
-                               Hi, Wi);
+            if (tx == 64)
+                hipLaunchKernelGGL(upsample2x_bwd_tile_kernel<64>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                                   gout, gin, Hi, Wi);
+            else
+                hipLaunchKernelGGL(upsample2x_bwd_tile_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                                   gout, gin, Hi, Wi);
             return (int)hipGetLastError();
         }
     }
