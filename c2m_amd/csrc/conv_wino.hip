@@ -66,7 +66,13 @@ static __device__ __forceinline__ f32x2 pk_b(f32x2 p, f32x2 q) {       // (x2 - 
     return d;
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
+// MT = 32-row output-channel tiles per workgroup: 2 (64 output channels, 128 accumulator registers, two workgroups per CU) or
+// 1 (<= 32 output channels -- the full-resolution heads and the data gradients of 32-channel inputs: 64 accumulators, three
+// workgroups per CU; half the MFMAs per chunk at the same transform / DMA work, which still beats the direct kernels' 32-row
+// tiles).  U is packed per 64 rows either way; MT = 1 reads the fragments of rows 0..31 (every second 1 KB record).
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const WinoP p) {
+    constexpr int NU = 4 * MT;                       // U fragment records (16 bytes per lane) per wave and chunk
     __shared__ float sP[3][PBUF];                   // input patch [k][PH][PW] (+pad), filled by LDS-DMA two chunks ahead
     __shared__ float sV[2 * 16 * CKW * 32];         // V[buf][xi][k][tile] (double buffered); reused by the epilogue
 #ifdef WINO_OCC1
@@ -144,18 +150,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     const unsigned long uaddr = (unsigned long)p.U;
     const u32x4 urs = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     const unsigned uvo = (unsigned)((((mt * 4 + wave) * 8 * 64) + lane) * 16);
-    f32x4 ua[8];
+    f32x4 ua[NU];
     auto load_u = [&](int chunk) {
         const f32x4* __restrict__ q = reinterpret_cast<const f32x4*>(ubase + chunk * ustride);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ua[i] = q[i * 64];
+        for (int i = 0; i < NU; ++i) ua[i] = q[(i * 2 / MT) * 64];
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][MT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
 
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     if (p.nchunks > 1) load_patch(1, 1);
     load_u(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(ua[i]));   // retire these loads HERE: a load pending at loop entry
+    for (int i = 0; i < NU; ++i) asm volatile("" :: "v"(ua[i]));   // retire these loads HERE: a load pending at loop entry
                                                        // costs a vmcnt(0) in front of the first MFMA of EVERY iteration
     if (p.nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     // shadow of the first eight MFMAs (two per MFMA pair) instead of in front of them, the DMA requests of patch(chunk + 2)
     // behind those (U loads stay older than the DMAs, so the counted wait still separates them), and the input transform of
     // the next chunk is mixed into the remaining MFMAs.
-    auto iteration = [&](const int chunk, f32x4 (&ucur)[8], f32x4 (&unext)[8]) {
+    auto iteration = [&](const int chunk, f32x4 (&ucur)[NU], f32x4 (&unext)[NU]) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < p.nchunks;
         // patch(chunk + 1) (this wave's part) has landed: nothing younger is in flight at this point
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
         auto mfma_pair = [&](int g) {                  // g = kk * 4 + j
             const int kk = g >> 2, j = g & 3;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const f32x4 v = ucur[j * 2 + mi];
+            for (int mi = 0; mi < MT; ++mi) {
+                const f32x4 v = ucur[j * MT + mi];
                 const float av = kk == 0 ? v.x : (kk == 1 ? v.y : (kk == 2 ? v.z : v.w));
                 acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][kk], acc[j][mi], 0, 0, 0);
             }
@@ -239,9 +245,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
         for (int g = 0; g < 4; ++g) {
             mfma_pair(g);
 #pragma unroll
-            for (int i = 2 * g; i < 2 * g + 2; ++i)
+            for (int i = MT * g; i < MT * g + MT; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int rec = i * 2 / MT;            // record j*2 + mi of the 64-row packing
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
-                             : "=&v"(unext[i]) : "v"(uvo), "s"(urs), "s"(i < 4 ? usoff0 : usoff1), "n"((i & 3) * 1024) : "memory");
+                             : "=&v"(unext[i]) : "v"(uvo), "s"(urs), "s"(rec < 4 ? usoff0 : usoff1), "n"((rec & 3) * 1024) : "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // patch(chunk + 2) -- always issued, so the iteration is one basic block and the requests sit between MFMAs; past
@@ -301,10 +310,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
         // the 8 U loads are older than the 6 DMA loads issued after them
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(unext[i]));   // uses of U(chunk + 1) stay behind the wait
+        for (int i = 0; i < NU; ++i) asm volatile("" : "+v"(unext[i]));   // uses of U(chunk + 1) stay behind the wait
         pnext = pnext == 2 ? 0 : pnext + 1;
     };
-    f32x4 ub[8];
+    f32x4 ub[NU];
     int chunk = 0;
     for (; chunk + 1 < p.nchunks; chunk += 2) {
         iteration(chunk, ua, ub);
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
         const int tile0 = (ey >> 1) * 8 + 2 * e4;
         const int ro = top ? 0 : 3 * 16 * 32;        // row combined with r1, r2: r0 (top) or r3 (bottom)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 __syncthreads();
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoP p) {
     const float* __restrict__ rq = sR + (ex & 1) * QS + (1 * 16 + c0) * 32 + (ey >> 1) * 8 + (ex >> 1);
     const int ro = top ? -16 * 32 : 2 * 16 * 32;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {               // accumulator registers r in [8hf, 8hf + 8) = tile rows 16hf .. 16hf+15
             __syncthreads();
@@ -537,7 +546,8 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     const long regions = (long)p.nimg * c2m_cdiv(p.Ho, WR) * c2m_cdiv(p.Wo, WC);
     if (regions * p.mtiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(regions * p.mtiles));
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (p.M <= 32) hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else           hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

@@ -343,7 +343,10 @@ class _ConvPlan:
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
             fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
-            if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and Cout >= 48 and
+            # rows: 64-row tiles need >= 48 output channels to pay; 17..32 run on the 32-row variant (MT = 1, three
+            # workgroups per CU), which beats the direct kernels' 32-row tiles
+            rows_ok = lambda m: m >= 48 or 17 <= m <= 32
+            if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and rows_ok(Cout) and
                                     regions * _cdiv(Cout, 64) >= 256):
                 self.wino_fwd = True
                 self.wino_fwd_geom = np.array([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
@@ -353,7 +356,7 @@ class _ConvPlan:
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
             dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
             dfit = Hd * Wd >= 0.65 * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16     # 34x66 (70 % fill) still wins: 115-121 vs 89-92 TF/s
-            if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and Cin >= 48 and
+            if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
                                                    dregions * _cdiv(Cin, 64) >= 256)):
                 self.wino_dgrad = True
                 o = -2 if reflect else -1
