@@ -58,6 +58,9 @@ def _f(t):
 # =============================================================================================== convolution
 _geom_cache = {}
 _conv_bf16 = False
+# minimum region fill of a Winograd data-gradient launch: the padded 18x34 domain of the 16x32 reflect layers fills 53 % of its
+# 8x16 regions and still beats the gather kernel by 14-30 % (tools/run_conv.py A/B); the 10x18 domain (35 %) does not
+_WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
 # the direct kernel, "off", "force" (tests: every eligible shape).
@@ -355,7 +358,7 @@ class _ConvPlan:
             # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
             dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
-            dfit = Hd * Wd >= 0.65 * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16     # 34x66 (70 % fill) still wins: 115-121 vs 89-92 TF/s
+            dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
             if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
                                                    dregions * _cdiv(Cin, 64) >= 256)):
                 self.wino_dgrad = True
