@@ -43,6 +43,11 @@ struct WinoP {
     float* Y2;
     long y2_sn, y2_sc, y2_sh;
     int lo_y, lo_x, ext_y, ext_x;
+    // 3x3x3 convolutions as a 2-D Winograd over "virtual" input channels (time tap, channel): image = (sample n, frame t),
+    // virtual channel v = kt * cin + ci reads frame t + kt + toff of channel ci (reflected in time or absent -> zero records).
+    // nkt = 0: plain 2-D layer (To = 1, in_st = out_st = 0).
+    int To, Ti, nkt, cin, toff, treflect;
+    long in_st, out_st;
 };
 
 constexpr int WR = 8, WC = 16;               // output region rows / cols
@@ -102,7 +107,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // lane, 64 + lane, 128 + lane and the channel rides in the scalar offset of the DMA: the reflect / bounds arithmetic
     // is done for 3 addresses per thread instead of 6 (and no div / mod by the channel size); a VALU next to the MFMAs of
     // the other resident workgroup costs 2.5 ... 5 matrix-pipe cycles (tools/micro/mfma_issue.hip).
-    const unsigned img_byte = (unsigned)(img * (int)p.in_sn) * 4u;
+    const int smp = p.nkt ? img / p.To : img, frm = p.nkt ? img - smp * p.To : 0;       // sample, frame (scalar)
+    const unsigned img_byte = (unsigned)(smp * (int)p.in_sn) * 4u;
     unsigned pvo[3];
 #pragma unroll
     for (int sg = 0; sg < 3; ++sg) {
@@ -132,10 +138,18 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     auto dma_row = [&](int chunk, int j, int buf, bool live) {
         const int k = 2 * wave + j / 3, sg = j % 3;
         const int ch = chunk * CKW + k;
+        bool on = live && ch < p.K;
+        int soff = ch * p.in_sc * 4;
+        if (p.nkt) {                                    // (time tap, channel): all scalar arithmetic
+            const int kt = ch / p.cin, ci = ch - kt * p.cin;
+            int tt = frm + kt + p.toff;
+            if (p.treflect) { tt = tt < 0 ? -tt : tt; tt = tt >= p.Ti ? 2 * p.Ti - 2 - tt : tt; }
+            on = on && (unsigned)tt < (unsigned)p.Ti;
+            soff = (int)(((long)ci * p.in_sc + (long)tt * p.in_st) * 4);
+        }
         u32x4 rsk = rs;
-        rsk[2] = (live && ch < p.K) ? p.x_bytes : 0u;
+        rsk[2] = on ? p.x_bytes : 0u;
         const unsigned dst = sp_lds + (unsigned)((buf * PBUF + k * PCS + sg * 64) * 4);
-        const int soff = ch * p.in_sc * 4;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                      :: "s"(dst), "v"(pvo[sg]), "s"(rsk), "s"(soff) : "memory");
     };
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
         const bool top = (ey & 1) == 0;
         // target of the 4-pixel group: all interior -> Y2, all outside the interior -> Y, straddling -> per pixel
         int mode = 0;                                 // 0: Y (vector), 1: Y2 (vector), 2: mixed (scalar per pixel)
-        float* __restrict__ yb0 = p.Y + p.out_off + (long)img * p.out_sn + (long)oy * p.out_sh + ox;
+        float* __restrict__ yb0 = p.Y + p.out_off + (long)smp * p.out_sn + (long)frm * p.out_st + (long)oy * p.out_sh + ox;
         long cs0 = p.out_sc;
         float* __restrict__ yb1 = yb0;
         long cs1 = cs0;
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
             ybase = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
             cstride = p.y2_sc;
         } else {
-            ybase = p.Y + p.out_off + (long)img * p.out_sn + (long)oy * p.out_sh + ox;
+            ybase = p.Y + p.out_off + (long)smp * p.out_sn + (long)frm * p.out_st + (long)oy * p.out_sh + ox;
             cstride = p.out_sc;
         }
     }
@@ -538,6 +552,13 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.out_sn = g[13]; p.out_sc = g[14]; p.out_sh = g[15]; p.out_off = g[16];
     if (g[17] <= 0 || g[17] >= 0x80000000LL) return (int)hipErrorInvalidValue;
     p.x_bytes = (unsigned)g[17];
+    p.To = (int)g[25]; p.in_st = g[26]; p.out_st = g[27]; p.cin = (int)g[28]; p.nkt = (int)g[29]; p.toff = (int)g[30];
+    p.Ti = (int)g[31]; p.treflect = (int)g[32];
+    if (p.nkt) {
+        if (Y_interior || p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
+    } else {
+        p.To = 1; p.in_st = p.out_st = 0;
+    }
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.K <= 0 || p.nimg <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
     if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;

@@ -300,6 +300,14 @@ def _geom(**kw):
     return g
 
 
+def _wino_geom(head, To=0, in_st=0, out_st=0, cin=0, nkt=0, toff=0, Ti=0, treflect=0):
+    """geom[] of c2m_conv_wino (include/c2m_hip.h): 33 entries; the tail describes the time taps of a 3x3x3 layer."""
+    g = np.zeros(33, dtype=np.int64)
+    g[:len(head)] = head
+    g[25:33] = (To, in_st, out_st, cin, nkt, toff, Ti, treflect)
+    return g
+
+
 class _ConvPlan:
     """Everything shape-dependent for one conv layer geometry (cached): gather tables + geom arrays."""
 
@@ -352,8 +360,8 @@ class _ConvPlan:
             if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and rows_ok(Cout) and
                                     regions * _cdiv(Cout, 64) >= 256):
                 self.wino_fwd = True
-                self.wino_fwd_geom = np.array([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
-                                               Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc], dtype=np.int64)
+                self.wino_fwd_geom = _wino_geom([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
+                                                 Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc])
             # data gradient: zero padding -> the unpadded domain; reflect padding -> the padded (H+2)x(W+2) domain with
             # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
@@ -363,9 +371,37 @@ class _ConvPlan:
                                                    dregions * _cdiv(Cin, 64) >= 256)):
                 self.wino_dgrad = True
                 o = -2 if reflect else -1
-                self.wino_dgrad_geom = np.array(
+                self.wino_dgrad_geom = _wino_geom(
                     [Cin, Cout, N, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Hd * Wd, Hd * Wd, Wd, 0,
-                     4 * N * Cout * osp, Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi], dtype=np.int64)
+                     4 * N * Cout * osp, Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi])
+        # ---- 3x3x3 stride-1 pad-1 layers (fuse_convs, the 3-D blocks): a 2-D Winograd over virtual input channels
+        # (time tap, channel) with image = (sample, frame) -- the K loop is three times as deep as the 2-D layer's, the
+        # temporal padding is a per-tap frame index (reflected, or a zero-record descriptor).  Data gradient: virtual
+        # channels (flipped time tap, output channel) of dY over the padded (T+2, H+2, W+2) domain (reflect; then one
+        # fold pass) or the unpadded one (zeros).
+        self.wino3d = False
+        if not bf16 and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and (pt, ph, pw) == (1, 1, 1):
+            rows_ok = lambda m: m >= 48 or 17 <= m <= 32
+            regions = N * To * _cdiv(Ho, 8) * _cdiv(Wo, 16)
+            fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
+            hw_i, hw_o = Hi * Wi, Ho * Wo
+            if _WINO == "force" or (_WINO == "auto" and fit and 3 * Cin >= 32 and rows_ok(Cout) and
+                                    regions * _cdiv(Cout, 64) >= 256):
+                self.wino_fwd = self.wino3d = True
+                self.wino_fwd_geom = _wino_geom(
+                    [Cout, 3 * Cin, N * To, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi, Cout * osp, osp, Wo,
+                     0, 4 * N * Cin * in_sc], To=To, in_st=hw_i, out_st=hw_o, cin=Cin, nkt=3, toff=-1, Ti=Ti,
+                    treflect=int(reflect))
+            Td, Hd, Wd = (Ti + 2, Hi + 2, Wi + 2) if reflect else (Ti, Hi, Wi)
+            dregions = N * Td * _cdiv(Hd, 8) * _cdiv(Wd, 16)
+            dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
+            if _WINO == "force" or (_WINO == "auto" and dfit and 3 * Cout >= 32 and rows_ok(dM) and
+                                    dregions * _cdiv(dM, 64) >= 256):
+                self.wino_dgrad = self.wino3d = True
+                o = -2 if reflect else -1
+                self.wino_dgrad_geom = _wino_geom(
+                    [dM, 3 * Cout, N * Td, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Td * Hd * Wd, Td * Hd * Wd, Wd,
+                     0, 4 * N * Cout * osp], To=Td, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
@@ -585,7 +621,11 @@ class _ConvFn(torch.autograd.Function):
         N, Cin, Cout = pl.dims[0:3]
         ctx.frozen_w = not ctx.needs_input_grad[1]
         if pl.wino_fwd:
-            U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
+            if pl.wino3d:      # virtual channels (kt, ci): [Cout][3*Cin][3][3]
+                U = _packed(w, ctx.frozen_w, ("wino-fwd3d",), lambda: _wino_filter(
+                    w.permute(0, 2, 1, 3, 4).reshape(Cout, 3 * Cin, 3, 3).contiguous(), Cout, 3 * Cin, 0))
+            else:
+                U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
             _lib.check(_timed("wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
@@ -625,7 +665,25 @@ class _ConvFn(torch.autograd.Function):
             gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and pl.wino_dgrad:
+        if ctx.needs_input_grad[0] and pl.wino_dgrad and pl.wino3d:
+            dM = pl.dM
+            # virtual channels (flipped time tap, output channel): a "native" [3*Cout][dM][3][3] weight for the 2-D transform
+            U = _packed(w, ctx.frozen_w, ("wino-dgrad3d", dM), lambda: _wino_filter(
+                w[:, :dM].flip(2).permute(2, 0, 1, 3, 4).reshape(3 * Cout, dM, 3, 3).contiguous(), 3 * Cout, dM, 1))
+            gx = torch.empty_like(x)
+            tgt = torch.empty(pl.dgrad_target, device=x.device, dtype=torch.float32) if pl.reflect else gx
+            g3 = pl.wino_dgrad_geom
+            npix = int(g3[2] * g3[5] * g3[6])
+            tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("wino", pl.dgrad_flops,
+                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), None, None, _gp(g3), 0, 0.0, _stream()), tag,
+                              4 * (gy.numel() + w.numel() + x.numel())), "conv_wino dgrad 3-D")
+            if pl.reflect:
+                Ti, Hi, Wi = pl.dims[3:6]
+                _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, _stream()), "reflect fold 3-D")
+            if dM < Cin:
+                gx[:, dM:].zero_()
+        elif ctx.needs_input_grad[0] and pl.wino_dgrad:
             U = _packed(w, ctx.frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
             gx = torch.empty_like(x)
             npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])

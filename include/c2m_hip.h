@@ -83,7 +83,12 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
  * geom[]: 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0 (input origin of output (0,0): -pad forward),
  *         9 reflect, 10 in_sn, 11 in_sc, 12 in_sh, 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes;
  *         with Y_interior (two-target data gradient of a reflect-padded conv, as in c2m_conv_igemm): 18 y2_sn, 19 y2_sc,
- *         20 y2_sh, 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x                                                              */
+ *         20 y2_sh, 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x;
+ *         3x3x3 layers (fuse_convs / the 3-D blocks of the motion decoder, modules/layers/common.py Conv3d call sites) run
+ *         as a 2-D Winograd over virtual channels (time tap kt, channel ci), image = (sample, frame): 25 To (frames per
+ *         sample of the output), 26 in_st, 27 out_st (frame strides), 28 cin, 29 nkt (0 = 2-D layer, else 3: K = nkt*cin),
+ *         30 toff (source frame = t + kt + toff), 31 Ti (source frames), 32 treflect (reflect the source frame index;
+ *         otherwise frames outside [0, Ti) are zeros).  geom[] always holds 33 entries.                                */
 long c2m_wino_upack_floats(int M, int K);
 int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
 int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,

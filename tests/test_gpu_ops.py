@@ -118,6 +118,9 @@ def test_conv_fwd_bwd(case, act):
 
 
 WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3] == 1 and c[4] == 1] + [
+    c for c in CONV_CASES if len(c[0]) == 5 and c[2] == (3, 3, 3) and c[3] == (1, 1, 1) and c[4] == (1, 1, 1)] + [
+    ((2, 12, 3, 16, 32), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), "zeros"),     # 3x3x3 as 2-D Winograd over (time tap, channel)
+    ((1, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "zeros"),
     ((3, 40, 24, 48), 70, (3, 3), 1, 1, "reflect"),      # channels not multiples of 8 / 64: zero-padded U, partial M tile
     ((2, 16, 10, 20), 8, (3, 3), 1, 1, "zeros"),         # partial 8x16 regions on both axes
     ((3, 40, 6, 48), 70, (3, 3), 1, 1, "zeros"),         # Winograd wgrad: partial channel tiles, 27 regions over 2 splits
@@ -145,8 +148,10 @@ def test_conv_winograd_forced(case, monkeypatch):
         (yr * go).sum().backward()
         xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
         y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
-        pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
-        assert pl.wino_fwd and pl.wino_dgrad and pl.wino_wgrad == (xs[2] % 2 == 0 and xs[3] % 16 == 0)
+        is3d = len(xs) == 5      # 3x3x3: 2-D Winograd over (time tap, channel) virtual channels; its wgrad stays direct
+        pl = ops._plan(xg, wg, (1, 1, 1), (1, 1, 1) if is3d else (0, 1, 1), mode == "reflect")
+        assert pl.wino_fwd and pl.wino_dgrad
+        assert pl.wino3d if is3d else pl.wino_wgrad == (xs[2] % 2 == 0 and xs[3] % 16 == 0)
         (y * g(go)).sum().backward()
         rel_close(y, yr, 2e-5, "winograd fwd")
         rel_close(xg.grad, xr.grad, 5e-5, "winograd dgrad")
