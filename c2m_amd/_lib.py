@@ -28,6 +28,7 @@ _SIGS = {
     "c2m_conv_wino": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),
     "c2m_wino_wgrad_splits": (c_int, [c_int] * 5),
     "c2m_conv_wino_wgrad": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "c2m_conv_wino_wgrad3d": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "c2m_prep_video": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_seg_onehot": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "c2m_prep_flow_occ": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),

@@ -593,8 +593,13 @@ struct WinoWgP {
     const float* dY; const float* X; float* slab; float* dbslab;
     int M, K, nimg, H, W;            // Cout, Cin, images, spatial size (dY and X have the same: stride 1, pad 1)
     int reflect;
-    long dy_sn, x_sn;                // image strides (elements); channel stride = H*W for both
+    long dy_sn, x_sn;                // sample strides (elements)
     unsigned dy_bytes, x_bytes;
+    // 3x3x3 layers: image = (sample, frame), input channels are virtual (time tap kt, channel): K = 3 * cin, the unit of
+    // virtual channel v reads frame t + kt - 1 of channel v % cin (reflected in time at the first / last frame, or zeros).
+    // T = 1, cin = K, cs = H * W for the 2-D layers.
+    int T, cin;
+    long cs;                         // channel stride (elements) of dY and X: T * H * W
     int regions, per_split;          // 2x16-output regions in total / per workgroup
 };
 
@@ -667,17 +672,20 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     for (int i = 0; i < GY_UNITS; ++i) {
         const int u = tid + i * 256;
         const int co = u >> 3, row = (u >> 2) & 1, q = u & 3;
-        yvo[i] = m0 + co < p.M ? (unsigned)((m0 + co) * HW + row * p.W + q * 4) * 4u : WINO_OOB;
+        yvo[i] = m0 + co < p.M ? (unsigned)((m0 + co) * (int)p.cs + row * p.W + q * 4) * 4u : WINO_OOB;
         ydst[i] = co * GY_STRIDE + row * GC + q * 4;
     }
-    unsigned xbase[GX_UNITS]; int xdst[GX_UNITS], rowfix[GX_UNITS], cfix[GX_UNITS];
+    unsigned xbase[GX_UNITS]; int xdst[GX_UNITS], rowfix[GX_UNITS], cfix[GX_UNITS], tfix[GX_UNITS];
+    const bool is3d = p.T > 1;
 #pragma unroll
     for (int i = 0; i < GX_UNITS; ++i) {
         const int u = tid + i * 256;
         const int ci = u / 20, rem = u % 20;
         const int r = rem / 5, q = rem % 5;
         const bool live = u < GX_TOTAL && c0 + ci < p.K;
-        xbase[i] = live ? (unsigned)(((c0 + ci) * HW + (r - 1) * p.W + 4 * q - 1) * 4) : WINO_OOB;
+        const int kt = is3d ? (c0 + ci) / p.cin : 1, cch = is3d ? (c0 + ci) - kt * p.cin : c0 + ci;
+        xbase[i] = live ? (unsigned)((cch * (int)p.cs + (kt - 1) * HW + (r - 1) * p.W + 4 * q - 1) * 4) : WINO_OOB;
+        tfix[i] = (!live || !is3d) ? 0 : (kt == 0 ? 2 * HW * 4 : (kt == 2 ? -2 * HW * 4 : 0));   // frame -1 -> 1, frame T -> T-2
         rowfix[i] = !live ? 0 : (r == 0 ? 2 * p.W * 4 : (r == 3 ? -2 * p.W * 4 : 0));
         cfix[i] = !live ? 0 : (q == 0 ? 4 : (q == 4 ? -12 : 0));       // > 0: holds column -1;  < 0: holds column W
         xdst[i] = u < GX_TOTAL ? ci * GX_STRIDE + r * GX_COLS + q * 4 : -1;
@@ -689,12 +697,14 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         const int rx = region % regions_x; int t = region / regions_x;
         const int ry = t % regions_y; const int img = t / regions_y;
         const int oy0 = ry * GR, ox0 = rx * GC;
-        const int ysoff = (int)(((long)img * p.dy_sn + (long)oy0 * p.W + ox0) * 4);
+        const int smp = img / p.T, frm = img - smp * p.T;             // (sample, frame); T = 1 for the 2-D layers
+        const int ysoff = (int)(((long)smp * p.dy_sn + (long)frm * HW + (long)oy0 * p.W + ox0) * 4);
 #pragma unroll
         for (int i = 0; i < GY_UNITS; ++i)
             gy[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, yvo[i], ysoff, 0));
-        const unsigned roff = (unsigned)(((long)img * p.x_sn + (long)oy0 * p.W + ox0) * 4);
+        const unsigned roff = (unsigned)(((long)smp * p.x_sn + (long)frm * HW + (long)oy0 * p.W + ox0) * 4);
         const bool top = ry == 0, bot = ry == regions_y - 1, left = rx == 0, right = rx == regions_x - 1; // wave-uniform
+        const bool first = is3d && frm == 0, last = is3d && frm == p.T - 1;
 #pragma unroll
         for (int i = 0; i < GX_UNITS; ++i) {
             unsigned vo = xbase[i] + roff;
@@ -703,9 +713,13 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
             if (p.reflect) {
                 if (top) vo += (unsigned)(rowfix[i] > 0 ? rowfix[i] : 0);
                 if (bot) vo += (unsigned)(rowfix[i] < 0 ? rowfix[i] : 0);
+                if (first) vo += (unsigned)(tfix[i] > 0 ? tfix[i] : 0);
+                if (last) vo += (unsigned)(tfix[i] < 0 ? tfix[i] : 0);
             } else {
                 if (top) vo = rowfix[i] > 0 ? WINO_OOB : vo;
                 if (bot) vo = rowfix[i] < 0 ? WINO_OOB : vo;
+                if (first) vo = tfix[i] > 0 ? WINO_OOB : vo;
+                if (last) vo = tfix[i] < 0 ? WINO_OOB : vo;
             }
             gx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
         }
@@ -1009,18 +1023,18 @@ C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     return (int)((regions + per - 1) / per);
 }
 
-// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 16 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
-C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
-                                int M, int K, int nimg, int H, int W, int reflect, void* stream) {
-    C2M_ENTER();
+// shared launcher of the 2-D and the 3x3x3 weight gradient (T = 1, cin = K for 2-D)
+static int wino_wgrad_launch(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
+                             int M, int K, int nimg, int H, int W, int reflect, int T, int cin, void* stream) {
     if (M <= 0 || K <= 0 || nimg <= 0) return 0;
-    if (H % GR || W % GC) return (int)hipErrorInvalidValue;
-    const long ybytes = 4L * nimg * M * H * W, xbytes = 4L * nimg * K * H * W;
+    if (H % GR || W % GC || T <= 0 || nimg % T || cin <= 0 || K % cin) return (int)hipErrorInvalidValue;
+    const long ybytes = 4L * nimg * M * H * W, xbytes = 4L * nimg * cin * H * W;
     if (ybytes >= 0x80000000LL || xbytes >= 0x80000000LL) return (int)hipErrorInvalidValue;
     WinoWgP p;
     p.dY = dY; p.X = X; p.slab = slab; p.dbslab = dbslab;
     p.M = M; p.K = K; p.nimg = nimg; p.H = H; p.W = W; p.reflect = reflect;
-    p.dy_sn = (long)M * H * W; p.x_sn = (long)K * H * W;
+    p.T = T; p.cin = cin; p.cs = (long)T * H * W;
+    p.dy_sn = (long)M * p.cs; p.x_sn = (long)cin * p.cs;
     p.dy_bytes = (unsigned)ybytes; p.x_bytes = (unsigned)xbytes;
     p.regions = nimg * (H / GR) * (W / GC);
     const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
@@ -1042,4 +1056,20 @@ C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, fl
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(c2m_grid((long)M * K, 256)), dim3(256), 0, s, usum, dbslab, dW, db,
                        M, K, S);
     return (int)hipGetLastError();
+}
+
+// 3x3, stride 1, pad 1 (zeros or reflect), H % 2 == 0, W % 16 == 0.  dY [N][M][H][W], X [N][K][H][W] contiguous.
+C2M_API int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
+                                int M, int K, int nimg, int H, int W, int reflect, void* stream) {
+    C2M_ENTER();
+    return wino_wgrad_launch(dY, X, slab, dbslab, dW, db, M, K, nimg, H, W, reflect, 1, K, stream);
+}
+
+// 3x3x3, stride 1, pad 1: dY [N][M][T][H][W], X [N][Cin][T][H][W]; dW comes out as [M][3][Cin][3][3] (time tap ahead of the
+// channel: the virtual-channel order of the kernel), the caller permutes it to the native [M][Cin][3][3][3].  slab / dbslab as
+// for c2m_conv_wino_wgrad with K = 3 * Cin and nimg = N * T.
+C2M_API int c2m_conv_wino_wgrad3d(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
+                                  int M, int Cin, int N, int T, int H, int W, int reflect, void* stream) {
+    C2M_ENTER();
+    return wino_wgrad_launch(dY, X, slab, dbslab, dW, db, M, 3 * Cin, N * T, H, W, reflect, T, Cin, stream);
 }

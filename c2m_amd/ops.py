@@ -379,7 +379,7 @@ class _ConvPlan:
         # temporal padding is a per-tap frame index (reflected, or a zero-record descriptor).  Data gradient: virtual
         # channels (flipped time tap, output channel) of dY over the padded (T+2, H+2, W+2) domain (reflect; then one
         # fold pass) or the unpadded one (zeros).
-        self.wino3d = False
+        self.wino3d = self.wino_wgrad3d = False
         if not bf16 and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and (pt, ph, pw) == (1, 1, 1):
             rows_ok = lambda m: m >= 48 or 17 <= m <= 32
             regions = N * To * _cdiv(Ho, 8) * _cdiv(Wo, 16)
@@ -402,6 +402,14 @@ class _ConvPlan:
                 self.wino_dgrad_geom = _wino_geom(
                     [dM, 3 * Cout, N * Td, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Td * Hd * Wd, Td * Hd * Wd, Wd,
                      0, 4 * N * Cout * osp], To=Td, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
+            # weight gradient: the 2-D Winograd wgrad kernel over images (sample, frame) and virtual channels (kt, ci)
+            wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, 64)
+            waste = 2048.0 * wg_tiles / (3 * Cin * Cout)
+            if Hi % 2 == 0 and Wi % 16 == 0 and (3 * Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
+                    _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
+                    and N * Ti * (Hi // 2) * (Wi // 16) >= 16 * max(1, 512 // wg_tiles))):
+                self.wino_wgrad = self.wino_wgrad3d = True
+                self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, 3 * Cin, N * Ti, Hi, Wi)
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
@@ -752,7 +760,21 @@ class _ConvFn(torch.autograd.Function):
                            "reflect fold")
             if pl.dM < Cin:
                 gx[:, pl.dM:].zero_()            # channels declared gradient-free by the caller (dgrad_rows)
-        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad:
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:
+            S = pl.wino_wg_splits
+            Ti, Hi, Wi = pl.dims[3:6]
+            slab = torch.empty((S + 1) * 16 * Cout * 3 * Cin, device=x.device, dtype=torch.float32)
+            dbslab = torch.empty(S * Cout, device=x.device, dtype=torch.float32)
+            gw3 = torch.empty(Cout, 3, Cin, 3, 3, device=x.device, dtype=torch.float32)      # (time tap, channel) order
+            gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+                              lambda: L.c2m_conv_wino_wgrad3d(_p(gy), _p(x), _p(slab), _p(dbslab), _p(gw3), _p(gb_t), Cout,
+                                                              Cin, N, Ti, Hi, Wi, int(pl.reflect), _stream()), tag,
+                              4 * (gy.numel() + x.numel() + w.numel())), "conv_wino_wgrad3d")
+            gw = gw3.permute(0, 2, 1, 3, 4).contiguous()
+            gb = gb_t if ctx.has_bias else None
+        elif (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad:
             S = pl.wino_wg_splits
             slab = torch.empty((S + 1) * 16 * Cout * Cin, device=x.device, dtype=torch.float32)
             dbslab = torch.empty(S * Cout, device=x.device, dtype=torch.float32)

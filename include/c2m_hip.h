@@ -100,6 +100,12 @@ int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interio
 int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W);
 int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db, int M, int K,
                         int nimg, int H, int W, int reflect, void* stream);
+/* The same for the 3x3x3 stride-1 pad-1 layers (Conv3d call sites of modules/layers/common.py): image = (sample, frame),
+ * virtual input channels (time tap, channel).  dY [N][M][T][H][W], X [N][Cin][T][H][W]; dW is written as [M][3][Cin][3][3]
+ * (the caller permutes to the native [M][Cin][3][3][3]); slab / dbslab sized for K = 3*Cin, nimg = N*T
+ * (c2m_wino_wgrad_splits(M, 3*Cin, N*T, H, W)). */
+int c2m_conv_wino_wgrad3d(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
+                          int M, int Cin, int N, int T, int H, int W, int reflect, void* stream);
 
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */

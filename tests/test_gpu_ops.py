@@ -148,10 +148,12 @@ def test_conv_winograd_forced(case, monkeypatch):
         (yr * go).sum().backward()
         xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
         y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
-        is3d = len(xs) == 5      # 3x3x3: 2-D Winograd over (time tap, channel) virtual channels; its wgrad stays direct
+        is3d = len(xs) == 5      # 3x3x3: 2-D Winograd kernels over (time tap, channel) virtual channels, image = (n, t)
         pl = ops._plan(xg, wg, (1, 1, 1), (1, 1, 1) if is3d else (0, 1, 1), mode == "reflect")
         assert pl.wino_fwd and pl.wino_dgrad
-        assert pl.wino3d if is3d else pl.wino_wgrad == (xs[2] % 2 == 0 and xs[3] % 16 == 0)
+        keff = (3 if is3d else 1) * xs[1]            # input channels of the Winograd weight gradient (virtual ones in 3-D)
+        assert pl.wino_wgrad == (xs[-2] % 2 == 0 and xs[-1] % 16 == 0 and (keff * cout) % 4 == 0)
+        assert not is3d or (pl.wino3d and pl.wino_wgrad3d == pl.wino_wgrad)
         (y * g(go)).sum().backward()
         rel_close(y, yr, 2e-5, "winograd fwd")
         rel_close(xg.grad, xr.grad, 5e-5, "winograd dgrad")
