@@ -61,6 +61,7 @@ _conv_bf16 = False
 # minimum region fill of a Winograd data-gradient launch: the padded 18x34 domain of the 16x32 reflect layers fills 53 % of its
 # 8x16 regions and still beats the gather kernel by 14-30 % (tools/run_conv.py A/B); the 10x18 domain (35 %) does not
 _WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
+_WINO_MIN_WGS = int(os.environ.get("C2M_WINO_MIN_WGS", "128"))   # smallest Winograd forward / dgrad grid: 160 workgroups of a 1536-deep layer still beat the gather kernel 1.5x
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
 # the direct kernel, "off", "force" (tests: every eligible shape).
@@ -358,7 +359,7 @@ class _ConvPlan:
             # workgroups per CU), which beats the direct kernels' 32-row tiles
             rows_ok = lambda m: m >= 48 or 17 <= m <= 32
             if _WINO == "force" or (_WINO == "auto" and fit and Cin >= 32 and rows_ok(Cout) and
-                                    regions * _cdiv(Cout, 64) >= 256):
+                                    regions * _cdiv(Cout, 64) >= _WINO_MIN_WGS):
                 self.wino_fwd = True
                 self.wino_fwd_geom = _wino_geom([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
                                                  Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc])
@@ -368,7 +369,7 @@ class _ConvPlan:
             dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
             dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
             if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
-                                                   dregions * _cdiv(Cin, 64) >= 256)):
+                                                   dregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS)):
                 self.wino_dgrad = True
                 o = -2 if reflect else -1
                 self.wino_dgrad_geom = _wino_geom(
@@ -386,7 +387,7 @@ class _ConvPlan:
             fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
             hw_i, hw_o = Hi * Wi, Ho * Wo
             if _WINO == "force" or (_WINO == "auto" and fit and 3 * Cin >= 32 and rows_ok(Cout) and
-                                    regions * _cdiv(Cout, 64) >= 256):
+                                    regions * _cdiv(Cout, 64) >= _WINO_MIN_WGS):
                 self.wino_fwd = self.wino3d = True
                 self.wino_fwd_geom = _wino_geom(
                     [Cout, 3 * Cin, N * To, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi, Cout * osp, osp, Wo,
@@ -396,7 +397,7 @@ class _ConvPlan:
             dregions = N * Td * _cdiv(Hd, 8) * _cdiv(Wd, 16)
             dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
             if _WINO == "force" or (_WINO == "auto" and dfit and 3 * Cout >= 32 and rows_ok(dM) and
-                                    dregions * _cdiv(dM, 64) >= 256):
+                                    dregions * _cdiv(dM, 64) >= _WINO_MIN_WGS):
                 self.wino_dgrad = self.wino3d = True
                 o = -2 if reflect else -1
                 self.wino_dgrad_geom = _wino_geom(
