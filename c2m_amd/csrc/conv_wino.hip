@@ -610,7 +610,6 @@ constexpr int GR = 2, GC = 16, GT = 8;               // region rows, cols, tiles
 constexpr int GY_STRIDE = GR * GC + 2;               // 34: dY patch [co][2][16] + 2 pad
 constexpr int GX_COLS = GC + 4;                      // 20: image columns ox0-1 .. ox0+18 as five 16-byte units (4-B aligned)
 constexpr int GX_STRIDE = 4 * GX_COLS + 6;           // 86: X patch [ci][4][20] + 6 pad
-constexpr int GY_UNITS = 64 * GR * (GC / 4) / 256;   // 2 float4 per thread and chunk
 
 // v_pk_add_f32 form the compiler does not emit: (t.x + t.y, t.x - t.y)
 static __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 t) {
@@ -621,12 +620,15 @@ static __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 t) {
 
 // NI = 32-wide input-channel tiles per workgroup: NI = 2 -> 64 x 64 channels, 256 accumulator registers, one workgroup per
 // CU; NI = 1 -> 64 x 32 channels, 128 accumulators, two workgroups per CU (their barriers / refills / epilogues overlap).
-template <int NI>
-__global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(const WinoWgP p) {
+// MI = 32-row output-channel tiles per workgroup: 2 (64 x 32 channels) or 1 (Cout <= 32: 32 x 32 channels, 64 accumulators,
+// three workgroups per CU -- half the MFMAs per k-step of the 64-row tile, none of them on empty rows).
+template <int NI, int MI>
+__global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_wino_wgrad_kernel(const WinoWgP p) {
+    constexpr int GY_UNITS = MI;                                   // dY float4 units per thread and chunk (32*MI co x 2 x 4 / 256)
     constexpr int NCI = 32 * NI;
     constexpr int GX_TOTAL = NCI * 4 * (GX_COLS / 4);              // 640 (NI = 1) / 1280 units per chunk
     constexpr int GX_UNITS = (GX_TOTAL + 255) / 256;               // 3 / 5 float4 per thread and chunk
-    __shared__ float pY[2][64 * GY_STRIDE];
+    __shared__ float pY[2][32 * MI * GY_STRIDE];
     __shared__ float pX[2][NCI * GX_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -638,11 +640,11 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         const unsigned L = blockIdx.x, total = gridDim.x;
         const unsigned q = total >> 3, r = total & 7u, x = L & 7u, j = L >> 3;
         const unsigned w = x * q + (x < r ? x : r) + j;
-        const unsigned mtiles = (unsigned)(p.M + 63) / 64, ntiles = (unsigned)(p.K + NCI - 1) / NCI;
+        const unsigned mtiles = (unsigned)(p.M + 32 * MI - 1) / (32 * MI), ntiles = (unsigned)(p.K + NCI - 1) / NCI;
         const unsigned t = w % (mtiles * ntiles);
         split = (int)(w / (mtiles * ntiles)); mt = (int)(t % mtiles); nt = (int)(t / mtiles);
     }
-    const int m0 = mt * 64, c0 = nt * NCI;
+    const int m0 = mt * 32 * MI, c0 = nt * NCI;
     const int HW = p.H * p.W;
     const int rbeg = split * p.per_split;
     int rend = rbeg + p.per_split; rend = rend < p.regions ? rend : p.regions;
@@ -779,24 +781,24 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     const int xoff_a = cl * GX_STRIDE + ra * GX_COLS + 2 * kl;      // + q * 32 * GX_STRIDE + 4 * ks: local column 2t, t = 2ks + kl
     const int xoff_b = cl * GX_STRIDE + rb * GX_COLS + 2 * kl;
 
-    f32x16 acc[4][2][NI];
+    f32x16 acc[4][MI][NI];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][mi][ni][r] = 0.f;
 
-    struct Raw { f32x2 y0[2], y1[2]; f32x2 a0[NI], a1[NI], b0[NI], b1[NI]; };
-    struct Frag { float a[2][4], b[NI][4]; };
+    struct Raw { f32x2 y0[MI], y1[MI]; f32x2 a0[NI], a1[NI], b0[NI], b1[NI]; };
+    struct Frag { float a[MI][4], b[NI][4]; };
     auto load_raw = [&](int buf, int ks, Raw& r) {
 #ifdef WG_DIAG_NOLDS        // timing diagnostics only: no LDS reads
         {
             const f32x2 c = {1.f + ks, 2.f + buf};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { r.y0[q] = c; r.y1[q] = c; }
+            for (int q = 0; q < MI; ++q) { r.y0[q] = c; r.y1[q] = c; }
 #pragma unroll
             for (int q = 0; q < NI; ++q) { r.a0[q] = c; r.a1[q] = c; r.b0[q] = c; r.b1[q] = c; }
             return;
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         const float* __restrict__ py = &pY[buf][0];
         const float* __restrict__ px = &pX[buf][0];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < MI; ++q) {
             const int yo = yoff + q * 32 * GY_STRIDE + 4 * ks;
             r.y0[q] = *reinterpret_cast<const f32x2*>(py + yo);
             r.y1[q] = *reinterpret_cast<const f32x2*>(py + yo + GC);
@@ -842,13 +844,13 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
     };
     auto transform = [&](const Raw& r, Frag& f) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) transform_y(r, f, q);
+        for (int q = 0; q < MI; ++q) transform_y(r, f, q);
 #pragma unroll
         for (int q = 0; q < NI; ++q) transform_x(r, f, q);
     };
     auto mma_j = [&](const Frag& f, int j) {           // the 2 * NI MFMAs of frequency column j
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[j][mi][ni], 0, 0, 0);
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
         transform_y(rw, FNEXT, 0);                                                \
         __builtin_amdgcn_sched_barrier(0);                                        \
         mma_j(FCUR, 1);                                                           \
-        transform_y(rw, FNEXT, 1);                                                \
+        if constexpr (MI == 2) transform_y(rw, FNEXT, 1);                         \
         __builtin_amdgcn_sched_barrier(0);                                        \
         mma_j(FCUR, 2);                                                           \
         _Pragma("unroll") for (int q_ = 0; q_ < NI; ++q_) transform_x(rw, FNEXT, q_); \
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256, NI == 1 ? 2 : 1) void conv_wino_wgrad_kernel(c
             if (ci >= p.K) continue;
             float* __restrict__ col = out + ((long)xi * p.K + ci) * p.M;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = m0 + mi * 32 + 8 * g + 4 * (lane >> 5);
@@ -1012,8 +1014,9 @@ static int wino_wg_ni(int M, int K) { (void)M; (void)K; return 1; }
 C2M_API int c2m_wino_wgrad_splits(int M, int K, int nimg, int H, int W) {
     const long regions = (long)nimg * (H / GR) * (W / GC);
     const int ni = wino_wg_ni(M, K);
-    const long tiles = (long)c2m_cdiv(M, 64) * c2m_cdiv(K, 32 * ni);
-    long S = (ni == 1 ? 512 : 256) / tiles;     // one resident round: 256 CUs x (1 | 2) workgroups
+    const int mrows = M <= 32 ? 32 : 64;        // 32-row variant for Cout <= 32 (three workgroups per CU)
+    const long tiles = (long)c2m_cdiv(M, mrows) * c2m_cdiv(K, 32 * ni);
+    long S = (mrows == 32 ? 768 : (ni == 1 ? 512 : 256)) / tiles;     // one resident round: 256 CUs x (3 | 2 | 1) workgroups
     if (S < 1) S = 1;
     const long maxS = (regions + 15) / 16;      // >= 16 regions (128 tiles) per split
     if (S > maxS) S = maxS;
@@ -1040,9 +1043,11 @@ static int wino_wgrad_launch(const float* dY, const float* X, float* slab, float
     const int S = c2m_wino_wgrad_splits(M, K, nimg, H, W);
     p.per_split = c2m_cdiv(p.regions, S);
     const int ni = wino_wg_ni(M, K);
-    dim3 grid((unsigned)S * c2m_cdiv(M, 64) * c2m_cdiv(K, 32 * ni));
+    const int mrows = M <= 32 ? 32 : 64;
+    dim3 grid((unsigned)S * c2m_cdiv(M, mrows) * c2m_cdiv(K, 32 * ni));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wino_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
+    if (mrows == 32) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
+    else             hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long n = 16L * M * K;

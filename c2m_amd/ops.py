@@ -344,13 +344,14 @@ class _ConvPlan:
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
-            wg_tiles = _cdiv(Cin, 32) * _cdiv(Cout, 64)           # workgroup tile: 64 output x 32 input channels
+            wrows = 32 if Cout <= 32 else 64                      # workgroup tile: 64 (32 for Cout <= 32) output x 32 input channels
+            wg_tiles = _cdiv(Cin, 32) * _cdiv(Cout, wrows)
             # A/B against the direct kernel (tools/ab_wino_wgrad.py, AB_EXTRA=1 for the marginal shapes): the Winograd form
-            # wins 1.1-1.3x even on a half-empty 64-row tile (Cout = 32) as long as there are two tiles; 32 -> 32 loses
-            waste = 2048.0 * wg_tiles / (Cin * Cout)
+            # wins 1.1-1.3x even on a half-empty 64-row tile as long as there are two tiles
+            waste = 32.0 * wrows * wg_tiles / (Cin * Cout)
             if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
                     _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
-                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, 512 // wg_tiles))):
+                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
@@ -404,11 +405,12 @@ class _ConvPlan:
                     [dM, 3 * Cout, N * Td, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Td * Hd * Wd, Td * Hd * Wd, Wd,
                      0, 4 * N * Cout * osp], To=Td, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
             # weight gradient: the 2-D Winograd wgrad kernel over images (sample, frame) and virtual channels (kt, ci)
-            wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, 64)
-            waste = 2048.0 * wg_tiles / (3 * Cin * Cout)
+            wrows = 32 if Cout <= 32 else 64
+            wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, wrows)
+            waste = 32.0 * wrows * wg_tiles / (3 * Cin * Cout)
             if Hi % 2 == 0 and Wi % 16 == 0 and (3 * Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
                     _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
-                    and N * Ti * (Hi // 2) * (Wi // 16) >= 16 * max(1, 512 // wg_tiles))):
+                    and N * Ti * (Hi // 2) * (Wi // 16) >= 16 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
                 self.wino_wgrad = self.wino_wgrad3d = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, 3 * Cin, N * Ti, Hi, Wi)
         # ---- forward
