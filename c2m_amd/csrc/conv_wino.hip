@@ -622,14 +622,18 @@ static __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 t) {
 // CU; NI = 1 -> 64 x 32 channels, 128 accumulators, two workgroups per CU (their barriers / refills / epilogues overlap).
 // MI = 32-row output-channel tiles per workgroup: 2 (64 x 32 channels) or 1 (Cout <= 32: 32 x 32 channels, 64 accumulators,
 // three workgroups per CU -- half the MFMAs per k-step of the 64-row tile, none of them on empty rows).
-template <int NI, int MI>
+// NB = LDS patch buffers: 2 (the refill of chunk c + 1 is loaded and stored during chunk c) or 3 (loaded during chunk c - 1,
+// stored at the top of chunk c: a whole chunk in flight).  The 32-row variant's chunk is only 16 MFMAs per wave, shorter than
+// the L2 / HBM latency of its refill -- with two buffers the 32 -> 32-channel layer ran 34 % MFMA-busy on ~2.9 TB/s of L2
+// reads; the 64-row variant measured 3 % SLOWER with three buffers and keeps two.
+template <int NI, int MI, int NB>
 __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_wino_wgrad_kernel(const WinoWgP p) {
     constexpr int GY_UNITS = MI;                                   // dY float4 units per thread and chunk (32*MI co x 2 x 4 / 256)
     constexpr int NCI = 32 * NI;
     constexpr int GX_TOTAL = NCI * 4 * (GX_COLS / 4);              // 640 (NI = 1) / 1280 units per chunk
     constexpr int GX_UNITS = (GX_TOTAL + 255) / 256;               // 3 / 5 float4 per thread and chunk
-    __shared__ float pY[2][32 * MI * GY_STRIDE];
-    __shared__ float pX[2][NCI * GX_STRIDE];
+    __shared__ float pY[NB][32 * MI * GY_STRIDE];
+    __shared__ float pX[NB][NCI * GX_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work order (see conv_wino_kernel): item w = split * tiles + tile.  All channel tiles of a split read the
@@ -881,35 +885,51 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
     if (nchunks > 0) {
         fetch(rbeg);
         stash(rbeg, 0);
+        if (NB == 3 && nchunks > 1) fetch(rbeg + 1);
         __syncthreads();
         Frag fa, fb;
         Raw rw;
         load_raw(0, 0, rw);
         transform(rw, fa);
         load_raw(0, 1, rw);
-        // the chunk loop is written for buffer 0 and buffer 1 explicitly: with a run-time buffer index every k-step spent
-        // four VALU on LDS addresses right behind its first MFMA; as constants they are the offset fields of the reads
-#define WG_CHUNK(CUR)                                                                                  \
+        // the chunk loop is written out per buffer: with a run-time buffer index every k-step spent four VALU on LDS
+        // addresses right behind its first MFMA; as constants they are the offset fields of the reads
+#define WG_CHUNK(CUR, NXT)                                                                             \
         {                                                                                              \
             const bool more = chunk + 1 < nchunks;                                                     \
-            if (more) fetch(rbeg + chunk + 1);               /* lands during k-steps 0 and 1 */        \
+            if (NB == 3) {                                   /* refill loaded during the previous chunk */ \
+                if (more) { stash(rbeg + chunk + 1, NXT); if (chunk + 2 < nchunks) fetch(rbeg + chunk + 2); } \
+            } else if (more) fetch(rbeg + chunk + 1);        /* lands during k-steps 0 and 1 */        \
             WG_STEP(CUR, 2, fa, fb);                         /* MFMAs of k-step 0, transform of 1, raw reads of 2 */ \
             WG_STEP(CUR, 3, fb, fa);                         /* k-step 1: the last raw reads of buffer CUR */ \
-            if (more) stash(rbeg + chunk + 1, (CUR) ^ 1);    /* buffer CUR ^ 1 was last read before the previous barrier */ \
+            if (NB == 2 && more) stash(rbeg + chunk + 1, NXT);   /* buffer NXT was last read before the previous barrier */ \
             __syncthreads();                                                                           \
             /* k-steps 2 and 3 + the first two raw sets of the next chunk (last chunk: stale LDS data, transformed and */ \
             /* dropped -- keeps the accumulators out of a conditional path) */                         \
-            WG_STEP((CUR) ^ 1, 0, fa, fb);                                                             \
-            WG_STEP((CUR) ^ 1, 1, fb, fa);                                                             \
+            WG_STEP(NXT, 0, fa, fb);                                                                   \
+            WG_STEP(NXT, 1, fb, fa);                                                                   \
         }
         int chunk = 0;
-        for (; chunk + 1 < nchunks; chunk += 2) {
-            WG_CHUNK(0)
-            ++chunk;
-            WG_CHUNK(1)
-            --chunk;
+        if (NB == 2) {
+            for (; chunk + 1 < nchunks; chunk += 2) {
+                WG_CHUNK(0, 1)
+                ++chunk;
+                WG_CHUNK(1, 0)
+                --chunk;
+            }
+            if (chunk < nchunks) WG_CHUNK(0, 1)
+        } else {
+            for (; chunk + 2 < nchunks; chunk += 3) {
+                WG_CHUNK(0, 1)
+                ++chunk;
+                WG_CHUNK(1, NB - 1)
+                ++chunk;
+                WG_CHUNK(NB - 1, 0)
+                chunk -= 2;
+            }
+            if (chunk < nchunks) { WG_CHUNK(0, 1) ++chunk; }
+            if (chunk < nchunks) { WG_CHUNK(1, NB - 1) }
         }
-        if (chunk < nchunks) WG_CHUNK(0)
 #undef WG_CHUNK
     }
 #undef WG_STEP
@@ -955,18 +975,34 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
     }
 }
 
-// Stage 1: u[e] = sum_s slab[s][e] over the 16*M*K elements (fixed order; 16-byte loads, four splits in flight).
-__global__ void wino_slab_sum_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ u, long n4, int S) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 acc = slab[i];
-        int s = 1;
-        for (; s + 3 < S; s += 4) {
-            const f32x4 a = slab[(long)s * n4 + i], b = slab[(long)(s + 1) * n4 + i], c = slab[(long)(s + 2) * n4 + i],
-                        d = slab[(long)(s + 3) * n4 + i];
-            acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
+// Stage 1: u[e] = sum_s slab[s][e] over the 16*M*K elements, fixed order.  A workgroup = 16 float4 elements x 16 split lanes:
+// lane sl sums the splits sl, sl + 16, ... (four loads in flight), the 16 partial sums are combined in order through LDS.
+// The first form gave every element ONE thread that walked all S splits: with few channels (16*M*K/4 = 4096 float4 at
+// 32 x 32 channels) that was 16 workgroups each chasing 768 dependent loads -- ~200 us of a 400 us launch.
+__global__ __launch_bounds__(256) void wino_slab_sum_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ u, long n4, int S) {
+    __shared__ f32x4 part[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (long base = (long)blockIdx.x * 16; base < n4; base += (long)gridDim.x * 16) {
+        const long i = base + el;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            int s = sl;
+            for (; s + 48 < S; s += 64) {
+                const f32x4 a = slab[(long)s * n4 + i], b = slab[(long)(s + 16) * n4 + i], c = slab[(long)(s + 32) * n4 + i],
+                            d = slab[(long)(s + 48) * n4 + i];
+                acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
+            }
+            for (; s < S; s += 16) acc = acc + slab[(long)s * n4 + i];
         }
-        for (; s < S; ++s) acc = acc + slab[(long)s * n4 + i];
-        u[i] = acc;
+        part[sl][el] = acc;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            f32x4 t = part[0][el];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t = t + part[k][el];
+            u[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -996,10 +1032,17 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ usum, const f
         }
     }
     if (db) {
-        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        // 16 lanes per output channel, lane sl sums the splits sl, sl + 16, ...; fixed-order butterfly over the 16 partial sums.
+        // (One thread per channel walking all S splits was 180 us of dependent loads at S = 768 -- the 32-channel layers.)
+        const long total16 = (long)M * 16;
+        const long stride = (long)gridDim.x * blockDim.x;        // a multiple of 16
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < ((total16 + 15) & ~15L); i += stride) {
+            const int m = (int)(i >> 4), sl = (int)(i & 15);
             float acc = 0.f;
-            for (int s = 0; s < S; ++s) acc += dbslab[(long)s * M + m];
-            db[m] = acc;
+            if (m < M)
+                for (int s = sl; s < S; s += 16) acc += dbslab[(long)s * M + m];
+            acc += __shfl_xor(acc, 8, 16); acc += __shfl_xor(acc, 4, 16); acc += __shfl_xor(acc, 2, 16); acc += __shfl_xor(acc, 1, 16);
+            if (sl == 0 && m < M) db[m] = acc;
         }
     }
 }
@@ -1046,14 +1089,14 @@ static int wino_wgrad_launch(const float* dY, const float* X, float* slab, float
     const int mrows = M <= 32 ? 32 : 64;
     dim3 grid((unsigned)S * c2m_cdiv(M, mrows) * c2m_cdiv(K, 32 * ni));
     hipStream_t s = (hipStream_t)stream;
-    if (mrows == 32) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
-    else             hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, p);
+    if (mrows == 32) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p);
+    else             hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2, 2>), grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const long n = 16L * M * K;
     float* usum = slab + (long)S * n;
     if ((n & 3) == 0) {
-        hipLaunchKernelGGL(wino_slab_sum_kernel, dim3(c2m_grid(n / 4, 256)), dim3(256), 0, s, (const f32x4*)slab,
+        hipLaunchKernelGGL(wino_slab_sum_kernel, dim3(c2m_grid(n / 4, 16)), dim3(256), 0, s, (const f32x4*)slab,
                            (f32x4*)usum, n / 4, S);
     } else {
         return (int)hipErrorInvalidValue;       // M*K is a multiple of 4 for every layer the host routes here (checked there)
