@@ -351,7 +351,7 @@ class _ConvPlan:
             waste = 32.0 * wrows * wg_tiles / (Cin * Cout)
             if Hi % 2 == 0 and Wi % 16 == 0 and (Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
                     _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
-                    and N * (Hi // 2) * (Wi // 16) >= 16 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
+                    and N * (Hi // 2) * (Wi // 16) >= 8 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
             regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
@@ -410,7 +410,7 @@ class _ConvPlan:
             waste = 32.0 * wrows * wg_tiles / (3 * Cin * Cout)
             if Hi % 2 == 0 and Wi % 16 == 0 and (3 * Cin * Cout) % 4 == 0 and (_WINO_WGRAD == "force" or (
                     _WINO_WGRAD == "auto" and (waste <= 1.35 or (waste <= 2.0 and wg_tiles >= 2))
-                    and N * Ti * (Hi // 2) * (Wi // 16) >= 16 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
+                    and N * Ti * (Hi // 2) * (Wi // 16) >= 8 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
                 self.wino_wgrad = self.wino_wgrad3d = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, 3 * Cin, N * Ti, Hi, Wi)
         # ---- forward
