@@ -348,10 +348,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // 16-byte stores (round 2): a thread owns FOUR consecutive x of one output row and two of the 16 output channels of a
     // pass, so a pass is 2 store instructions per thread instead of 8 dword stores -- the store path of a CU takes ~5 B/clk
     // in dword stores, which made the epilogue 8 % (K = 256) to 30 % (K = 64) of the kernel.
-    const bool vec_ok = (p.Wo & 3) == 0 && (p.out_sh & 3) == 0 && (p.out_sc & 3) == 0 && (p.out_sn & 3) == 0 &&
-                        (p.out_off & 3) == 0 && (((unsigned long)p.Y) & 15) == 0 &&
-                        (((unsigned long)p.Y2) & 3) == 0;
-    if (vec_ok) {
+    // The stores are 4-byte aligned vector stores, so any row length / stride works: a group that crosses the end of its
+    // row -- padded domains are W + 2 wide -- is stored per pixel.  (The first version of this path required W % 4 == 0 and
+    // left every reflect data gradient on a dword-store form.)
+    {
         const int e4 = tid & 3, ey = (tid >> 2) & 7, cg = tid >> 5;
         const int oy = oy0 + ey, ox = ox0 + 4 * e4;
         const bool inb = oy < p.Ho && ox < p.Wo;
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
             // (fine for global_store_dwordx4); groups that straddle the interior's edge are stored per pixel
             mode = (in0 && in3) ? 1 : ((in0 || in1 || in2 || in3) ? 2 : 0);
         }
+        if (ox + 3 >= p.Wo && mode == 0) mode = 2;    // the group crosses the end of the row
         const int tile0 = (ey >> 1) * 8 + 2 * e4;
         const int ro = top ? 0 : 3 * 16 * 32;        // row combined with r1, r2: r0 (top) or r3 (bottom)
 #pragma unroll
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
                         if (mode == 2) {
 #pragma unroll
                             for (int dx = 0; dx < 4; ++dx) {
+                                if (ox + dx >= p.Wo) continue;
                                 if ((unsigned)(xi + dx) < (unsigned)p.ext_x) yb1[(long)cout * cs1 + dx] = v[dx];
                                 else yb0[(long)cout * cs0 + dx] = v[dx];
                             }
@@ -414,54 +416,6 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
                             *reinterpret_cast<f32x4u*>((mode ? yb1 : yb0) + (long)cout * (mode ? cs1 : cs0)) = vv;
                         }
                     }
-                }
-            }
-        }
-        return;
-    }
-    const int ex = tid & 15, ey = (tid >> 4) & 7, c0 = tid >> 7;
-    const int oy = oy0 + ey, ox = ox0 + ex;
-    const bool inb = oy < p.Ho && ox < p.Wo;
-    const bool top = (ey & 1) == 0;
-    float* __restrict__ ybase;
-    long cstride;
-    {
-        const int yi = oy - p.lo_y, xi = ox - p.lo_x;
-        if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y && (unsigned)xi < (unsigned)p.ext_x) {
-            ybase = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
-            cstride = p.y2_sc;
-        } else {
-            ybase = p.Y + p.out_off + (long)smp * p.out_sn + (long)frm * p.out_st + (long)oy * p.out_sh + ox;
-            cstride = p.out_sc;
-        }
-    }
-    // R rows this pixel combines: top row r0 + r1 + r2, bottom row r1 - r2 - r3; `rq` points at r1, `ro` at r0 or r3
-    const float* __restrict__ rq = sR + (ex & 1) * QS + (1 * 16 + c0) * 32 + (ey >> 1) * 8 + (ex >> 1);
-    const int ro = top ? -16 * 32 : 2 * 16 * 32;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {               // accumulator registers r in [8hf, 8hf + 8) = tile rows 16hf .. 16hf+15
-            __syncthreads();
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = hf * 8 + rr;
-                const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);        // 0..15 within the half
-                sR[0 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
-                sR[1 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
-            }
-            __syncthreads();
-            // 16 couts x 8 rows x 16 columns; consecutive threads -> consecutive x (64-byte row segments)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int co = c0 + 2 * it;
-                const float r1 = rq[co * 32 - c0 * 32], r2 = rq[co * 32 - c0 * 32 + 16 * 32], rx = rq[co * 32 - c0 * 32 + ro];
-                float v = top ? (rx + r1) + r2 : (r1 - r2) - rx;
-                const int cout = m0 + mi * 32 + hf * 16 + co;
-                if (inb && cout < p.M) {
-                    if (p.bias) v += p.bias[cout];
-                    v = c2m_act(v, p.act, p.slope);
-                    ybase[(long)cout * cstride] = v;
                 }
             }
         }
