@@ -131,12 +131,58 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     torch.set_num_threads(prev)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": best, "kind": "port",
+    # host-saturating figure: P independent replicas (one clip each) x the best thread count, all running at once
+    saturated = None
+    P = min(phys // best, 16)
+    if P > 1:
+        h_, w_ = cfg["train_params"]["input_size"]
+        env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(best), "--height", str(h_), "--width", str(w_)]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(P)]
+        per = []
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=240)
+                per += [float(l.split()[1]) for l in out.splitlines() if l.startswith("CPU_WORKER_S_PER_STEP")]
+            except Exception:
+                pr.kill()
+        if len(per) == P:
+            per.sort()
+            saturated = {"value": round(P * 7.0 / per[len(per) // 2], 3), "unit": "frames/s", "processes": P,
+                         "threads_each": best, "cores": P * best,
+                         "sample": f"{P} concurrent replicas x 2 timed steps of 1 clip each, median replica {per[len(per) // 2]:.3f} s/step"}
+    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": best, "kind": "port", "saturated": saturated,
             "host": f"{_cpu_model()}, {phys} physical cores visible",
             "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "reference_code_datapoint": "the reference itself, build container (8 vCPU): 3.0 frames/s G-only (SURVEY.md 6)",
             "sample": f"{len(times)} timed steps of 1 clip (B=1, 7 frames, {h}x{w}, G-only fwd+bwd) at {best} threads "
                       f"(best of the sweep); median {med:.3f} s/step"}
+
+
+def _cpu_worker(nthreads, height, width):
+    """One replica of the saturated cpu_baseline leg: oracle fwd + bwd of one clip, `nthreads` threads; prints s/step."""
+    from oracle import c2m_oracle as O
+    import copy
+    torch.set_num_threads(nthreads)
+    cfg = bench_config(height, width, False)
+    torch.manual_seed(0)
+    model = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
+                               model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    del model
+    batch = make_batch(1, height, width, 2, seed=0)
+    rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=0)
+    ts = []
+    for it in range(3):
+        S = O.State(sd)
+        b = dict(batch)
+        b["tracking_gnn"] = batch["tracking_gnn"].clone()
+        t0 = time.time()
+        _, lg, _, _ = O.forward(S, cfg, b, rng)
+        O.train_step_backward(cfg, lg, {}, {})
+        if it:
+            ts.append(time.time() - t0)
+    print(f"CPU_WORKER_S_PER_STEP {sum(ts) / len(ts):.4f}", flush=True)
 
 
 def _free_port():
@@ -173,8 +219,8 @@ def _family(s, names, divide=1.0, peak=PEAK_FP32_MFMA_TFLOPS, step_s=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=1,
                     help="BASELINE.json configs[k]: 1 = the metric's configuration (default); 2 = 256x512 B4 bf16 full step; "
                          "3 = 128x256 B8/rank bf16 full step; 4 = 256x512, 2 x 7-frame windows, bf16 full step")
@@ -194,11 +240,16 @@ def main():
                     help="after the run, verify that every rank holds bit-identical (all-reduced) gradients "
                          "(always on when N > 1)")
     ap.add_argument("--graph", action="store_true",
-                    help="side measurement: capture zero_grad + forward + backward into a HIP graph and time replays (single "
-                         "GPU only; no per-kernel events, so no roofline object)")
+                    help="side measurement: capture zero_grad + forward + backward into a HIP graph and time replays (no "
+                         "per-kernel events, so no roofline object; with N > 1 the all-reduces run eagerly after each replay)")
+    ap.add_argument("--fp32-allreduce", action="store_true",
+                    help="keep fp32 gradient buckets on the wire in the bf16 configurations (default there: bf16 copies)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return _cpu_worker(args.cpu_worker, args.height or 128, args.width or 256)
     for k, v in CONFIGS[args.config].items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -226,8 +277,10 @@ def main():
                                model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
     model.to(dev).train()
     distributed = world > 1 or args.force_reducer
+    # bf16 configurations all-reduce bf16 copies of the fp32 gradient buckets (212 MB instead of 424 MB)
+    comm_dtype = torch.bfloat16 if (args.dtype == "bf16" and not args.fp32_allreduce) else torch.float32
     step = TrainStep(model, run_optimizers=args.full_step, distributed=distributed,
-                     force_collectives=args.force_reducer, measure_comm=True)
+                     force_collectives=args.force_reducer, measure_comm=True, comm_dtype=comm_dtype)
     clips = args.batch * args.windows
     batch = batch_to(make_stream_batch(args.batch, args.windows, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)
@@ -239,8 +292,6 @@ def main():
         torch.cuda.synchronize(dev)
 
     import contextlib
-    if args.graph and distributed:
-        raise SystemExit("bench.py: --graph is a single-GPU side measurement")
     gctx = torch.cuda.stream(step.graph_stream) if args.graph else contextlib.nullcontext()
     with gctx:                                  # with --graph every step (eager warm-up included) runs on the capture stream
         for _ in range(args.warmup):
@@ -288,6 +339,8 @@ def main():
     if step.reducer is not None:
         result["allreduce_bytes_per_step"] = step.reducer.bytes_per_step()
         result["allreduce_buckets"] = len(step.reducer.buckets)
+        result["allreduce_dtype"] = "bf16" if comm_dtype == torch.bfloat16 else "f32"
+        result["allreduce_op"] = "avg" if step.reducer.use_avg else "pre-divide + sum"
         ex = step.reducer.exposed_ms()
         if ex is not None and world > 1:
             t = torch.tensor([ex], device=dev, dtype=torch.float64)
@@ -327,13 +380,21 @@ def main():
             nbytes = sum(d["bytes"] for d in s.values())
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json); counters cannot be read from inside the process
+            # of the SAME build: the file records the conv launches per step it was taken at, and a different count here
+            # (a kernel was added / fused since) makes it stale -> traffic null, with the reason
             traffic, traffic_src = None, None
-            tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tp) and args.config == 1 and (args.batch, args.windows, args.height, args.width) == (8, 1, 128, 256) \
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            if cands and args.config == 1 and (args.batch, args.windows, args.height, args.width) == (8, 1, 128, 256) \
                     and args.dtype == "f32" and not args.full_step:
-                with open(tp) as f:
+                with open(cands[-1]) as f:
                     tj = json.load(f)
-                traffic, traffic_src = tj["conv"]["traffic_bytes_per_launch"], tj["note"]
+                taken_at = tj["conv"].get("launches_per_step")
+                if taken_at is not None and abs(float(taken_at) - nl / args.steps) < 0.5:
+                    traffic, traffic_src = tj["conv"]["traffic_bytes_per_launch"], os.path.basename(cands[-1]) + ": " + tj["note"]
+                else:
+                    traffic_src = (f"{os.path.basename(cands[-1])} is stale: taken at {taken_at} conv launches/step, this build "
+                                   f"runs {nl / args.steps:.1f}; regenerate with tools/prof_round.sh")
             result["roofline"] = {
                 "bound": "mfma",
                 "kernel": "all conv MFMA launches: conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (forward, "

@@ -793,9 +793,14 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                // channels beyond Cin only meet zero weights (the packed rows are zero-padded); they read finite data or 0
-                const int soff = (chunk * 16 + phalf[r] * 8 + j) * p.in_sc * 4;
-                pv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvo[r], soff, 0));
+                // channels past Cin (the last chunk of a Cin % 16 != 0 layer): the scalar offset is NOT range-checked by the
+                // hardware, so they get a zero-record descriptor (wave-uniform select, SALU only) and read 0 -- never the
+                // memory behind X (a NaN there times the zero-padded weight would poison the pixel)
+                const int ch = chunk * 16 + phalf[r] * 8 + j;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.X), 0, ch < p.cin ? p.x_bytes : 0, 0x00020000);
+                const int soff = ch * p.in_sc * 4;
+                pv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pvo[r], soff, 0));
             }
     };
     auto stash_patch = [&](int buf, const float (&pv)[3][8]) {

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
         ydst[i] = co * GY_STRIDE + row * GC + q * 4;
     }
     unsigned xbase[GX_UNITS]; int xdst[GX_UNITS], rowfix[GX_UNITS], cfix[GX_UNITS], tfix[GX_UNITS];
-    const bool is3d = p.T > 1;
+    const bool is3d = p.cin != p.K;              // virtual channels (time tap, channel); NOT `T > 1`: a one-frame 3x3x3 layer is still 3-D
 #pragma unroll
     for (int i = 0; i < GX_UNITS; ++i) {
         const int u = tid + i * 256;

@@ -154,18 +154,66 @@ __global__ void warp_inv_fill_kernel(const WarpInvP p, int* __restrict__ cursor,
     }
 }
 
-// per source pixel: sort its bucket by key in place (insertion sort; buckets hold ~4 entries for a smooth flow)
+// per source pixel: sort its bucket by key in place.  Buckets hold ~4 entries for a smooth flow: insertion sort by the
+// owning thread up to WARP_SMALL_BUCKET entries.  Larger buckets (a diverged flow collapses whole rows or regions onto a
+// border pixel: 1e4 - 1e5 entries) are queued for warp_inv_sort_big_kernel -- a single-thread insertion sort would be
+// O(n^2) dependent global accesses, a multi-second kernel that looks like a hang.
+constexpr int WARP_SMALL_BUCKET = 32;
+
 __global__ void warp_inv_sort_kernel(const int* __restrict__ count, const int* __restrict__ offset,
-                                     int* __restrict__ keys, float* __restrict__ vals, long nimg, int HW) {
+                                     int* __restrict__ keys, float* __restrict__ vals, long nimg, int HW,
+                                     int* __restrict__ nbig, int* __restrict__ biglist) {
     const long total = nimg * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long o = (i / HW) * (long)HW * 4 + offset[i];
         const int n = count[i];
+        if (n > WARP_SMALL_BUCKET) { biglist[atomicAdd(nbig, 1)] = (int)i; continue; }   // at most 4*total/33 of them
         for (int a = 1; a < n; ++a) {
             const int ka = keys[o + a]; const float va = vals[o + a];
             int j = a;
             while (j > 0 && keys[o + j - 1] > ka) { keys[o + j] = keys[o + j - 1]; vals[o + j] = vals[o + j - 1]; --j; }
             keys[o + j] = ka; vals[o + j] = va;
+        }
+    }
+}
+
+// One 1024-thread workgroup per queued bucket: bitonic sorting network in place (global memory, O(n log^2 n) compare-
+// exchanges spread over the workgroup).  The all-ascending form of the network (first step of every merge compares i with
+// its mirror in the block, the rest are half-cleaners) lets the bucket be padded VIRTUALLY to a power of two with +inf
+// keys behind its end: a pair whose upper index is >= n never swaps.  Keys are unique, so the result is the same
+// permutation the insertion sort produces (the summation order stays fixed).
+__global__ __launch_bounds__(1024) void warp_inv_sort_big_kernel(const int* __restrict__ count, const int* __restrict__ offset,
+                                                                 int* __restrict__ keys, float* __restrict__ vals, int HW,
+                                                                 const int* __restrict__ nbig, const int* __restrict__ biglist) {
+    const int nb = *nbig;
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const long i = biglist[b];
+        const long o = (i / HW) * (long)HW * 4 + offset[i];
+        int* __restrict__ kk = keys + o;
+        float* __restrict__ vv = vals + o;
+        const int n = count[i];
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        auto cmpswap = [&](int lo, int hi) {
+            if (hi < n) {
+                const int a = kk[lo], c = kk[hi];
+                if (a > c) { kk[lo] = c; kk[hi] = a; const float t = vv[lo]; vv[lo] = vv[hi]; vv[hi] = t; }
+            }
+        };
+        for (int k = 2; k <= np2; k <<= 1) {
+            const int h = k >> 1;
+            for (int t = threadIdx.x; t < (np2 >> 1); t += blockDim.x) {
+                const int blk = t / h, r = t - blk * h;
+                cmpswap(blk * k + r, blk * k + k - 1 - r);
+            }
+            __syncthreads();
+            for (int j = k >> 2; j >= 1; j >>= 1) {
+                for (int t = threadIdx.x; t < (np2 >> 1); t += blockDim.x) {
+                    const int lo = (t / j) * 2 * j + (t % j);
+                    cmpswap(lo, lo + j);
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -276,13 +324,13 @@ C2M_API int c2m_flow_warp_fwd(const float* img, const float* flow, const float* 
 }
 
 // Workspace of c2m_flow_warp_bwd (bytes): the inverted tap list of d(image) (count, offset, cursor: N*HW ints each;
-// keys, weights: 4*N*HW each) and the per-chunk partial sums of d(flow).  Neither output needs to be zeroed.
+// keys, weights: 4*N*HW each; a queue of the buckets too large for the per-thread sort) and the per-chunk partial sums of d(flow).  Neither output needs to be zeroed.
 C2M_API long c2m_flow_warp_bwd_workspace_bytes(int N, int C, int H, int W, int want_gimg, int want_gflow) {
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
     const long px = (long)N * H * W;
     long b = 0;
-    if (want_gimg) b += px * 4 * 3 + px * 4 * 4 * 2;
+    if (want_gimg) b += px * 4 * 3 + px * 4 * 4 * 2 + 16 + (px / 8 + 1) * 4;     // + queue of the large buckets
     if (want_gflow && grid.y > 1) b += (long)grid.y * px * 2 * 4;
     return b > 0 ? b : 4;
 }
@@ -297,20 +345,25 @@ C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* 
     const long HW = (long)H * W, px = (long)N * HW;
     char* ws = (char*)workspace;
     if (gimg) {
-        int* count = (int*)ws;
+        int* nbig = (int*)ws;                 // [0]: number of queued large buckets (zeroed together with count)
+        int* count = nbig + 4;
         int* offset = count + px;
         int* cursor = offset + px;
         int* keys = cursor + px;
         float* vals = (float*)(keys + px * 4);
-        ws += px * 4 * 3 + px * 4 * 4 * 2;
-        hipError_t e = c2m_zero_async(count, sizeof(int) * px, s);
+        int* biglist = (int*)(vals + px * 4);
+        ws += px * 4 * 3 + px * 4 * 4 * 2 + 16 + (px / 8 + 1) * 4;
+        hipError_t e = c2m_zero_async(nbig, sizeof(int) * (px + 4), s);
         if (e != hipSuccess) return (int)e;
         WarpInvP p{flow, occ, N, H, W};
         const int g1 = c2m_grid(px, 256);
         hipLaunchKernelGGL(warp_inv_count_kernel, dim3(g1), dim3(256), 0, s, p, count);
         hipLaunchKernelGGL(warp_inv_scan_kernel, dim3((unsigned)N), dim3(1024), 0, s, count, offset, cursor, (int)HW);
         hipLaunchKernelGGL(warp_inv_fill_kernel, dim3(g1), dim3(256), 0, s, p, cursor, keys, vals);
-        hipLaunchKernelGGL(warp_inv_sort_kernel, dim3(g1), dim3(256), 0, s, count, offset, keys, vals, (long)N, (int)HW);
+        hipLaunchKernelGGL(warp_inv_sort_kernel, dim3(g1), dim3(256), 0, s, count, offset, keys, vals, (long)N, (int)HW,
+                           nbig, biglist);
+        hipLaunchKernelGGL(warp_inv_sort_big_kernel, dim3(64), dim3(1024), 0, s, count, offset, keys, vals, (int)HW, nbig,
+                           biglist);
         hipLaunchKernelGGL(flow_warp_bwd_img_kernel, grid, dim3(256), 0, s, gout, occ, count, offset, keys, vals, gimg, N,
                            C, (int)HW, cchunk);
     }

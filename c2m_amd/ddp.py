@@ -8,10 +8,19 @@ four optimizers, ~2.3 M parameters that never receive a gradient):
   * parameters are packed into flat fp32 buckets in reverse registration order; `.grad` of every parameter is a view
     into its bucket, so autograd accumulates straight into the communication buffer (no copy-in / copy-out);
   * `arm()` is called before the LAST backward of the step; from then on a bucket is all-reduced on a side HIP stream
-    as soon as all of its parameters that are expected to fire have fired, overlapping RCCL with the rest of backward;
-    the expected set is learned from the first step (which is reduced at `finish()` without overlap);
+    as soon as all of its parameters that are expected to fire have fired, overlapping RCCL with the rest of backward.
+    Buckets are launched in a RANK-AGREED ORDER, the order in which they completed on rank 0 during the first step
+    (not bucket-index order: one late parameter in bucket k would otherwise hold back every later bucket); every rank
+    issues the same RCCL call sequence, whatever its own completion order was.  The expected set and the order are
+    learned on the first step (which is reduced at `finish()` without overlap);
+  * the collective is `ReduceOp.AVG` on RCCL (one pass; gloo has no AVG: pre-divide + SUM there).  `comm_dtype=
+    torch.bfloat16` (BASELINE configs[3-4], SURVEY 8d: 212 MB instead of 424 MB per step) sends a bf16 copy of each
+    bucket and expands the result back into the fp32 bucket -- the accumulation across the three backward calls and
+    the optimizer input stay fp32;
   * `finish()` flushes what is left, makes the compute stream wait for the side stream and sets `.grad = None` for
-    parameters that received no gradient this step (the optimizers then skip them exactly as in the reference).
+    parameters that received no gradient this step (the optimizers then skip them exactly as in the reference);
+  * `reduce_all()` is the no-overlap form for a HIP-graph replay of forward + backward (hooks do not run in a replay):
+    every bucket is reduced after the replay, eagerly, in bucket order.
 On CPU tensors (gloo, used by the tests) the same logic runs synchronously.
 """
 import torch
@@ -19,10 +28,11 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    def __init__(self, params, device):
+    def __init__(self, params, device, comm_dtype):
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.comm = None if comm_dtype == torch.float32 else torch.empty(self.numel, device=device, dtype=comm_dtype)
         self.views, off = [], 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -35,54 +45,67 @@ class _Bucket:
 
 class GradientReducer:
     def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False, buffers=(),
-                 measure=False):
-        """buffers: module buffers (BatchNorm running statistics, spectral-norm u/v) that are broadcast from rank 0
-        together with the parameters at construction (what DistributedDataParallel's constructor does); afterwards they
-        stay per-rank like the reference's BatchNorm.  measure: record HIP events around the join in finish() so that
-        `exposed_ms()` reports the all-reduce time that was NOT hidden behind backward."""
+                 measure=False, comm_dtype=torch.float32):
+        """params: ALL parameters of the model.  The trainable ones are bucketed; every parameter -- frozen ones (the
+        VGG-19 of the perceptual loss, a flow net) included -- and every tensor of `buffers` (BatchNorm running
+        statistics, spectral-norm u/v) is broadcast from rank 0 at construction, which is what DistributedDataParallel's
+        `_sync_module_states` does: with per-rank seeding the ranks would otherwise optimise different perceptual losses
+        while averaging their gradients.  Afterwards buffers stay per-rank like the reference's BatchNorm.
+        measure: record HIP events around the join in finish() so that `exposed_ms()` reports the all-reduce time that
+        was NOT hidden behind backward."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collectives: issue the all-reduces even in a 1-rank group (exercises the RCCL / side-stream path on a
         # single GPU; used by the tests)
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
-        params = [p for p in params if p.requires_grad]
-        seen, uniq = set(), []
+        params = list(params)
+        seen, uniq, everything = set(), [], []
         for p in params:
-            if id(p) not in seen:
-                seen.add(id(p))
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            everything.append(p)
+            if p.requires_grad:
                 uniq.append(p)
         self.params = uniq
         if not uniq:
             raise ValueError("no trainable parameters")
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype: torch.float32 or torch.bfloat16")
+        self.comm_dtype = comm_dtype
         self.device = uniq[0].device
         self.on_gpu = self.device.type == "cuda"
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(uniq):                      # gradients become ready roughly in reverse creation order
             if cur and n + p.numel() > cap:
-                self.buckets.append(_Bucket(cur, self.device))
+                self.buckets.append(_Bucket(cur, self.device, comm_dtype))
                 cur, n = [], 0
             cur.append(p)
             n += p.numel()
         if cur:
-            self.buckets.append(_Bucket(cur, self.device))
+            self.buckets.append(_Bucket(cur, self.device, comm_dtype))
         self.where = {}
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
+            b.index = bi
             for i, p in enumerate(b.params):
                 self.where[id(p)] = (b, i)
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.expected = None          # ids of params that fire in the final backward (learned on step 1, rank-agreed)
         self.ever_fired = None        # ids of params that receive a gradient at all (learned on step 1, rank-agreed)
+        self.order = list(range(len(self.buckets)))     # launch order of the buckets (rank 0's completion order of step 1)
         self.fired_final, self.fired_any = set(), set()
+        self._fire_seq = []           # step 1: parameter ids in the order they fired in the final backward
         self.armed = False
-        self.next_bucket = 0          # buckets are all-reduced strictly in index order: same RCCL call sequence on all ranks
+        self.next_slot = 0            # position in self.order of the next bucket to launch
+        self.use_avg = self.on_gpu and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         self.measure = measure and self.on_gpu
         self._exposed = []            # (event at end of backward compute, event after the side stream was joined)
         if self.world > 1:            # identical starting point on every rank, whatever the callers seeded
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
             with torch.no_grad():
-                for t in list(uniq) + [b for b in buffers if torch.is_tensor(b)]:
-                    dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                                   group=self.group)
+                for t in everything + [b for b in buffers if torch.is_tensor(b)]:
+                    dist.broadcast(t.data, src=src, group=self.group)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in uniq]
         self.zero_grad()
 
@@ -96,13 +119,16 @@ class GradientReducer:
                 p.grad = v
         self.fired_final.clear()
         self.fired_any.clear()
+        self._fire_seq = []
         self.armed = False
-        self.next_bucket = 0
+        self.next_slot = 0
+        self.overlapped_launches = 0  # buckets that went out from a hook, i.e. while backward was still running
 
     def arm(self):
         """Call right before the last backward() of the step."""
         self.armed = True
         self.fired_final.clear()
+        self._fire_seq = []
         if self.expected is not None:
             for b in self.buckets:
                 b.pending = sum(1 for p in b.params if id(p) in self.expected)
@@ -118,16 +144,44 @@ class GradientReducer:
         if not self.armed:
             return
         self.fired_final.add(id(p))
-        if self.expected is not None and id(p) in self.expected and not b.launched:
+        if self.expected is None:
+            self._fire_seq.append(id(p))
+            return
+        if b.launched:
+            # the agreed `expected` set said this parameter does not fire in the final backward, so its bucket went out
+            # without waiting for it: the write above raced with an all-reduce in flight and the other ranks never see
+            # this contribution.  Fail loudly (rank-local, like DistributedDataParallel's reduction errors).
+            raise RuntimeError("GradientReducer: a parameter outside the set agreed on the first step received a gradient "
+                               "in the final backward after its bucket was all-reduced (data-dependent graph); rebuild "
+                               "the reducer, or run the first step on data that exercises every branch")
+        if id(p) in self.expected:
             b.pending -= 1
             if b.pending == 0:
                 b.ready = True
                 self._launch_ready()
 
     def _launch_ready(self):
-        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket].ready:
-            self._launch(self.buckets[self.next_bucket])
-            self.next_bucket += 1
+        while self.next_slot < len(self.order) and self.buckets[self.order[self.next_slot]].ready:
+            self._launch(self.buckets[self.order[self.next_slot]])
+            self.next_slot += 1
+            self.overlapped_launches += 1
+
+    def _collective(self, b):
+        """mean over ranks of b.flat, in place (on the current stream)."""
+        t = b.flat
+        if b.comm is not None:
+            b.comm.copy_(t)                       # fp32 -> bf16 (RNE)
+            t = b.comm
+        if self.use_avg:
+            work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=self.on_gpu)
+        else:
+            t.div_(self.world)
+            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=self.on_gpu)
+        return work
+
+    def _expand(self, b):
+        if b.comm is not None:
+            b.flat.copy_(b.comm)
 
     def _launch(self, b):
         b.launched = True
@@ -136,22 +190,16 @@ class GradientReducer:
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
-                b.flat.div_(self.world)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._collective(b)
+                if b.comm is not None:           # stream-ordered behind the collective on the side stream
+                    b.work.wait()
+                    b.work = None
+                    self._expand(b)
         else:
-            b.flat.div_(self.world)
-            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._collective(b)
+            self._expand(b)
 
-    def finish(self):
-        """After the last backward: reduce the remaining buckets, join streams, drop never-touched grads."""
-        ev0 = None
-        if self.measure and self.collectives:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record(torch.cuda.current_stream(self.device))
-        for b in self.buckets:                         # index order (see next_bucket)
-            if not b.launched:
-                self._launch(b)
-        self.next_bucket = len(self.buckets)
+    def _join(self, ev0):
         if self.on_gpu and self.collectives:
             for b in self.buckets:
                 if b.work is not None:
@@ -161,17 +209,67 @@ class GradientReducer:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record(torch.cuda.current_stream(self.device))
                 self._exposed.append((ev0, ev1))
+
+    def _mark(self):
+        if self.measure and self.collectives:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(self.device))
+            return ev0
+        return None
+
+    def finish(self):
+        """After the last backward: reduce the remaining buckets, join streams, drop never-touched grads."""
+        ev0 = self._mark()
+        for bi in self.order:                          # the agreed order (see _launch_ready)
+            b = self.buckets[bi]
+            if not b.launched:
+                self._launch(b)
+        self.next_slot = len(self.order)
+        self._join(ev0)
         if self.expected is None:
-            # Step 1: agree across ranks on which parameters fire (in the final backward / at all).  Every later step
-            # uses the agreed sets, so all ranks issue the same bucket sequence and drop the same gradients even if a
-            # data-dependent branch made one rank's graph differ.
-            fin = torch.tensor([[float(id(p) in self.fired_final), float(id(p) in self.fired_any)] for p in self.params],
-                               device=self.device)
-            if self.world > 1:
-                dist.all_reduce(fin, op=dist.ReduceOp.MAX, group=self.group)
-            fin = fin.cpu()
-            self.expected = {id(p) for p, f in zip(self.params, fin) if f[0] > 0}
-            self.ever_fired = {id(p) for p, f in zip(self.params, fin) if f[1] > 0}
+            self._agree()
+        self._drop_unfired()
+
+    def reduce_all(self):
+        """No-overlap form: all-reduce every bucket now (after a HIP-graph replay of forward + backward, whose hooks
+        did not run).  Needs the sets learned by one eager step."""
+        if self.expected is None:
+            raise RuntimeError("GradientReducer.reduce_all: run one eager step (arm / finish) first")
+        ev0 = self._mark()
+        for b in self.buckets:
+            b.work, b.launched = None, False
+            self._launch(b)
+        self._join(ev0)
+        for p in self.params:                          # a replay re-creates no .grad: keep the agreed set bound, drop the rest
+            b, i = self.where[id(p)]
+            p.grad = b.views[i] if id(p) in self.ever_fired else None
+
+    def _agree(self):
+        # Step 1: agree across ranks on which parameters fire (in the final backward / at all) and on the bucket launch
+        # order.  Every later step uses the agreed sets, so all ranks issue the same bucket sequence and drop the same
+        # gradients even if a data-dependent branch made one rank's graph differ.
+        fin = torch.tensor([[float(id(p) in self.fired_final), float(id(p) in self.fired_any)] for p in self.params],
+                           device=self.device)
+        if self.world > 1:
+            dist.all_reduce(fin, op=dist.ReduceOp.MAX, group=self.group)
+        fin = fin.cpu()
+        self.expected = {id(p) for p, f in zip(self.params, fin) if f[0] > 0}
+        self.ever_fired = {id(p) for p, f in zip(self.params, fin) if f[1] > 0}
+        # completion position of a bucket on THIS rank = when its last expected parameter fired (never: at the end);
+        # buckets without expected parameters are ready at arm() and go first
+        pos = {pid: k for k, pid in enumerate(self._fire_seq)}
+        late = len(self._fire_seq) + 1
+        done = []
+        for b in self.buckets:
+            exp = [id(p) for p in b.params if id(p) in self.expected]
+            done.append(max((pos.get(pid, late) for pid in exp), default=-1))
+        order = sorted(range(len(self.buckets)), key=lambda i: (done[i], i))
+        t = torch.tensor(order, device=self.device, dtype=torch.int64)
+        if self.world > 1:                             # rank 0's order is everybody's order
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self.order = [int(v) for v in t.cpu()]
+
+    def _drop_unfired(self):
         for p in self.params:
             if id(p) not in self.fired_any and id(p) not in self.ever_fired:
                 p.grad = None
@@ -188,7 +286,8 @@ class GradientReducer:
         self._exposed = []
 
     def bytes_per_step(self):
-        return 4 * sum(b.numel for b in self.buckets)
+        """Bytes each rank hands to the all-reduce per step."""
+        return (2 if self.comm_dtype == torch.bfloat16 else 4) * sum(b.numel for b in self.buckets)
 
     def remove(self):
         for h in self._hooks:

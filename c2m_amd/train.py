@@ -29,7 +29,7 @@ def init_distributed():
 
 class TrainStep:
     def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0,
-                 force_collectives=False, measure_comm=False):
+                 force_collectives=False, measure_comm=False, comm_dtype=torch.float32):
         self.c2m = c2m
         self.tp = c2m.train_params
         self.loss_weights = loss_weights or self.tp["loss_weights"]
@@ -41,7 +41,9 @@ class TrainStep:
             self.optimizers.append(c2m.d_optimizer_video)
         distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb, buffers=list(c2m.buffers()),
-                                       force_collectives=force_collectives, measure=measure_comm) if distributed else None
+                                       force_collectives=force_collectives, measure=measure_comm,
+                                       comm_dtype=comm_dtype) if distributed else None
+        self._deferred_nan = []       # NaN checks recorded while capturing (utils.isnan), evaluated after every replay
 
     # ---- HIP-graph replay of zero_grad + forward + backward (single GPU, static batch) ---------------------------------------
     def capture(self, data, warmup=3):
@@ -49,13 +51,14 @@ class TrainStep:
         `__call__(data)` with the same object replays the graph (one launch instead of ~1200) and then runs the optimizers
         eagerly (their bias-correction scalars are host-computed kernel arguments and change every step).
 
-        New data for a captured step must be copied INTO the tensors of `data` (static addresses).  Not available with the
-        gradient reducer: its RCCL launches would have to be captured too.  Everything on the captured path is kernel nodes
-        only: the one hipMemsetAsync per splat / warp-inversion of round 1 was a memset NODE whose replay faulted ("write
-        access to a read-only page" on the second replay, ROCm 7.2) and is a zero-fill kernel now; the reference's NaN
-        checks (host syncs) are deferred to after the replay (`utils.check_deferred_nan`)."""
-        if self.reducer is not None:
-            raise RuntimeError("TrainStep.capture: graph capture of the RCCL gradient reducer is not supported")
+        New data for a captured step must be copied INTO the tensors of `data` (static addresses).  With the gradient
+        reducer (N > 1) the graph holds zero_grad + forward + backward only -- gradients accumulate into the reducer's flat
+        buckets (static addresses) -- and the RCCL all-reduces are issued eagerly after each replay (`reduce_all`, no
+        overlap with backward: hooks do not run in a replay); every rank must call capture() at the same point.
+        Everything on the captured path is kernel nodes only: the one hipMemsetAsync per splat / warp-inversion of round 1
+        was a memset NODE whose replay faulted ("write access to a read-only page" on the second replay, ROCm 7.2) and is a
+        zero-fill kernel now; the reference's NaN checks (host syncs, losses.py:251-253) are recorded during the capture
+        and evaluated after every replay (`check_nan_every`: one fused reduction, synchronised every that many steps)."""
         dev = next(self.c2m.parameters()).device
         # An AccumulateGrad node lives on the stream it was created on and stays alive while ANY autograd graph refers to it
         # (nn.utils.spectral_norm, for one, keeps `module.weight = weight_orig / sigma` -- a tensor with grad_fn -- from one
@@ -64,20 +67,41 @@ class TrainStep:
         # under `with torch.cuda.stream(step.graph_stream)` (bench.py --graph does), or capture before the first eager step.
         side = self.graph_stream
         side.wait_stream(torch.cuda.current_stream(dev))
+        from .utils import utils as U
         run_opt, self.run_optimizers = self.run_optimizers, False
         try:
             with torch.cuda.stream(side):
                 for _ in range(warmup):                       # plans, caches and allocator state settle outside the capture
-                    self._eager(data)
+                    self._eager(data)                         # (with a reducer: also learns the rank-agreed gradient sets)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                outputs = self._eager(data)
+            U.begin_deferred_nan()
+            try:
+                with torch.cuda.graph(graph, stream=side):
+                    outputs = self._eager(data, in_capture=True)
+            finally:
+                self._deferred_nan = U.end_deferred_nan()
         finally:
             self.run_optimizers = run_opt
         self._graph, self._graph_data, self._graph_out = graph, data, outputs
+        self._replays = 0
         return self
+
+    check_nan_every = 1               # replays between two host-side evaluations of the deferred NaN checks
+
+    def _check_deferred_nan(self):
+        """The reference raises ValueError when a theta loss is NaN (utils.py:375-379 <- losses.py:251-253).  Under replay
+        the flags live in static graph tensors: one fused any() over them, read back every `check_nan_every` replays."""
+        if not self._deferred_nan:
+            return
+        self._replays += 1
+        if self._replays % max(1, int(self.check_nan_every)):
+            return
+        flags = torch.stack([f.reshape(()) for f, _ in self._deferred_nan])
+        if bool(flags.any()):
+            bad = [name for (f, name) in self._deferred_nan if bool(f)]
+            raise ValueError(f"nan in {', '.join(bad)}")
 
     @property
     def graph_stream(self):
@@ -97,13 +121,16 @@ class TrainStep:
         """One update; returns (generated dict, generator loss dict incl. total_gen, D loss dict)."""
         if getattr(self, "_graph", None) is not None and data is self._graph_data:
             self._graph.replay()
+            if self.reducer is not None:
+                self.reducer.reduce_all()
+            self._check_deferred_nan()
             if self.run_optimizers:
                 for o in self.optimizers:
                     o.step()
             return self._graph_out
         return self._eager(data)
 
-    def _eager(self, data):
+    def _eager(self, data, in_capture=False):
         self.zero_grad()
         generated, loss_g, loss_d_img, loss_d_vid = self.c2m(data)
         total = None
@@ -118,10 +145,10 @@ class TrainStep:
         if self.tp["use_video_discriminator"]:
             losses_d["total_video_dis"] = (loss_d_vid.get("d_real", 0) + loss_d_vid.get("d_fake", 0)) * 0.5
             losses_d["total_video_dis"].backward()
-        if self.reducer is not None:
+        if self.reducer is not None and not in_capture:
             self.reducer.arm()
         total.backward()
-        if self.reducer is not None:
+        if self.reducer is not None and not in_capture:
             self.reducer.finish()
         if self.run_optimizers:
             for o in self.optimizers:

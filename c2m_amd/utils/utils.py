@@ -48,14 +48,28 @@ def resize_video(video, scale_factor, mode="nearest", is_flow=False):
     return _unfold(F.interpolate(flat, size=size, mode=mode), t)
 
 
-_deferred_nan_checks = []
+_deferred_nan_checks = []          # [(flag tensor computed INSIDE the capture, description)] of the capture in progress / last capture
+
+
+def begin_deferred_nan():
+    """Start collecting the NaN checks of one graph capture (TrainStep.capture); drops the previous capture's list, which
+    would otherwise pin that graph's pool tensors."""
+    del _deferred_nan_checks[:]
+
+
+def end_deferred_nan():
+    """The checks recorded since begin_deferred_nan(); the caller (TrainStep) owns and evaluates them after each replay."""
+    out = list(_deferred_nan_checks)
+    del _deferred_nan_checks[:]
+    return out
 
 
 def isnan(x, input_tensor=None):
     """Raises ValueError on NaN like the reference (utils.py:375-379) -- one host sync per call.  While the current stream is
-    being captured into a HIP graph a host sync is illegal: the check is deferred (`check_deferred_nan()` after the replay)."""
+    being captured into a HIP graph a host sync is illegal: the flag `any(isnan(x))` is computed by a captured kernel into a
+    static tensor and evaluated after the replay (TrainStep._check_deferred_nan, or check_deferred_nan())."""
     if x.is_cuda and torch.cuda.is_current_stream_capturing():
-        _deferred_nan_checks.append((x, input_tensor))
+        _deferred_nan_checks.append((torch.isnan(x).any(), "theta loss" if input_tensor is None else str(type(input_tensor))))
         return x
     if torch.any(torch.isnan(x)):
         raise ValueError(f"Value is nan {x}, input tensor is {input_tensor}")
@@ -63,10 +77,10 @@ def isnan(x, input_tensor=None):
 
 
 def check_deferred_nan():
-    """NaN checks registered during a graph capture, evaluated on the graph's (static) output tensors after a replay."""
-    for x, input_tensor in _deferred_nan_checks:
-        if torch.any(torch.isnan(x)):
-            raise ValueError(f"Value is nan {x}, input tensor is {input_tensor}")
+    """Evaluate NaN checks recorded during a capture that was not made through TrainStep.capture (which keeps its own)."""
+    for flag, what in _deferred_nan_checks:
+        if bool(flag):
+            raise ValueError(f"Value is nan ({what})")
 
 
 def get_rank():

@@ -179,3 +179,106 @@ def test_rank0_broadcast_and_rank_divergent_graph():
             if g0[k] is not None:
                 assert (g0[k] == g1[k]).all(), (step, k)
         assert g1["head_x.weight"] is not None and abs(g1["head_x.weight"]).sum() > 0   # mean with rank 0's contribution
+
+
+class Backwards(nn.Module):
+    """Registration order is the OPPOSITE of what bucketing assumes: the first-registered layer is used last, so the bucket
+    that holds it (the last bucket in reverse-registration order) completes FIRST in backward."""
+
+    def __init__(self):
+        super().__init__()
+        self.last = nn.Linear(8, 3)            # used last in forward -> its gradient fires first
+        self.mid = nn.Linear(8, 8)
+        self.first = nn.Linear(6, 8)           # used first in forward -> fires last, but sits in bucket 0
+        self.frozen = nn.Linear(3, 3)
+        for p in self.frozen.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        return self.frozen(self.last(torch.tanh(self.mid(torch.relu(self.first(x)))))).abs().mean()
+
+
+def _worker_order(rank, world, port, comm_dtype, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(20 + rank)             # per-rank seeding: frozen parameters must be broadcast too
+        model = Backwards()
+        red = GradientReducer(list(model.parameters()), bucket_mb=0.0002, comm_dtype=comm_dtype)
+        frozen = model.frozen.weight.detach().clone().numpy()
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + rank))
+        early = []
+        for step in range(3):
+            red.zero_grad()
+            red.arm()
+            loss = model(x)
+            # count the buckets that are launched while backward is still running (from the hooks)
+            loss.backward()
+            early.append(red.overlapped_launches)
+            red.finish()
+        grads = {k: p.grad.clone().numpy() for k, p in model.named_parameters() if p.grad is not None}
+        q.put((rank, frozen, list(red.order), early, grads, red.bytes_per_step(), len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_backwards(rank, state):
+    m = Backwards()
+    m.load_state_dict(state)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + rank))
+    m(x).backward()
+    return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_out_of_order_readiness_agreed_launch_order_and_bf16_buckets(comm_dtype):
+    """(1) buckets launch as they complete, in the order rank 0 saw on the first step -- not in bucket-index order, where the
+    late bucket 0 would hold back all others until finish(); (2) frozen parameters are broadcast from rank 0 as well;
+    (3) bf16 buckets: half the bytes on the wire, mean-of-ranks gradient within bf16 rounding."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_order, args=(r, world, port, comm_dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (fz0, order0, early0, g0, bytes0, nb), (fz1, order1, early1, g1, _, _) = res[0], res[1]
+    assert (fz0 == fz1).all(), "frozen parameters must start from rank 0's values on every rank"
+    assert order0 == order1 and sorted(order0) == list(range(nb)) and nb >= 4
+    assert order0 != list(range(nb)), "bucket 0 holds the parameters that fire last: it must not be first in the launch order"
+    assert order0[-1] in (0, 1) and order0[0] in (nb - 1, nb - 2)      # `first`'s weight / bias fire last, `last`'s first
+    assert early0[0] == 0 and early0[1] >= nb - 1 and early0[2] >= nb - 1, early0     # step 1 learns; later steps overlap
+    torch.manual_seed(20)
+    state = Backwards().state_dict()             # rank 0's initial weights
+    e0, e1 = _single_backwards(0, state), _single_backwards(1, state)
+    total = sum(p.numel() for p in Backwards().parameters() if p.requires_grad)
+    assert bytes0 == total * (2 if comm_dtype == torch.bfloat16 else 4)
+    for k in e0:
+        mean = (e0[k] + e1[k]) / 2
+        assert (g0[k] == g1[k]).all(), k
+        tol = dict(rtol=1e-2, atol=1e-3) if comm_dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(torch.from_numpy(g0[k]), mean, **tol, msg=lambda m: f"{k}: {m}")
+
+
+def test_unexpected_late_gradient_fails_loudly():
+    """A parameter outside the agreed set that fires in the final backward after its bucket went out must raise, not race
+    with the all-reduce in flight."""
+    torch.manual_seed(0)
+    model = Branchy()
+    red = GradientReducer(list(model.parameters()), bucket_mb=1e-6)       # one bucket per parameter
+    x = torch.randn(5, 6)
+    red.zero_grad()
+    red.arm()
+    model(x, use_x=False).backward()              # step 1: head_x never fires -> not expected
+    red.finish()
+    red.zero_grad()
+    red.arm()                                      # head_x's buckets have nothing to wait for: launched right here
+    with pytest.raises(RuntimeError, match="outside the set agreed"):
+        model(x, use_x=True).backward()

@@ -338,7 +338,7 @@ def test_step_is_deterministic():
         losses.append(float(lg["total_gen"]))
         grads.append(model.generator.first.conv.weight.grad.clone())
     assert losses[0] == losses[1]
-    # conv/norm/loss kernels are deterministic; only the warp image-gradient uses float atomics (upstream of this weight? no)
+    # no float atomics anywhere in the library (warp / RoIAlign backward are fixed-order gathers since round 2)
     assert torch.equal(grads[0], grads[1])
 
 

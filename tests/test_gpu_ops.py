@@ -121,6 +121,7 @@ WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3
     c for c in CONV_CASES if len(c[0]) == 5 and c[2] == (3, 3, 3) and c[3] == (1, 1, 1) and c[4] == (1, 1, 1)] + [
     ((2, 12, 3, 16, 32), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), "zeros"),     # 3x3x3 as 2-D Winograd over (time tap, channel)
     ((1, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "zeros"),
+    ((2, 12, 1, 16, 32), 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), "zeros"),     # ONE frame: the time taps -1 / +1 only meet zeros
     ((3, 40, 24, 48), 70, (3, 3), 1, 1, "reflect"),      # channels not multiples of 8 / 64: zero-padded U, partial M tile
     ((2, 16, 10, 20), 8, (3, 3), 1, 1, "zeros"),         # partial 8x16 regions on both axes
     ((3, 40, 6, 48), 70, (3, 3), 1, 1, "zeros"),         # Winograd wgrad: partial channel tiles, 27 regions over 2 splits
@@ -196,6 +197,34 @@ def test_conv_bf16_mode(case):
     if cout > 4:       # <= 4 output channels run on the fp32 vector-ALU kernel in either mode (more precise, not less)
         rel_close(y2, _ref_conv(_bf(x2), _bf(w2), None, stride, pad, mode, None), 2e-5,
                   "bf16 rounding is RNE of both operands")
+
+
+@pytest.mark.parametrize("cin,cout", [(40, 200), (200, 45)])
+def test_conv_bf16_patch_never_reads_past_the_input(cin, cout):
+    """the bf16 LDS-patch kernel carries the channel in the scalar offset of its buffer loads, which the
+    hardware does not range-check.  With Cin (forward) or Cout (data gradient) not a multiple of 16 the padded channels of the
+    last chunk must read 0, not whatever lies behind the tensor: the inputs here are views whose allocation continues with
+    NaNs, and no output may become NaN."""
+    H, W = 24, 64
+    pool = torch.full((2 * cin * H * W + 4096,), float("nan"), device=DEV)
+    x = pool[:cin * H * W].view(1, cin, H, W)
+    x.copy_(g(_bf(rnd(7, 1, cin, H, W))))
+    w = g(_bf(rnd(8, cout, cin, 3, 3, scale=(1.0 / (cin * 9)) ** 0.5)))
+    gpool = torch.full((2 * cout * H * W + 4096,), float("nan"), device=DEV)
+    go = gpool[:cout * H * W].view(1, cout, H, W)
+    go.copy_(g(_bf(rnd(9, 1, cout, H, W))))
+    xg, wg = x.requires_grad_(True), w.requires_grad_(True)
+    with ops.conv_precision("bf16"):
+        pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), False)
+        assert pl.fwd_patch or any(c["patch"] for c in pl.classes), "the case must run on the bf16 patch kernel"
+        y = ops.conv(xg, wg, None, stride=1, padding=1)
+        y.backward(go)
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(xg.grad).all()) and bool(torch.isfinite(wg.grad).all())
+    xr, wr = x.detach().cpu().requires_grad_(True), w.detach().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, padding=1)
+    yr.backward(go.cpu())
+    rel_close(y, yr, 2e-5, "bf16 patch fwd")
+    rel_close(xg.grad, xr.grad, 5e-5, "bf16 patch dgrad")
 
 
 def test_conv_stride2_fuzz():
@@ -371,6 +400,33 @@ def test_flow_warp_backward_is_bit_repeatable(shape):
         ((O.resample(ir, fr) * occ.cpu()) * go.cpu()).sum().backward()
         rel_close(grads[0][0], ir.grad, 2e-5, "d image (converging flow)" if flow is not None else "")
         rel_close(grads[0][1], fr.grad, 2e-4, "d flow")
+
+
+def test_flow_warp_backward_diverged_flow_is_bounded_and_exact():
+    """a diverged flow field sends whole regions onto border / corner pixels -- buckets of 1e4+ taps.  The
+    per-thread insertion sort would be O(n^2) there (seconds: looks like a hang); buckets above 32 entries are sorted by a
+    workgroup-wide bitonic network instead.  Same fixed (dest pixel, corner) order, so still bit-repeatable and equal to
+    the CPU restatement up to its own summation order."""
+    import time
+    N, C, H, W = 2, 3, 128, 256
+    img, go = g(rnd(21, N, C, H, W)), g(rnd(22, N, C, H, W))
+    flow = rnd(23, N, 2, H, W, scale=3.0)
+    flow[0] += 4000.0                        # every pixel of image 0 samples the bottom-right corner: ONE bucket of 32768 x 1 taps
+    flow[1, 0] -= 900.0                      # image 1: every row collapses onto its left border pixel(s)
+    grads = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(2):
+        ig, fg = img.clone().requires_grad_(True), g(flow).requires_grad_(True)
+        (ops.flow_warp(ig, fg) * go).sum().backward()
+        grads.append((ig.grad.clone(), fg.grad.clone()))
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0, "the diverged-flow backward must stay bounded"
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    ir, fr = img.cpu().clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    (O.resample(ir, fr) * go.cpu()).sum().backward()
+    rel_close(grads[0][0], ir.grad, 5e-5, "d image (diverged flow)")
+    rel_close(grads[0][1], fr.grad, 2e-4, "d flow (diverged flow)")
 
 
 @pytest.mark.parametrize("shape", [(40, 16, 4, 8), (5, 64, 32, 64), (2, 3, 128, 256), (3, 7, 9, 13)])

@@ -1,11 +1,12 @@
-# Round-2 evidence for profiles/: bench line, kernel trace, HBM traffic (separate --pmc passes, calibrated), MFMA busy.
-#   tools/prof_round2.sh   ->  gpurun_out/r02/final/*
+# Evidence for profiles/ (any round): bench line, kernel trace, HBM traffic (separate --pmc passes, calibrated), MFMA busy.
+#   tools/prof_round.sh r03   ->  gpurun_out/r03/final/*   (copy the summaries into profiles/r03_*)
 set -e
 export TMPDIR=/tmp
+TAG=${1:-r03}
 R=$PWD
-O=$R/gpurun_out/r02/final
+O=$R/gpurun_out/$TAG/final
 mkdir -p $O
-python3 bench.py > $O/bench_final.json 2> $O/bench_final.err || tail -3 $O/bench_final.err
+python3 bench.py --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err || tail -3 $O/bench_final.err
 echo "bench done"
 rm -rf $O/trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --conv-table $O/conv_shape_table.txt > $O/trace.log 2>&1 || tail -5 $O/trace.log
@@ -23,3 +24,4 @@ rm -rf $O/pmc_MFMA
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_MFMA -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_MFMA.log 2>&1 || tail -5 $O/pmc_MFMA.log
 echo "pmc mfma done"
 python3 tools/prof_round2_post.py $O
+rm -f $O/kernel_trace.csv

@@ -66,12 +66,21 @@ conv = [r for r in rows if any(s in r[1] for s in ("conv_wino_kernel", "conv_ige
 nl = sum(r[2] for r in conv)
 rd = sum(r[4] * r[2] for r in conv) / nl
 wr = sum(r[5] * r[2] for r in conv) / nl
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1` (tools/prof_round2.sh); "
+# the launch count bench.py's own profiler sees for this build (its staleness check compares against it)
+bench_launches = None
+try:
+    for line in open(f"{O}/bench_final.json"):
+        if line.startswith("{"):
+            bench_launches = json.loads(line)["roofline"]["launches_per_step"]
+except Exception:
+    pass
+res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1` (tools/prof_round.sh); "
                "counters are KiB; traffic_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for wide reads, "
                f"measured on this box: x{f16 and round(f16, 2)} for 16-B/lane reads, x{f4 and round(f4, 2)} for 4-B/lane gathers); "
                "launch-weighted mean over all conv MFMA kernels",
        "calibration": calib,
-       "conv": {"launches_per_step": round(nl, 1), "read_bytes_per_launch_raw": round(rd), "write_bytes_per_launch": round(wr),
+       "conv": {"launches_per_step": bench_launches if bench_launches is not None else round(nl, 1),
+                "launches_per_step_in_trace": round(nl, 1), "read_bytes_per_launch_raw": round(rd), "write_bytes_per_launch": round(wr),
                 "traffic_bytes_per_launch": round(2 * rd + wr), "traffic_bytes_per_launch_uncorrected": round(rd + wr)}}
 json.dump(res, open(f"{O}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res["conv"]), "calib", f16, f4)
