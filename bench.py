@@ -133,12 +133,15 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     med = times[len(times) // 2]
     # host-saturating figure: P independent replicas (one clip each) x the best thread count, all running at once
     saturated = None
-    P = min(phys // best, 16)
+    # at most 4 replicas: the GPU boxes' process guard allows 6 processes with the device open, and a child that imports
+    # torch counts as one (this parent is the fifth) -- so on a 128-core host this leg loads 4 x `best` cores, not all
+    P = min(phys // best, 4)
     if P > 1:
         h_, w_ = cfg["train_params"]["input_size"]
         env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(best), "--height", str(h_), "--width", str(w_)]
-        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(P)]
+        procs = [subprocess.Popen(cmd + ["--cpu-worker-index", str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                  text=True, env=env) for r in range(P)]       # replica r is pinned to its own `best` cores
         per = []
         for pr in procs:
             try:
@@ -151,7 +154,7 @@ def cpu_baseline(cfg, seconds_budget=30.0):
             saturated = {"value": round(P * 7.0 / per[len(per) // 2], 3), "unit": "frames/s", "processes": P,
                          "threads_each": best, "cores": P * best,
                          "sample": f"{P} concurrent replicas x 2 timed steps of 1 clip each, median replica {per[len(per) // 2]:.3f} s/step"}
-    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": best, "kind": "port", "saturated": saturated,
+    return {"value": round(7.0 / med, 3), "unit": "frames/s", "cores": best, "kind": "port", "multi_process": saturated,
             "host": f"{_cpu_model()}, {phys} physical cores visible",
             "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "reference_code_datapoint": "the reference itself, build container (8 vCPU): 3.0 frames/s G-only (SURVEY.md 6)",
@@ -159,10 +162,16 @@ def cpu_baseline(cfg, seconds_budget=30.0):
                       f"(best of the sweep); median {med:.3f} s/step"}
 
 
-def _cpu_worker(nthreads, height, width):
-    """One replica of the saturated cpu_baseline leg: oracle fwd + bwd of one clip, `nthreads` threads; prints s/step."""
+def _cpu_worker(nthreads, height, width, index=0):
+    """One replica of the multi-process cpu_baseline leg: oracle fwd + bwd of one clip, `nthreads` threads pinned to the
+    replica's own slice of the allowed CPUs (unpinned replicas migrate onto each other's cores); prints s/step."""
     from oracle import c2m_oracle as O
     import copy
+    if hasattr(os, "sched_setaffinity"):
+        cpus = sorted(os.sched_getaffinity(0))
+        mine = cpus[index * nthreads:(index + 1) * nthreads]
+        if len(mine) == nthreads:
+            os.sched_setaffinity(0, set(mine))
     torch.set_num_threads(nthreads)
     cfg = bench_config(height, width, False)
     torch.manual_seed(0)
@@ -247,9 +256,10 @@ def main():
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-index", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        return _cpu_worker(args.cpu_worker, args.height or 128, args.width or 256)
+        return _cpu_worker(args.cpu_worker, args.height or 128, args.width or 256, args.cpu_worker_index)
     for k, v in CONFIGS[args.config].items():
         if getattr(args, k) is None:
             setattr(args, k, v)

@@ -43,6 +43,11 @@ _SIGS = {
     "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
     "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
     "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_void_p]),
+    "c2m_resample2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "c2m_channelnorm_fwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "c2m_correlation_out_size": (c_int, [c_int] * 5),
+    "c2m_correlation_fwd": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "c2m_bias_act": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_float, c_void_p]),
     "c2m_flow_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "c2m_flow_warp_bwd_workspace_bytes": (c_long, [c_int] * 6),
     "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p]),

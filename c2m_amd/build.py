@@ -11,7 +11,8 @@ ARCH = "gfx950"
 # index/mask-path files pin the fp32 operation order: no implicit contraction there
 SOURCES = {"conv_igemm.hip": [], "conv_wino.hip": [], "norm.hip": [], "losses.hip": [], "optim.hip": ["-ffp-contract=off"],
            "data_prep.hip": ["-ffp-contract=off"],
-           "warp.hip": ["-ffp-contract=off"], "motion_raster.hip": ["-ffp-contract=off"], "events.hip": []}
+           "warp.hip": ["-ffp-contract=off"], "motion_raster.hip": ["-ffp-contract=off"], "events.hip": [],
+           "flownet_ops.hip": ["-ffp-contract=off"]}
 
 
 def _stale(target, deps):

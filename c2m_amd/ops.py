@@ -602,30 +602,140 @@ def _pack_native(w, M, C, ck, kdims, stride, s_m, s_c):
     return out
 
 
-_frozen_pack_cache = {}
+_frozen_pack_cache = {}       # (id(w), kind) -> (weakref(w), w._version, w.data_ptr(), packed)   [name kept from round 1]
+_PACK_CACHE_LIMIT = 4096
 
 
 def _packed(w, frozen, kind, build):
-    """Packed weight matrix; weights that take no gradient (the frozen VGG-19 of the perceptual loss) are packed once
-    and reused while the SAME tensor object is alive and unmodified (weak reference + _version: a new tensor that
-    happens to reuse a freed allocation never hits)."""
-    if not frozen:
+    """Packed weight matrix (K-order rows, Winograd U fragments, bf16 patch image ...), built once per weight VALUE: cached
+    while the SAME tensor object is alive and unmodified (weak reference + `_version` + data pointer: a new tensor that
+    happens to reuse a freed allocation never hits).  Frozen weights (the VGG-19 of the perceptual loss) are packed once per
+    run; trainable weights once per optimizer step -- `c2m_amd.optim.Adam.step` (and every in-place torch update) bumps
+    `_version` -- instead of once per call: the discriminators run three times per step, every layer's forward and data
+    gradient layouts were rebuilt on every use (pack_weights 76 + wino_filter 94 launches per step in round 2).
+    Under a HIP-graph capture trainable weights are re-packed INSIDE the graph and never cached: the graph is replayed after
+    eager optimizer steps, and a pack tensor from the graph's private pool must not leak into eager code."""
+    if not frozen and w.is_cuda and torch.cuda.is_current_stream_capturing():
         return build()
     key = (id(w), kind)
     hit = _frozen_pack_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
         return hit[3]
-    if len(_frozen_pack_cache) > 512:
-        _frozen_pack_cache.clear()
+    if len(_frozen_pack_cache) > _PACK_CACHE_LIMIT:
+        for k in [k for k, v in _frozen_pack_cache.items() if v[0]() is None]:       # owners that died (e.g. the
+            del _frozen_pack_cache[k]                                                  # per-forward spectral-norm weight)
+        if len(_frozen_pack_cache) > _PACK_CACHE_LIMIT:
+            _frozen_pack_cache.clear()
     A = build()
     _frozen_pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), A)
     return A
 
 
+def _conv_dgrad(pl, w, gy, frozen_w):
+    """Data gradient of the convolution described by plan `pl` (= the transposed convolution of gy with w): shared by
+    _ConvFn.backward and conv_transpose2d.  gy contiguous [N, Cout, (To,) Ho, Wo]; returns [N, Cin, (Ti,) Hi, Wi]."""
+    L = _lib.lib()
+    N, Cin, Cout = pl.dims[0:3]
+    Ti_, Hi_, Wi_ = pl.dims[3:6]
+    xshape = (N, Cin, Ti_, Hi_, Wi_) if pl.is3d else (N, Cin, Hi_, Wi_)
+    xnumel = N * Cin * Ti_ * Hi_ * Wi_
+    dev = gy.device
+    gx = None
+    if pl.wino_dgrad and pl.wino3d:
+        dM = pl.dM
+        # virtual channels (flipped time tap, output channel): a "native" [3*Cout][dM][3][3] weight for the 2-D transform
+        U = _packed(w, frozen_w, ("wino-dgrad3d", dM), lambda: _wino_filter(
+            w[:, :dM].flip(2).permute(2, 0, 1, 3, 4).reshape(3 * Cout, dM, 3, 3).contiguous(), 3 * Cout, dM, 1))
+        gx = torch.empty(xshape, device=dev, dtype=torch.float32)
+        tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
+        g3 = pl.wino_dgrad_geom
+        npix = int(g3[2] * g3[5] * g3[6])
+        tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+        _lib.check(_timed("wino", pl.dgrad_flops,
+                          lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), None, None, _gp(g3), 0, 0.0, _stream()), tag,
+                          4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad 3-D")
+        if pl.reflect:
+            Ti, Hi, Wi = pl.dims[3:6]
+            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, _stream()), "reflect fold 3-D")
+        if dM < Cin:
+            gx[:, dM:].zero_()
+    elif pl.wino_dgrad:
+        U = _packed(w, frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
+        gx = torch.empty(xshape, device=dev, dtype=torch.float32)
+        npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
+        tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+        # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
+        tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
+        _lib.check(_timed("wino", pl.fwd_flops,
+                          lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
+                                                  _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
+                          4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad")
+        if pl.reflect:
+            Ti, Hi, Wi = pl.dims[3:6]
+            _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, _stream()),
+                       "reflect border add")
+    else:
+        S = pl.dgrad_splits
+        folded = pl.reflect and any(pl.pad)
+        two_target = folded and S == 1 and not pl.dgrad_needs_zero
+        alloc = torch.zeros if pl.dgrad_needs_zero else torch.empty
+        tgt = alloc(pl.dgrad_target, device=dev, dtype=torch.float32)
+        gx = torch.empty(xshape, device=dev, dtype=torch.float32) if folded else tgt.view(xshape)
+        dst = tgt if S == 1 else alloc(S * tgt.numel(), device=dev, dtype=torch.float32)
+        st, sh, sw = pl.stride
+        w5 = w if pl.is3d else w.unsqueeze(2)
+        cb = pl.cls_batch
+        if cb is not None:
+            kt, kh, kw = pl.dims[9:12]
+            A = _packed(w, frozen_w, ("dgrad-all", cb["ck"], pl.stride), lambda: _pack_native(
+                w, Cin, Cout, cb["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
+            for grp in cb["groups"]:
+                Ag = A[grp["first"] * Cin:]
+                tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
+                       pl.reflect, S)
+                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
+                                  pl.dgrad_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
+                                  lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
+                                                           None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
+                                                           _stream()), tag,
+                                  4 * (gy.numel() * grp["ncls"] // cb["ncls"] + w.numel() +
+                                       xnumel * grp["ncls"] // cb["ncls"])),
+                           "conv_igemm dgrad (batched classes)")
+        kt, kh, kw = pl.dims[9:12]
+        Aall = None
+        if cb is None and pl.classes_packable and not (pl.bf16 and all(c["patch"] for c in pl.classes)):
+            Aall = _packed(w, frozen_w, ("dgrad-all", pl.classes[0]["ck"], pl.stride), lambda: _pack_native(
+                w, Cin, Cout, pl.classes[0]["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
+        for ci, c in enumerate(pl.classes if cb is None else ()):
+            rt, ry, rx = c["r"]
+            A = _packed(w, frozen_w, ("dgrad-bf16-patch", pl.dM), lambda: _pack_bf16_patch(
+                w, pl.dM, Cout, 9, Cin * 9)) if (c["patch"] and pl.bf16) else \
+                Aall[ci * Cin:] if Aall is not None else _packed(
+                w, frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
+                    w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
+            tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
+            _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
+                              lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
+                                                       _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
+                              4 * (gy.numel() + w.numel() + xnumel) // len(pl.classes)), "conv_igemm dgrad")
+        if S > 1:
+            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
+                       "splitk_reduce dgrad")
+        if folded:
+            Ti, Hi, Wi = pl.dims[3:6]
+            fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
+            _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
+                       "reflect fold")
+        if pl.dM < Cin:
+            gx[:, pl.dM:].zero_()            # channels declared gradient-free by the caller (dgrad_rows)
+    return gx
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, reflect, act, dgrad_rows=None):
+    def forward(ctx, x, w, b, stride, pad, reflect, act, dgrad_rows=None, slope=LRELU_SLOPE):
         _dev(x, w, b)
+        ctx.slope = slope = float(slope)
         x, w = _f(x), _f(w)
         pl = _plan(x, w, stride, pad, reflect, dgrad_rows)
         L = _lib.lib()
@@ -641,7 +751,7 @@ class _ConvFn(torch.autograd.Function):
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
             _lib.check(_timed("wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                               lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
-                                                      LRELU_SLOPE, _stream()), tag,
+                                                      slope, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
@@ -656,11 +766,11 @@ class _ConvFn(torch.autograd.Function):
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                           lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
-                                                   ACT[act], LRELU_SLOPE, _stream()), tag,
+                                                   ACT[act], slope, _stream()), tag,
                           4 * (x.numel() + w.numel() + y.numel())), "conv_igemm fwd")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
-                                           LRELU_SLOPE, _stream()), "splitk_reduce")
+                                           slope, _stream()), "splitk_reduce")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
         return y
@@ -672,97 +782,12 @@ class _ConvFn(torch.autograd.Function):
         gy = _f(gy)
         if ACT[ctx.act]:
             g = torch.empty_like(gy)
-            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], LRELU_SLOPE, _stream()), "act_bwd")
+            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], ctx.slope, _stream()), "act_bwd")
             gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and pl.wino_dgrad and pl.wino3d:
-            dM = pl.dM
-            # virtual channels (flipped time tap, output channel): a "native" [3*Cout][dM][3][3] weight for the 2-D transform
-            U = _packed(w, ctx.frozen_w, ("wino-dgrad3d", dM), lambda: _wino_filter(
-                w[:, :dM].flip(2).permute(2, 0, 1, 3, 4).reshape(3 * Cout, dM, 3, 3).contiguous(), 3 * Cout, dM, 1))
-            gx = torch.empty_like(x)
-            tgt = torch.empty(pl.dgrad_target, device=x.device, dtype=torch.float32) if pl.reflect else gx
-            g3 = pl.wino_dgrad_geom
-            npix = int(g3[2] * g3[5] * g3[6])
-            tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("wino", pl.dgrad_flops,
-                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), None, None, _gp(g3), 0, 0.0, _stream()), tag,
-                              4 * (gy.numel() + w.numel() + x.numel())), "conv_wino dgrad 3-D")
-            if pl.reflect:
-                Ti, Hi, Wi = pl.dims[3:6]
-                _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, _stream()), "reflect fold 3-D")
-            if dM < Cin:
-                gx[:, dM:].zero_()
-        elif ctx.needs_input_grad[0] and pl.wino_dgrad:
-            U = _packed(w, ctx.frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
-            gx = torch.empty_like(x)
-            npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
-            tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
-            tgt = torch.empty(pl.dgrad_target, device=x.device, dtype=torch.float32) if pl.reflect else gx
-            _lib.check(_timed("wino", pl.fwd_flops,
-                              lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
-                                                      _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
-                              4 * (gy.numel() + w.numel() + x.numel())), "conv_wino dgrad")
-            if pl.reflect:
-                Ti, Hi, Wi = pl.dims[3:6]
-                _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, _stream()),
-                           "reflect border add")
-        elif ctx.needs_input_grad[0]:
-            S = pl.dgrad_splits
-            folded = pl.reflect and any(pl.pad)
-            two_target = folded and S == 1 and not pl.dgrad_needs_zero
-            alloc = torch.zeros if pl.dgrad_needs_zero else torch.empty
-            tgt = alloc(pl.dgrad_target, device=x.device, dtype=torch.float32)
-            gx = torch.empty_like(x) if folded else tgt.view(x.shape)
-            dst = tgt if S == 1 else alloc(S * tgt.numel(), device=x.device, dtype=torch.float32)
-            st, sh, sw = pl.stride
-            w5 = w if pl.is3d else w.unsqueeze(2)
-            cb = pl.cls_batch
-            if cb is not None:
-                kt, kh, kw = pl.dims[9:12]
-                A = _packed(w, ctx.frozen_w, ("dgrad-all", cb["ck"], pl.stride), lambda: _pack_native(
-                    w, Cin, Cout, cb["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
-                for grp in cb["groups"]:
-                    Ag = A[grp["first"] * Cin:]
-                    tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
-                           pl.reflect, S)
-                    _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
-                                      pl.dgrad_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
-                                      lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
-                                                               None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
-                                                               _stream()), tag,
-                                      4 * (gy.numel() * grp["ncls"] // cb["ncls"] + w.numel() +
-                                           x.numel() * grp["ncls"] // cb["ncls"])),
-                               "conv_igemm dgrad (batched classes)")
-            kt, kh, kw = pl.dims[9:12]
-            Aall = None
-            if cb is None and pl.classes_packable and not (pl.bf16 and all(c["patch"] for c in pl.classes)):
-                Aall = _packed(w, ctx.frozen_w, ("dgrad-all", pl.classes[0]["ck"], pl.stride), lambda: _pack_native(
-                    w, Cin, Cout, pl.classes[0]["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
-            for ci, c in enumerate(pl.classes if cb is None else ()):
-                rt, ry, rx = c["r"]
-                A = _packed(w, ctx.frozen_w, ("dgrad-bf16-patch", pl.dM), lambda: _pack_bf16_patch(
-                    w, pl.dM, Cout, 9, Cin * 9)) if (c["patch"] and pl.bf16) else \
-                    Aall[ci * Cin:] if Aall is not None else _packed(
-                    w, ctx.frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
-                        w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
-                tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
-                _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
-                                  lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
-                                                           _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
-                                  4 * (gy.numel() + w.numel() + x.numel()) // len(pl.classes)), "conv_igemm dgrad")
-            if S > 1:
-                _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
-                           "splitk_reduce dgrad")
-            if folded:
-                Ti, Hi, Wi = pl.dims[3:6]
-                fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
-                _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
-                           "reflect fold")
-            if pl.dM < Cin:
-                gx[:, pl.dM:].zero_()            # channels declared gradient-free by the caller (dgrad_rows)
+        if ctx.needs_input_grad[0]:
+            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:
             S = pl.wino_wg_splits
             Ti, Hi, Wi = pl.dims[3:6]
@@ -800,10 +825,10 @@ class _ConvFn(torch.autograd.Function):
                                                        _gp(pl.wg_geom), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgrad_channels=None):
+def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgrad_channels=None, slope=LRELU_SLOPE):
     """conv2d (4-D x) / conv3d (5-D x) with zero or reflect padding folded into the gather; bias + activation fused.
     dgrad_channels: the caller guarantees that only x[:, :dgrad_channels] needs a gradient (x is a concatenation whose tail
     carries no grad); the data gradient of the tail is returned as zeros instead of being computed."""
@@ -819,8 +844,41 @@ def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgra
     k = _chunks_for_2gib(x.shape, w.shape, stride3, pad3)
     if k > 1:
         size = _cdiv(n, k)
-        return torch.cat([_ConvFn.apply(xc, w, b, stride3, pad3, reflect, act, dgrad_channels) for xc in x.split(size)], 0)
-    return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act, dgrad_channels)
+        return torch.cat([_ConvFn.apply(xc, w, b, stride3, pad3, reflect, act, dgrad_channels, slope) for xc in x.split(size)], 0)
+    return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act, dgrad_channels, slope)
+
+
+def conv_transpose2d(x, w, b=None, stride=2, padding=1, act=None, slope=LRELU_SLOPE):
+    """nn.ConvTranspose2d(x; w [Cin, Cout, kh, kw], stride, padding) (+ bias, activation) for frozen, no-grad use (FlowNet2's
+    `deconv` / `upsampled_flow` layers, flownet2/networks/submodules.py:75-80): a transposed convolution IS the data gradient
+    of the convolution with the same weight tensor, so it runs on the stride-parity-class data-gradient kernels (no
+    zero-stuffed MACs).  Output size (H - 1) * stride - 2 * padding + k."""
+    _dev(x, w, b)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        raise RuntimeError("conv_transpose2d is forward-only (frozen flow network under no_grad)")
+    x, w = _f(x), _f(w)
+    N, Ci, H, W = x.shape
+    Co, kh, kw = w.shape[1], w.shape[2], w.shape[3]
+    s3, p3 = _triple(stride, 2), _pad3(padding, 2)
+    Ho, Wo = (H - 1) * s3[1] - 2 * p3[1] + kh, (W - 1) * s3[2] - 2 * p3[2] + kw
+    # the forward convolution whose data gradient this is: input [N, Co, Ho, Wo] (x of the plan), weight [Ci, Co, kh, kw]
+    key = ((N, Co, Ho, Wo), tuple(w.shape), s3, p3, False, x.device.index, _conv_bf16, None)
+    pl = _geom_cache.get(key)
+    if pl is None:
+        pl = _geom_cache[key] = _ConvPlan((N, Co, Ho, Wo), tuple(w.shape), s3, p3, False, x.device, _conv_bf16, None)
+        if _conv_bf16:
+            pl.fwd_geom[34] = pl.wg_geom[34] = 1
+            for c in pl.classes:
+                c["geom"][34] = 1
+            for grp in (pl.cls_batch["groups"] if pl.cls_batch else ()):
+                grp["geom"][34] = 1
+    if pl.out_shape != (N, Ci, H, W):
+        raise ValueError(f"conv_transpose2d: inconsistent geometry {tuple(x.shape)} vs {pl.out_shape}")
+    with torch.no_grad():
+        y = _conv_dgrad(pl, w, x, True)
+        if b is not None or ACT[act]:
+            _lib.check(_lib.lib().c2m_bias_act(_p(y), _p(b), N, Co, Ho * Wo, ACT[act], float(slope), _stream()), "bias_act")
+    return y
 
 
 _MAX_TENSOR_BYTES = int(0.9 * 2 ** 31)      # 10 % margin: the Winograd data gradient rounds its padded domain up to whole tiles
@@ -933,6 +991,45 @@ class _FlowWarpFn(torch.autograd.Function):
 def flow_warp(img, flow, occ=None):
     """utils.resample(img, flow) [* occ]: backward warp with pixel-unit flow (reference coordinate quirk included)."""
     return _FlowWarpFn.apply(img, flow, occ)
+
+
+def resample2d(img, flow):
+    """FlowNet2 Resample2d (kernel_size 1, bilinear): img [N,C,H,W] sampled at (x + flow[:,0], y + flow[:,1]), taps clamped to
+    the border (third_party/resample2d/src/resample2d_kernel.cu:16-75).  Forward only."""
+    _dev(img, flow)
+    img, flow = _f(img.detach()), _f(flow.detach())
+    N, C, H, W = img.shape
+    assert flow.shape == (N, 2, H, W)
+    out = torch.empty_like(img)
+    _lib.check(_lib.lib().c2m_resample2d_fwd(_p(img), _p(flow), _p(out), N, C, H, W, _stream()), "resample2d")
+    return out
+
+
+def channelnorm(x):
+    """FlowNet2 ChannelNorm: sqrt(sum_c x^2) -> [N,1,H,W] (third_party/channelnorm/src/channelnorm_kernel.cu:19-62)."""
+    _dev(x)
+    x = _f(x.detach())
+    N, C, H, W = x.shape
+    out = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().c2m_channelnorm_fwd(_p(x), _p(out), N, C, H, W, _stream()), "channelnorm")
+    return out
+
+
+def correlation(a, b, pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2):
+    """FlowNetC cost volume (third_party/correlation/src/correlation_cuda_kernel.cu:47-147; defaults = flownet_c.py:44-46):
+    [N,C,H,W] x [N,C,H,W] -> [N, (2*(max_displacement//stride2)+1)^2, oH, oW]."""
+    _dev(a, b)
+    a, b = _f(a.detach()), _f(b.detach())
+    assert a.shape == b.shape
+    N, C, H, W = a.shape
+    L = _lib.lib()
+    D = 2 * (max_displacement // stride2) + 1
+    oH = L.c2m_correlation_out_size(H, pad_size, kernel_size, max_displacement, stride1)
+    oW = L.c2m_correlation_out_size(W, pad_size, kernel_size, max_displacement, stride1)
+    out = torch.empty(N, D * D, oH, oW, device=a.device, dtype=torch.float32)
+    _lib.check(L.c2m_correlation_fwd(_p(a), _p(b), _p(out), N, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                     stride2, _stream()), "correlation")
+    return out
 
 
 class _Upsample2xFn(torch.autograd.Function):

@@ -155,6 +155,20 @@ int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int N
 int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
 int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
 
+/* ---- FlowNet2 operators of the online target-flow path (flownet_ops.hip) -----------------------------
+ * Replace the reference's CUDA extensions, forward only (the flow net runs frozen under no_grad, flow_net.py:32,66-67):
+ * resample2d/src/resample2d_kernel.cu:16-75 (bilinear warp, pixel-unit flow, border clamp; caller flownet2/models.py:127,
+ * 146,166,177), channelnorm/src/channelnorm_kernel.cu:19-62 (L2 norm over channels -> [N,1,H,W]; models.py:130,148,165,
+ * 175), correlation/src/correlation_cuda_kernel.cu:47-147 (+ correlation_cuda.cc:25-38 output size; FlowNetC cost volume,
+ * networks/flownet_c.py:44-46).  c2m_bias_act: bias + activation in place, the epilogue of the transposed convolutions
+ * (networks/submodules.py:75-80), whose matrix part runs on c2m_conv_igemm's data-gradient form.                          */
+int c2m_resample2d_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream);
+int c2m_channelnorm_fwd(const float* x, float* out, int N, int C, int H, int W, void* stream);
+int c2m_correlation_out_size(int H, int pad, int kernel_size, int max_displacement, int stride1);
+int c2m_correlation_fwd(const float* in1, const float* in2, float* out, int N, int C, int H, int W, int pad,
+                        int kernel_size, int max_displacement, int stride1, int stride2, void* stream);
+int c2m_bias_act(float* x, const float* bias, long N, int C, long HW, int act, float slope, void* stream);
+
 /* ---- sparse-motion raster + occlusion splat (motion_raster.hip): bit-exact index/mask path ------------------
  * motion_estimator/dense_motion.py:94-168 generate_sparse_motion/warp/clip_mask;
  * utils/ops.py:205-275 get_occlusion_map/get_corresponding_map.                                              */

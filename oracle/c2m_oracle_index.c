@@ -174,3 +174,89 @@ void oc_occlusion_splat(const float* flow, float* occ, int B, int H, int W) {
         for (long i = 0; i < HW; ++i) acc[i] = fminf(fmaxf(acc[i], 0.0f), 1.0f);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * FlowNet2's three custom operators, forward.  The reference implements them as CUDA extensions
+ * (src/modules/third_party/{resample2d,channelnorm,correlation}/src/ *.cu) that cannot be built or run here, and holds no
+ * fixtures for them: PARITY UNPINNED -- restated from the kernel sources, statement by statement.
+ *
+ *   oc_resample2d   resample2d_kernel.cu:16-75   bilinear, kernel_size 1: xf = x + dx, alpha = xf - floor(xf), taps
+ *                   clamped to [0, W-1]; the terms (1.-alpha)*(1.-beta)*v, alpha*(1.-beta)*v, (1.-alpha)*beta*v are
+ *                   double products rounded to float, alpha*beta*v is a float product; summed in that order in float.
+ *   oc_channelnorm  channelnorm_kernel.cu:19-62  sqrt(sum_c v*v), float, ascending channels.
+ *   oc_correlation  correlation_cuda_kernel.cu:74-147 + correlation_cuda.cc:25-38: zero-padded inputs, displacement grid
+ *                   (2*(max_displacement/stride2)+1)^2, sum over the k x k patch and all channels of in1 * in2(shifted),
+ *                   divided by k*k*C.  The CUDA kernel spreads the channels over 32 lanes and tree-reduces; the sum here
+ *                   runs patch row, patch column, channel ascending (a different fp32 rounding of the same sum; the HIP
+ *                   kernel uses THIS order, so the two agree bit for bit).                                           */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void oc_resample2d(const float* img, const float* flow, float* out, int N, int C, int H, int W) {
+    const long HW = (long)H * W;
+    for (int b = 0; b < N; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const float dx = flow[((long)b * 2 + 0) * HW + (long)y * W + x];
+                const float dy = flow[((long)b * 2 + 1) * HW + (long)y * W + x];
+                const float xf = (float)x + dx, yf = (float)y + dy;
+                const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+                const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)(floorf(xf) + 1.0f), 0, W - 1);
+                const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)(floorf(yf) + 1.0f), 0, H - 1);
+                for (int c = 0; c < C; ++c) {
+                    const float* p = img + ((long)b * C + c) * HW;
+                    float val = 0.0f;
+                    val += (float)((1. - alpha) * (1. - beta) * p[(long)yT * W + xL]);
+                    val += (float)((alpha) * (1. - beta) * p[(long)yT * W + xR]);
+                    val += (float)((1. - alpha) * (beta) * p[(long)yB * W + xL]);
+                    val += (float)((alpha) * (beta) * p[(long)yB * W + xR]);
+                    out[((long)b * C + c) * HW + (long)y * W + x] = val;
+                }
+            }
+}
+
+void oc_channelnorm(const float* x, float* out, int N, int C, long HW) {
+    for (long b = 0; b < N; ++b)
+        for (long sp = 0; sp < HW; ++sp) {
+            float acc = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float v = x[(b * C + c) * HW + sp];
+                acc += v * v;
+            }
+            out[b * HW + sp] = sqrtf(acc);
+        }
+}
+
+int oc_correlation_out_size(int H, int pad, int kernel_size, int max_displacement, int stride1) {
+    const int border = (kernel_size - 1) / 2 + max_displacement;
+    const float span = (float)(H + 2 * pad - 2 * border);
+    return span <= 0 ? 0 : (int)ceilf(span / (float)stride1);
+}
+
+void oc_correlation(const float* in1, const float* in2, float* out, int N, int C, int H, int W, int pad, int kernel_size,
+                    int max_displacement, int stride1, int stride2) {
+    const int krad = (kernel_size - 1) / 2, drad = max_displacement / stride2, D = 2 * drad + 1;
+    const int oH = oc_correlation_out_size(H, pad, kernel_size, max_displacement, stride1);
+    const int oW = oc_correlation_out_size(W, pad, kernel_size, max_displacement, stride1);
+    const long HW = (long)H * W;
+    const float nelems = (float)(kernel_size * kernel_size * C);
+    for (long n = 0; n < N; ++n)
+        for (int tj = -drad; tj <= drad; ++tj)
+            for (int ti = -drad; ti <= drad; ++ti)
+                for (int oy = 0; oy < oH; ++oy)
+                    for (int ox = 0; ox < oW; ++ox) {
+                        /* padded coordinates y1 = oy*stride1 + max_displacement; unpadded = y1 - pad */
+                        const int y1 = oy * stride1 + max_displacement - pad, x1 = ox * stride1 + max_displacement - pad;
+                        const int y2 = y1 + tj * stride2, x2 = x1 + ti * stride2;
+                        float acc = 0.0f;
+                        for (int j = -krad; j <= krad; ++j)
+                            for (int i = -krad; i <= krad; ++i) {
+                                const int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+                                if (ya < 0 || ya >= H || xa < 0 || xa >= W || yb < 0 || yb >= H || xb < 0 || xb >= W)
+                                    continue;               /* a zero-padded operand */
+                                for (int c = 0; c < C; ++c)
+                                    acc += in1[(n * C + c) * HW + (long)ya * W + xa] * in2[(n * C + c) * HW + (long)yb * W + xb];
+                            }
+                        const int tc = (tj + drad) * D + (ti + drad);
+                        out[((n * D * D + tc) * oH + oy) * (long)oW + ox] = acc / nelems;
+                    }
+}

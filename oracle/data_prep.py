@@ -1,10 +1,13 @@
 """TEST INFRASTRUCTURE (oracle) -- CPU restatement of the sample-building arithmetic of the reference's dataset class
-(src/datasets/cityscapes.py), from decoded arrays to the tensors of the batch dict.  torchvision's ToTensor is an absent
-third-party dependency (unpinned); its published behaviour is restated: uint8 HWC ndarray -> CHW float32
-`.div(255)`; non-uint8 arrays are only transposed.  "parity unpinned" for the image / mask functions: the reference has
-no fixtures for its dataset code and they need torchvision + image files to run.  The scene-graph and .flo functions at the
-end of the file ARE pinned: tests/golden/data_scene_graph.npz holds the live reference's outputs on committed track files.
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module."""
+(src/datasets/cityscapes.py), from decoded arrays to the tensors of the batch dict.
+PINNED (round 3): tests/golden/data_dataset_prep.npz holds what the LIVE reference's own functions
+(cityscapes.py:20-70 replace_index_and_read_frame / read_video, :195-199 load_tracking_mask, :208-231 load_instance /
+load_optical_flow, :234-265 load_optical_flow_occlusion_mask / clip_mask) built from PNG / .flo files that
+oracle/capture_golden.py::capture_dataset wrote from the stored arrays (PIL decodes them; the one stand-in is torchvision's
+ToTensor -- an absent, un-vendored third-party dependency whose published behaviour is restated: uint8 HWC -> CHW float32
+`.div(255)`, other dtypes only transposed); tests/test_data_graph.py holds every function below to it bit for bit.
+The scene-graph and .flo functions at the end of the file are pinned by tests/golden/data_scene_graph.npz (live reference on
+committed track files).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module."""
 import torch
 
 

@@ -91,8 +91,32 @@ def install():
         def __init__(self, ts):
             self.ts = ts
 
-    ident = lambda *a, **k: None
-    tr = _mod("torchvision.transforms", Compose=_Compose, ToTensor=ident, Normalize=ident, Resize=ident)
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class _ToTensor:
+        """torchvision.transforms.ToTensor (absent third-party dependency; published behaviour restated, "unpinned"):
+        PIL image -> ndarray (HWC), ndarray [H,W] -> [H,W,1]; CHW tensor; uint8 -> float32 / 255, other dtypes unchanged.
+        Only capture_dataset() calls it -- what it pins is the reference's OWN code around it (cityscapes.py:20-70,195-265)."""
+
+        def __call__(self, pic):
+            import numpy as np
+            arr = pic if isinstance(pic, np.ndarray) else np.array(pic)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            img = torch.from_numpy(np.ascontiguousarray(arr.transpose((2, 0, 1))))
+            return img.to(torch.float32).div(255) if img.dtype == torch.uint8 else img
+
+    class _Unused:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            raise RuntimeError("torchvision stand-in: this transform is not restated (the capture never needs it)")
+
+    tr = _mod("torchvision.transforms", Compose=_Compose, ToTensor=_ToTensor, Normalize=_Unused, Resize=_Unused)
     ops = _mod("torchvision.ops", roi_align=thirdparty.roi_align, roi_pool=None)
     models = _mod("torchvision.models", vgg19=_vgg19)
     _mod("torchvision", transforms=tr, ops=ops, models=models)

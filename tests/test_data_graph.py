@@ -104,3 +104,26 @@ def test_collate_samples_and_tracking_mask():
     out = G.collate([sample, sample])
     assert out["video"].shape == (2, 3, 7, 16, 32) and out["tracking_gnn"].num_nodes == 6
     assert out["complete_list"] == [["a", "b"], ["a", "b"]]
+
+
+# ------------------------------------------------------------------------ image / mask half of the dataset code (round 3)
+def test_oracle_dataset_prep_matches_the_reference():
+    """oracle/data_prep.py vs the tensors the LIVE reference built (datasets/cityscapes.py:20-70,195-265, run by
+    oracle/capture_golden.py::capture_dataset on PNG / .flo files written from the stored arrays): bit-exact.  This pins the
+    oracle the GPU kernels of data_prep.hip are held to."""
+    c = Case("data_dataset_prep")
+    i, o = c.group("in"), c.group("out")
+    assert torch.equal(D.read_video(i["frames"].numpy()), o["video"])
+    bg, fg = D.read_seg_masks(i["labels"].numpy())
+    assert torch.equal(bg, o["bg_mask"]) and torch.equal(fg, o["fg_mask"])
+    assert float(bg.sum() + fg.sum()) == float((i["labels"] < 20).sum())
+    assert torch.equal(i["inst"].unsqueeze(0), o["instance_mask"])                       # ToTensor of an integer array: ids as they are
+    occ, flow = D.load_flow_occ(i["occ"][1:].numpy(), i["flow"][1:].numpy())             # frames 1..T-1 (cityscapes.py:239)
+    assert torch.equal(occ, o["target_bw_occ"]) and torch.equal(flow, o["target_bw_of"])
+    assert set(o["target_bw_occ"].unique().tolist()) <= {0.0, 1.0}
+    # tracking mask: the ids of the committed track files, per frame
+    tracks = _tracks(c.meta["track_prefix"])
+    info = D.scene_info(tracks, (c.meta["H"], c.meta["W"]), 2, c.meta["T"])
+    tm = G.tracking_mask(i["inst"], torch.from_numpy(info["tracking_ids"]))
+    assert torch.equal(tm, o["tracking_mask"].unsqueeze(0) if o["tracking_mask"].dim() == 3 else o["tracking_mask"])
+    assert 0 < float(tm.sum()) < float((i["inst"] > 0).sum())                            # the untracked instance stays 0

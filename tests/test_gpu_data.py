@@ -106,3 +106,24 @@ def test_track_file_graphs_drive_the_model():
     total.backward()
     assert np.isfinite(float(total)) and out["generated"].shape == (B, 3, 5, H, W)
     assert float(out["sparse_motion_bin"].sum()) > 0, "the rasteriser found the tracked instances"
+
+
+def test_prep_kernels_bitexact_vs_reference_capture():
+    """data_prep.hip vs the LIVE reference's dataset code (tests/golden/data_dataset_prep.npz, captured from
+    datasets/cityscapes.py:20-70,195-265 on files written from the stored arrays): video, one-hot split, instance ids,
+    occlusion clip and .flo layout bit-exact, and the tracking mask built on the device."""
+    from golden_io import Case
+    from c2m_amd import graph as G
+    c = Case("data_dataset_prep")
+    i, o = c.group("in"), c.group("out")
+    dev = lambda t: t.unsqueeze(0).to(DEV)
+    batch = data.assemble_batch(dev(i["frames"]), dev(i["labels"]), dev(i["inst"]), dev(i["occ"][1:]), dev(i["flow"][1:]), None)
+    for k in ("video", "bg_mask", "fg_mask", "instance_mask", "target_bw_occ", "target_bw_of"):
+        assert torch.equal(batch[k][0].cpu(), o[k]), k
+    import glob, os
+    from golden_io import GOLDEN
+    tracks = [open(p).read().splitlines() for p in sorted(glob.glob(os.path.join(GOLDEN, "scene_tracks", c.meta["track_prefix"]) + "*.txt"))]
+    ids, _ = G.scene_graph(tracks, (c.meta["H"], c.meta["W"]), 2, c.meta["T"])
+    tm = G.tracking_mask(batch["instance_mask"][0], torch.as_tensor(ids))
+    want = o["tracking_mask"]
+    assert torch.equal(tm.cpu().reshape(want.shape), want)
