@@ -22,7 +22,7 @@ _MODULE_ALIASES = [
     "modules.motion_estimator.sparse_motion_estimator", "modules.appearance_encoder",
     "modules.appearance_encoder.appearance_encoder", "modules.discriminator",
     "modules.discriminator.discriminator", "modules.third_party", "modules.third_party.flow_net",
-    "modules.third_party.flow_net.flow_net", "losses", "losses.losses"]
+    "modules.third_party.flow_net.flow_net", "modules.third_party.flow_net.flownet2", "losses", "losses.losses"]
 
 # hot-path functions of the reference's utils package (src/utils/ops.py:187-202,263-275, src/utils/utils.py:346-379)
 # that are replaced by the HIP-backed ones; every other member of the reference's `utils` is left untouched

@@ -27,6 +27,41 @@ def init_distributed():
     return int(os.environ.get("RANK", "0")), local_rank, world
 
 
+def compute_flow(flownet, train_batch, train_params):
+    """Trainer.compute_flow (src/trainer/trainer.py:42-98): optical flow + occlusion targets from the frozen flow net when
+    `use_pre_processed_of` is False.  Forward flow between consecutive input frames -> `input_of` / `input_occ` (the
+    occlusion comes from the reverse pair); between the last input frame and every predicted frame both directions ->
+    `target_bw_of` / `target_bw_occ` (and `target_fw_*` when `use_fw_of`).  Frames are mapped to [-1, 1] first.
+    The 2 * (t_in - 1 + t_out) flow-net passes of the reference loop are issued as ONE batched pass: the pairs are
+    independent images and every kernel of the net is batch-wise bit-deterministic."""
+    t_in, t_out = train_params["num_input_frames"], train_params["num_predicted_frames"]
+    video = train_batch["video"]
+    b = video.shape[0]
+    frame = lambda i: video[:, :, i] * 2 - 1
+    pairs = []                                           # (a, b) frame indices: flow a -> b, occlusion map of that flow
+    for i in range(t_in - 1):
+        pairs += [(i, i + 1), (i + 1, i)]
+    for i in range(t_out):
+        pairs += [(t_in - 1, t_in + i), (t_in + i, t_in - 1)]
+    A = torch.cat([frame(a) for a, _ in pairs], 0)
+    B = torch.cat([frame(c) for _, c in pairs], 0)
+    flow, conf = flownet(A, B)
+    flow = [f.unsqueeze(2) for f in flow.split(b)]
+    conf = [c.unsqueeze(2) for c in conf.split(b)]
+    n_in = t_in - 1
+    out = {}
+    # input frames: forward flow of (i -> i+1), confidence of the REVERSE pair (trainer.py:63-69)
+    out["input_of"] = torch.cat([flow[2 * i] for i in range(n_in)], dim=2) if n_in else None
+    out["input_occ"] = torch.cat([conf[2 * i + 1] for i in range(n_in)], dim=2) if n_in else None
+    fw = [2 * n_in + 2 * i for i in range(t_out)]      # (last input -> target i); +1: the reverse pair
+    out["target_bw_of"] = torch.cat([flow[k + 1] for k in fw], dim=2)
+    out["target_bw_occ"] = torch.cat([conf[k] for k in fw], dim=2)
+    if train_params.get("use_fw_of", False):
+        out["target_fw_of"] = torch.cat([flow[k] for k in fw], dim=2)
+        out["target_fw_occ"] = torch.cat([conf[k + 1] for k in fw], dim=2)
+    return out
+
+
 class TrainStep:
     def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0,
                  force_collectives=False, measure_comm=False, comm_dtype=torch.float32):

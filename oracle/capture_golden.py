@@ -536,6 +536,45 @@ def capture_dataset(ref_utils):
     save("data_dataset_prep", meta, arrays)
 
 
+def capture_flownet(ref_utils):
+    """SURVEY 8f-4.  The reference's OWN FlowNet2 graph (flownet2/models.py + networks/*.py: module tree, initialisation,
+    stage wiring), its FlowNet.forward / compute_flow_and_conf (flow_net.py:34-88) and Trainer.compute_flow
+    (trainer/trainer.py:42-98) run live on CPU; only the three CUDA extensions are stand-ins backed by our C restatements
+    (ref_shims: parity for those three kernels is unpinned).  Weights: the reference's seeded random init (162.5 M
+    parameters are not stored -- the product must reproduce them from the same seed: per-key fingerprints are stored)."""
+    from modules.third_party.flow_net.flownet2 import models as ref_models
+    from modules.third_party.flow_net.flow_net import FlowNet as RefFlowNet
+    RefTrainer = ref_shims.import_reference("trainer.trainer").Trainer
+    seed, H, W = 1234, 64, 128
+    torch.manual_seed(seed)
+    net = ref_models.FlowNet2(types.SimpleNamespace(fp16=False, rgb_max=1.0)).eval()
+    arrays = {}
+    meta = dict(seed=seed, H=H, W=W, nparams=sum(p.numel() for p in net.parameters()),
+                spec=state_spec(net.state_dict()), video=dict(seed=77, shape=[1, 3, 7, H, W], kind="rand"))
+    arrays["init.fingerprints"] = np.stack([summarize(v) for v in net.state_dict().values()])
+    fn = RefFlowNet.__new__(RefFlowNet)          # its __init__ hard-codes .to('cuda') and a download (flow_net.py:25-31)
+    torch.nn.Module.__init__(fn)
+    fn.flowNet = net
+    video = synth_input(meta["video"])
+    with torch.no_grad():
+        a, b = video[:, :, 1] * 2 - 1, video[:, :, 2] * 2 - 1
+        flow, conf = fn(a, b)
+        arrays.update(compact("pair", "flow", flow))
+        arrays.update(compact("pair", "conf", conf))
+        for tag, t in (("netc", net.flownetc(torch.cat((a - a.mean(), b - b.mean()), 1))[0]),):
+            arrays.update(compact("pair", tag, t))
+        odd_a = torch.nn.functional.interpolate(a, size=(80, 144), mode="bilinear", align_corners=False)
+        odd_b = torch.nn.functional.interpolate(b, size=(80, 144), mode="bilinear", align_corners=False)
+        f2, c2 = fn(odd_a, odd_b)                  # 80 x 144: resized to 64 x 128 and back (flow_net.py:58-63, 83-87)
+        arrays.update(compact("odd", "flow", f2))
+        arrays.update(compact("odd", "conf", c2))
+        fake = types.SimpleNamespace(train_params=dict(num_input_frames=2, num_predicted_frames=5, use_fw_of=True), flownet=fn)
+        out = RefTrainer.compute_flow(fake, {"video": video})
+    for k, v in out.items():
+        arrays.update(compact("cf", k, v))
+    save("flownet2_compute_flow", meta, arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_utils = ref_shims.install()
@@ -546,6 +585,9 @@ def main():
         return
     if "--data-only" in sys.argv:           # likewise
         capture_data(ref_utils)
+        return
+    if "--flownet-only" in sys.argv:        # likewise (round 3: SURVEY 8f-4)
+        capture_flownet(ref_utils)
         return
     if "--dataset-only" in sys.argv:        # likewise (round 3: pins SURVEY 8f-3's image / mask half)
         capture_dataset(ref_utils)
@@ -568,6 +610,8 @@ def main():
     print("data")
     capture_data(ref_utils)
     capture_dataset(ref_utils)
+    print("flownet")
+    capture_flownet(ref_utils)
 
 
 if __name__ == "__main__":

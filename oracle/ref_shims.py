@@ -124,6 +124,36 @@ def install():
     gnn = _mod("torch_geometric.nn", GATv2Conv=_GATv2Conv, MessagePassing=_MessagePassing, Sequential=None)
     _mod("torch_geometric", data=data, nn=gnn)
 
+    # FlowNet2's three CUDA extensions (top-level packages `resample2d`, `channelnorm`, `correlation`, built by the
+    # reference's setup.py files): module objects whose layers call OUR C restatements (thirdparty.resample2d / ...).
+    class _Resample2d(nn.Module):
+        def __init__(self, kernel_size=1, bilinear=True):
+            super().__init__()
+            assert kernel_size == 1 and bilinear
+
+        def forward(self, input1, input2):
+            return thirdparty.resample2d(input1, input2)
+
+    class _ChannelNorm(nn.Module):
+        def __init__(self, norm_deg=2):
+            super().__init__()
+            assert norm_deg == 2
+
+        def forward(self, x):
+            return thirdparty.channelnorm(x)
+
+    class _Correlation(nn.Module):
+        def __init__(self, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2, corr_multiply=1):
+            super().__init__()
+            self.cfg = (pad_size, kernel_size, max_displacement, stride1, stride2)
+
+        def forward(self, a, b):
+            return thirdparty.correlation(a, b, *self.cfg)
+
+    _mod("resample2d", Resample2d=_Resample2d)
+    _mod("channelnorm", ChannelNorm=_ChannelNorm)
+    _mod("correlation", Correlation=_Correlation)
+
     if REF_SRC not in sys.path:
         sys.path.insert(0, REF_SRC)
     import utils.ops as ref_ops  # noqa: the reference's utils package
@@ -146,3 +176,37 @@ def install():
 
     ref_disc.GANLoss.get_target_tensor = get_target_tensor_cpu
     return ref_utils
+
+
+class _Anything(types.ModuleType):
+    """Import-only stand-in for a module the reference imports but never calls on the captured path (dominate,
+    tensorboard ...): any attribute is another stand-in, calling it returns None."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.__path__ = []
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        m = _Anything(self.__name__ + "." + k)
+        sys.modules[m.__name__] = m
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return None
+
+
+def import_reference(name, max_stubs=32):
+    """importlib.import_module(name) for a reference module, injecting an empty stand-in for every absent third-party
+    package it trips over (observability / metrics imports of trainer/base.py: dominate, tensorboard ...)."""
+    import importlib
+    for _ in range(max_stubs):
+        try:
+            return importlib.import_module(name)
+        except ModuleNotFoundError as e:
+            if not e.name or e.name.split(".")[0] in ("modules", "utils", "trainer", "datasets", "losses"):
+                raise
+            sys.modules[e.name] = _Anything(e.name)
+    raise ImportError(name)

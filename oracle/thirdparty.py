@@ -152,3 +152,50 @@ def gatv2_conv(x, edge_index, lin_l_w, lin_l_b, lin_r_w, lin_r_b, att, bias, hea
     msg = xl[src] * alpha.unsqueeze(-1)
     out = torch.zeros((N, H, C), dtype=x.dtype, device=x.device).index_add(0, dst, msg)
     return out.mean(dim=1) + bias
+
+
+# ------------------------------------------------------------------------------------------------ FlowNet2 operators
+# Python faces of the C restatements in oracle/c2m_oracle_index.c (oc_resample2d / oc_channelnorm / oc_correlation) of the
+# reference's CUDA extensions src/modules/third_party/{resample2d,channelnorm,correlation} -- "parity unpinned": the
+# extensions cannot be built here and the reference holds no fixtures for them.  CPU float32 tensors in, tensors out.
+def _oc():
+    import ctypes
+    from . import build as _build
+    L = _build.load()
+    L.oc_correlation_out_size.restype = ctypes.c_int
+    return L, ctypes
+
+
+def _fp(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def resample2d(img, flow):
+    L, ct = _oc()
+    img, flow = img.detach().contiguous().float(), flow.detach().contiguous().float()
+    N, C, H, W = img.shape
+    out = torch.empty_like(img)
+    L.oc_resample2d(_fp(img), _fp(flow), _fp(out), N, C, H, W)
+    return out
+
+
+def channelnorm(x):
+    L, ct = _oc()
+    x = x.detach().contiguous().float()
+    N, C, H, W = x.shape
+    out = torch.empty(N, 1, H, W)
+    L.oc_channelnorm(_fp(x), _fp(out), N, C, ct.c_long(H * W))
+    return out
+
+
+def correlation(a, b, pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2):
+    L, ct = _oc()
+    a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
+    N, C, H, W = a.shape
+    D = 2 * (max_displacement // stride2) + 1
+    oH = L.oc_correlation_out_size(H, pad_size, kernel_size, max_displacement, stride1)
+    oW = L.oc_correlation_out_size(W, pad_size, kernel_size, max_displacement, stride1)
+    out = torch.empty(N, D * D, oH, oW)
+    L.oc_correlation(_fp(a), _fp(b), _fp(out), N, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    return out
