@@ -13,13 +13,13 @@ c_void_p, c_int, c_long, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctyp
 
 _SIGS = {
     "c2m_conv_igemm": (c_int, [c_void_p] * 7 + [c_int, c_float, c_void_p]),
-    "c2m_reflect_border_add": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
+    "c2m_reflect_border_add": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 7 + [c_void_p]),
     "c2m_conv_igemm_splits": (c_int, [c_int, c_int, c_int]),
-    "c2m_splitk_reduce": (c_int, [c_void_p] * 3 + [c_long, c_int, c_long, c_int, c_int, c_float, c_void_p]),
+    "c2m_splitk_reduce": (c_int, [c_void_p] * 3 + [c_long, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_conv_wgrad_splits": (c_int, [c_int, c_int, c_int]),
     "c2m_conv_wgrad_rows": (c_int, [c_int, c_int]),
     "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
-    "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 6 + [c_void_p]),
+    "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 7 + [c_void_p]),
     "c2m_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "c2m_pack_weights_bf16_patch_bytes": (c_long, [c_int, c_int]),
     "c2m_pack_weights_bf16_patch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -39,30 +39,30 @@ _SIGS = {
     "c2m_adam_chunk": (c_int, []),
     "c2m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_double] * 5 + [c_void_p]),
     "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),
-    "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_void_p]),
-    "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
-    "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_void_p]),
-    "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_void_p]),
+    "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_int, c_void_p]),
+    "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_int, c_void_p]),
     "c2m_resample2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "c2m_channelnorm_fwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "c2m_correlation_out_size": (c_int, [c_int] * 5),
     "c2m_correlation_fwd": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
     "c2m_bias_act": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_float, c_void_p]),
-    "c2m_flow_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "c2m_flow_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "c2m_flow_warp_bwd_workspace_bytes": (c_long, [c_int] * 6),
-    "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p]),
-    "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_void_p]),
-    "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
-    "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_flow_warp_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_int, c_void_p]),
+    "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_int, c_void_p]),
+    "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "c2m_roi_align_bwd": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_float, c_void_p]),
-    "c2m_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
-    "c2m_maxpool2x2_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p]),
+    "c2m_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    "c2m_maxpool2x2_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_sparse_raster": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "c2m_occlusion_splat_workspace_bytes": (c_long, [c_long, c_int, c_int]),
     "c2m_occlusion_splat": (c_int, [c_void_p, c_long, c_long, c_long] + [c_int] * 4 + [c_void_p] * 4),
-    "c2m_l1_mean_fwd": (c_int, [c_void_p] * 4 + [c_long, c_int, c_long, c_void_p, c_void_p]),
-    "c2m_l1_mean_bwd": (c_int, [c_void_p] * 6 + [c_long, c_int, c_long, c_void_p]),
+    "c2m_l1_mean_fwd": (c_int, [c_void_p] * 4 + [c_long, c_int, c_long, c_void_p, c_int, c_void_p]),
+    "c2m_l1_mean_bwd": (c_int, [c_void_p] * 6 + [c_long, c_int, c_long, c_int, c_void_p]),
     "c2m_ssim_fwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p, c_void_p]),
     "c2m_ssim_bwd": (c_int, [c_void_p] * 5 + [c_long, c_int, c_int, c_void_p]),
 }

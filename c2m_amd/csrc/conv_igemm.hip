@@ -21,6 +21,7 @@
 //
 // Tiling: 256 threads = 4 waves, BK = 16, register-prefetched + double-buffered LDS, one barrier per K-step.
 #include "common.h"
+#include "dtype.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -54,6 +55,10 @@ struct ConvP {
     // class batching (stride-s data gradient: the s^d parity classes share every dimension and differ only in
     // weights, tap table and output origin): blockIdx.z = cls * splits + split
     int ncls, splits, ktab_cls;       // ktab_cls: int4 entries per class table
+    // bf16 data path (dtype.h): the bf16-operand kernels (BF) gather X as bf16 ALWAYS -- the host casts fp32 inputs once -- and
+    // write Y / Y2 as bf16 when yh is set and the launch stores results directly (split-K slabs stay fp32).  The fp32 kernels
+    // and the vector-ALU thin kernels read fp32 X, or bf16 X when xh is set (thin kernels only).
+    int xh, yh;
     long a_cls;                       // floats per class weight matrix
     long out_off_c[8];
     int po_c[8][3];
@@ -87,9 +92,9 @@ template <int MI, int NI>
 __device__ __forceinline__ void c2m_store_tile_fast(const f32x16 (&acc)[MI][NI], float* __restrict__ ybase,
                                                     const unsigned (&voff)[NI], const int row0, const long row_stride,
                                                     const float* __restrict__ bias, const bool direct, const int act,
-                                                    const float slope, const int lane) {
+                                                    const float slope, const int lane, const bool yh = false) {
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, 0x80000000u, 0x00020000);
-    const int rs4 = (int)row_stride * 4;
+    const int rs4 = (int)row_stride * (yh ? 2 : 4);      // voff[] is in bytes of the output element type as well
     float bv[MI][16];
     if (direct && bias) {
         const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 0x80000000u, 0x00020000);
@@ -114,7 +119,8 @@ __device__ __forceinline__ void c2m_store_tile_fast(const f32x16 (&acc)[MI][NI],
             _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                           \
                 float v = acc[i][j][r] + bv[i][r];                                                                     \
                 v = (EXPR);                                                                                            \
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, voff[j], soff, 0);          \
+                if (yh) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)v), yr, voff[j], soff, 0); \
+                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, voff[j], soff, 0);     \
             }                                                                                                          \
         }
     if (a == C2M_ACT_NONE)       { C2M_STORE_LOOP(v) }
@@ -193,7 +199,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[U][APASS];
-    float rb[U][BPASS];
+    float rb[BF ? 1 : U][BF ? 1 : BPASS];
+    unsigned short rh[BF ? U : 1][BF ? BPASS : 1];     // BF: X is bf16 in HBM, gathered as raw 16-bit values
+    constexpr int XES = BF ? 2 : 4;                     // bytes per gathered element
 
     // per-thread weight row pointers (fixed for the whole K loop)
     const float* __restrict__ aptr[APASS];
@@ -216,9 +224,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     // this lane (computed once per tap) and the SCALAR offset is the channel offset (SALU only); padding taps and
     // lanes outside the image carry an out-of-range voffset and read 0 -- no per-element VALU at all.
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    const unsigned img_byte = (unsigned)(pn * (int)p.in_sn) * 4u;
+    const unsigned img_byte = (unsigned)(pn * (int)p.in_sn) * (unsigned)XES;
     // one 16-deep table step into register set u; kt >= kt_end (odd tail of a U = 2 pair) loads zeros
-    auto load_step = [&](int kt, float4 (&fa)[APASS], float (&fb)[BPASS]) {
+    auto load_step = [&](int kt, float4 (&fa)[APASS], float (&fb)[BF ? 1 : BPASS], unsigned short (&fh)[BF ? BPASS : 1]) {
         const bool real = kt < kt_end;
 #pragma unroll
         for (int s = 0; s < APASS; ++s) {
@@ -230,21 +238,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int so = spatial_off(t_tap[q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
-            vo[q] = (real && so >= 0) ? img_byte + (unsigned)so * 4u : C2M_OOB;
+            vo[q] = (real && so >= 0) ? img_byte + (unsigned)so * (unsigned)XES : C2M_OOB;
         }
 #pragma unroll
         for (int s = 0; s < BPASS; ++s) {
             const int slot = (s * BROWS) / CK;                       // compile-time
             const int cc = (s * BROWS) % CK + brow0;                  // wave-uniform
             // channels beyond nvalid only meet zero weights (A is zero-padded); they read in-range data or 0
-            const int soff = (hdr.x + cc * p.in_sc) * 4;
-            fb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[slot], soff, 0));
+            const int soff = (hdr.x + cc * p.in_sc) * XES;
+            if constexpr (BF) fh[s] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, vo[slot], soff, 0);
+            else fb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo[slot], soff, 0));
         }
         fetch_table(kt + 1 < p.nk ? kt + 1 : p.nk - 1);
     };
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) load_step(kt + u, ra[u], rb[u]);
+        for (int u = 0; u < U; ++u) load_step(kt + u, ra[u], rb[BF ? 0 : u], rh[BF ? u : 0]);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 for (int hh = 0; hh < BPASS / 8; ++hh) {
                     bf16x8 q;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) q[e] = (__bf16)rb[u][hh * 8 + e];
+                    for (int e = 0; e < 8; ++e) q[e] = __builtin_bit_cast(__bf16, rh[u][hh * 8 + e]);
                     const int h = BROWS == 1 ? hh : brow0;
                     b8[h * BN + bp] = __builtin_bit_cast(uint4, q);
                 }
@@ -419,7 +428,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     // ---- epilogue: acc[i][j][r] -> row m = ..(r&3)+8*(r>>2)+4*(lane>>5), col pix = ..(lane&31)
     const bool direct = p.splits == 1;
-    float* __restrict__ Yb = p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
+    const bool yh = BF && p.yh && direct;                 // bf16 output elements (slabs are fp32)
+    const int yes = yh ? 2 : 4;
+    float* __restrict__ Yb = yh ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(p.Y) + p.out_off_c[cls])
+                                : p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
     const int po_t = p.po_c[cls][0], po_y = p.po_c[cls][1], po_x = p.po_c[cls][2];
     {
         const int row0 = __builtin_amdgcn_readfirstlane(m0 + wm * TM);
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 decompose_pix(pix < p.Npix ? pix : 0, p, n, ot, oy, ox);
                 const long e = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw +
                                4L * (lane >> 5) * p.out_sc;
-                voff[j] = pix < p.Npix ? (unsigned)(e * 4) : 0x80000000u;
+                voff[j] = pix < p.Npix ? (unsigned)(e * yes) : 0x80000000u;
                 voff2[j] = 0x80000000u;
                 if (p.Y2) {
                     const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y,
@@ -445,15 +457,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         (unsigned)xp < (unsigned)p.ext_x) {
                         const long e2 = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp +
                                         4L * (lane >> 5) * p.y2_sc;
-                        voff2[j] = (unsigned)(e2 * 4);
+                        voff2[j] = (unsigned)(e2 * yes);
                         voff[j] = 0x80000000u;
                     }
                 }
                 ring = ring || voff[j] != 0x80000000u;
             }
-            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane);
+            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
             if (!p.Y2 || __any(ring))
-                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane);
+                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
             return;
         }
     }
@@ -463,14 +475,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if (pix >= p.Npix) continue;
         int n, ot, oy, ox;
         decompose_pix(pix, p, n, ot, oy, ox);
-        float* __restrict__ yb = Yb + (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh +
-                                 (long)ox * p.out_sw;
+        float* ybase = Yb;                                     // element type: float, or bf16_t when yh
+        long yidx = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw;
         long row_stride = p.out_sc;
         if (p.Y2) {
             const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y,
                       xp = ox * p.ps_x + po_x - p.lo_x;
             if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
-                yb = p.Y2 + (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                ybase = p.Y2;
+                yidx = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
                 row_stride = p.y2_sc;
             }
         }
@@ -485,7 +498,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         if (p.bias) v += p.bias[row];
                         v = c2m_act(v, p.act, p.slope);
                     }
-                    yb[(long)row * row_stride] = v;
+                    if (yh) reinterpret_cast<bf16_t*>(ybase)[yidx + (long)row * row_stride] = (bf16_t)v;
+                    else ybase[yidx + (long)row * row_stride] = v;
                 }
             }
         }
@@ -660,6 +674,8 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
 
     // ---- epilogue
     const bool direct = blk.nz == 1;
+    constexpr bool yh = false;                             // the fp32 kernels write fp32
+    constexpr int yes = 4;
     float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
     {
         const int row0 = __builtin_amdgcn_readfirstlane(m0 + wm * TM);
@@ -681,15 +697,15 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
                         (unsigned)xp < (unsigned)p.ext_x) {
                         const long e2 = (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp +
                                         4L * (lane >> 5) * p.y2_sc;
-                        voff2[j] = (unsigned)(e2 * 4);
+                        voff2[j] = (unsigned)(e2 * yes);
                         voff[j] = 0x80000000u;
                     }
                 }
                 ring = ring || voff[j] != 0x80000000u;
             }
-            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane);
+            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, row0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
             if (!p.Y2 || __any(ring))
-                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane);
+                c2m_store_tile_fast<MI, NI>(acc, Yb, voff, row0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
             return;
         }
     }
@@ -770,7 +786,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
 
     // ---- patch gather: three rounds of (pixel, 8-channel half); the half is wave-uniform in every round
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    const unsigned img_byte = (unsigned)(n_img * (int)p.in_sn + t_img * (int)p.in_st) * 4u;
+    const unsigned img_byte = (unsigned)(n_img * (int)p.in_sn + t_img * (int)p.in_st) * 2u;     // X is bf16 (2-byte elements)
     const int ppix[3] = {tid, tid, 256 + (tid & 127)};
     const int phalf[3] = {0, 1, wave >> 1};
     unsigned pvo[3];
@@ -785,10 +801,10 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
             ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
         }
         ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        pvo[r] = ok ? img_byte + (unsigned)(iy * (int)p.in_sh + ix) * 4u : C2M_OOB;
+        pvo[r] = ok ? img_byte + (unsigned)(iy * (int)p.in_sh + ix) * 2u : C2M_OOB;
     }
-    struct Stage { float pv[3][8]; };
-    auto fetch_patch = [&](int chunk, float (&pv)[3][8]) {
+    struct Stage { unsigned short pv[3][8]; };
+    auto fetch_patch = [&](int chunk, unsigned short (&pv)[3][8]) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -799,16 +815,16 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
                 const int ch = chunk * 16 + phalf[r] * 8 + j;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(p.X), 0, ch < p.cin ? p.x_bytes : 0, 0x00020000);
-                const int soff = ch * p.in_sc * 4;
-                pv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pvo[r], soff, 0));
+                const int soff = ch * p.in_sc * 2;
+                pv[r][j] = __builtin_amdgcn_raw_buffer_load_b16(rs, pvo[r], soff, 0);
             }
     };
-    auto stash_patch = [&](int buf, const float (&pv)[3][8]) {
+    auto stash_patch = [&](int buf, const unsigned short (&pv)[3][8]) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             bf16x8 q;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[j] = (__bf16)pv[r][j];
+            for (int j = 0; j < 8; ++j) q[j] = __builtin_bit_cast(__bf16, pv[r][j]);
             if (r < 2 || ppix[r] < NPIX) sP[buf][phalf[r] * NPIX + ppix[r]] = __builtin_bit_cast(uint4, q);
         }
     };
@@ -923,12 +939,48 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
 
     // ---- epilogue (same mapping as the fp32 patch kernel)
     const bool direct = blk.nz == 1;
+    const bool yh = p.yh && direct;                        // bf16 output elements (split-K slabs are fp32)
     float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
     // Vector path: a dword store per accumulator register (128 per wave) is store-ISSUE bound (~5 B/clk/CU: 27k cycles for
     // the 128 KB tile against 37k cycles of MFMAs at Cin = 256).  The tile goes through LDS instead (the weight buffers are
     // free now): [channel][64 pixels] per wave, 64 channels at a time, read back as float4 along the pixels and stored with
     // 16-byte stores (32 per wave instead of 128), still full 128-byte row segments per channel.
-    if (!p.Y2 && p.out_sw == 1 && (p.Wo & 3) == 0 && (p.out_off & 3) == 0 && (p.out_sc & 3) == 0 && (p.out_sn & 3) == 0 &&
+    if (yh && !p.Y2 && p.out_sw == 1 && (p.Wo & 7) == 0 && (p.out_off & 7) == 0 && (p.out_sc & 7) == 0 && (p.out_sn & 7) == 0 &&
+        (p.out_st & 7) == 0 && (p.out_sh & 7) == 0 && ((uintptr_t)p.Y & 15) == 0 && BM >= 64) {
+        // bf16 output: the same staging through LDS, read back as 8 pixels per lane -> one 16-byte store of 8 bf16
+        float* __restrict__ T = reinterpret_cast<float*>(&sA[0][0]) + wave * (64 * 64);
+        bf16_t* __restrict__ yimg = reinterpret_cast<bf16_t*>(p.Y) + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st;
+#pragma unroll
+        for (int h = 0; h < MI / 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cl = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float v = acc[2 * h + q][jj][r];
+                        const int row = m0 + h * 64 + cl;
+                        if (p.bias && row < p.M) v += p.bias[row];
+                        T[cl * 64 + jj * 32 + (lane & 31)] = c2m_act(v, p.act, p.slope);
+                    }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int cl = it * 8 + (lane >> 3), px = (lane & 7) * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(&T[cl * 64 + px]);
+                const float4 v1 = *reinterpret_cast<const float4*>(&T[cl * 64 + px + 4]);
+                const int row = m0 + h * 64 + cl;
+                const int oy = oy0 + wave * NI + (px >> 5), ox = ox0 + (px & 31);
+                if (row < p.M && oy < p.Ho && ox < p.Wo) {
+                    const bf16x8 o = {(bf16_t)v0.x, (bf16_t)v0.y, (bf16_t)v0.z, (bf16_t)v0.w,
+                                      (bf16_t)v1.x, (bf16_t)v1.y, (bf16_t)v1.z, (bf16_t)v1.w};
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(yimg + (long)row * p.out_sc + (long)oy * p.out_sh + ox));
+                }
+            }
+        }
+        return;
+    }
+    if (!yh && !p.Y2 && p.out_sw == 1 && (p.Wo & 3) == 0 && (p.out_off & 3) == 0 && (p.out_sc & 3) == 0 && (p.out_sn & 3) == 0 &&
         (p.slab_stride & 3) == 0 && ((uintptr_t)p.Y & 15) == 0 && BM >= 64) {
         float* __restrict__ T = reinterpret_cast<float*>(&sA[0][0]) + wave * (64 * 64);     // 16 KB per wave
         float* __restrict__ yimg = Yb + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st;
@@ -969,14 +1021,15 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
     for (int j = 0; j < NI; ++j) {
         const int oy = oy0 + wave * NI + j, ox = ox0 + (lane & 31);
         if (oy >= p.Ho || ox >= p.Wo) continue;
-        float* __restrict__ yb = Yb + p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh +
-                                 (long)ox * p.out_sw;
+        float* ybase = Yb;                                     // element type: float, or bf16_t when yh (then blk.z == 0)
+        long yidx = p.out_off + (long)n_img * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw;
         long row_stride = p.out_sc;
         if (p.Y2) {
             const int tp = t_img * p.ps_t + p.po_t - p.lo_t, yp = oy * p.ps_y + p.po_y - p.lo_y,
                       xp = ox * p.ps_x + p.po_x - p.lo_x;
             if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
-                yb = p.Y2 + (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                ybase = p.Y2;
+                yidx = (long)n_img * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
                 row_stride = p.y2_sc;
             }
         }
@@ -991,7 +1044,8 @@ __global__ __launch_bounds__(256) void conv_patch3x3_bf16_kernel(const ConvP p) 
                         if (p.bias) v += p.bias[row];
                         v = c2m_act(v, p.act, p.slope);
                     }
-                    yb[(long)row * row_stride] = v;
+                    if (yh) reinterpret_cast<bf16_t*>(ybase)[yidx + (long)row * row_stride] = (bf16_t)v;
+                    else ybase[yidx + (long)row * row_stride] = v;
                 }
             }
     }
@@ -1006,21 +1060,22 @@ static int launch_patch_bf16(const ConvP& p, int splits, hipStream_t s) {
 }
 
 // out[i] = act( sum_z slab[z][i] + bias[(i / chan_stride) % M] ), fixed order
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+template <class T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, T* __restrict__ out,
                                      const float* __restrict__ bias, long total, int S, long chan_stride, int M, int act,
                                      float slope) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float acc = 0.f;
         for (int z = 0; z < S; ++z) acc += slab[(long)z * total + i];
         if (bias) acc += bias[(int)((i / chan_stride) % M)];
-        out[i] = c2m_act(acc, act, slope);
+        c2m_st(out, i, c2m_act(acc, act, slope));
     }
 }
 
 // 16-byte form: 4 consecutive outputs share a channel when chan_stride % 4 == 0.  I = 32-bit indices whenever the slab
 // fits (the bias channel needs a division per element; in 64 bits it costs more than the S loads)
-template <typename I>
-__global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, float4* __restrict__ out,
+template <typename I, class T = float>
+__global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, T* __restrict__ out,
                                          const float* __restrict__ bias, long total4_, int S, long chan_stride4_, int M,
                                          int act, float slope) {
     const I total4 = (I)total4_, chan_stride4 = (I)chan_stride4_;
@@ -1034,8 +1089,8 @@ __global__ void splitk_reduce_vec_kernel(const float4* __restrict__ slab, float4
             const float b = bias[(int)((i / chan_stride4) % (I)M)];
             acc.x += b; acc.y += b; acc.z += b; acc.w += b;
         }
-        out[i] = make_float4(c2m_act(acc.x, act, slope), c2m_act(acc.y, act, slope), c2m_act(acc.z, act, slope),
-                             c2m_act(acc.w, act, slope));
+        c2m_st4(out + 4 * (long)i, make_float4(c2m_act(acc.x, act, slope), c2m_act(acc.y, act, slope), c2m_act(acc.z, act, slope),
+                                               c2m_act(acc.w, act, slope)));
     }
 }
 
@@ -1099,12 +1154,12 @@ C2M_API int c2m_conv_igemm_splits(int M, int nk, int Npix) {
 }
 
 // geom[] layout (int64): see include/c2m_hip.h
-C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_interior, const float* bias,
+C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_interior, const float* bias,
                            const int* ktab, const int64_t* g, int act, float slope, void* stream) {
     C2M_ENTER();
     ConvP p;
-    p.A = A; p.X = X; p.Y = Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
-    p.Y2 = Y_interior;
+    p.A = A; p.X = (const float*)X; p.Y = (float*)Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
+    p.Y2 = (float*)Y_interior;
     p.ps_t = (int)g[36]; p.ps_y = (int)g[37]; p.ps_x = (int)g[38]; p.po_t = (int)g[39]; p.po_y = (int)g[40];
     p.po_x = (int)g[41]; p.lo_t = (int)g[42]; p.lo_y = (int)g[43]; p.lo_x = (int)g[44]; p.ext_t = (int)g[45];
     p.ext_y = (int)g[46]; p.ext_x = (int)g[47]; p.y2_sn = g[48]; p.y2_sc = g[49]; p.y2_st = g[50]; p.y2_sh = g[51];
@@ -1122,6 +1177,8 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
     if (g[32] <= 0 || g[32] >= 0x80000000LL) return (int)hipErrorInvalidValue;   // X must be < 2 GiB
     p.x_bytes = (unsigned)g[32];
     p.act = act; p.slope = slope;
+    p.xh = (int)g[90]; p.yh = (int)g[91];       // element types of X and of Y / Y_interior: 0 fp32, 1 bf16 (dtype.h)
+    if ((p.xh | p.yh) & ~1) return (int)hipErrorInvalidValue;
     if (p.M <= 0 || p.Npix <= 0) return 0;
     if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
     if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;   // the two-target epilogue is a direct-store feature
@@ -1148,17 +1205,19 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         p.ksteps_per_split = c2m_cdiv(p.nchunks, splits);           // chunks per split
         if (c2m_cdiv(p.nchunks, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;
         if (g[34] == 1) {
-            // bf16: A = c2m_pack_weights_bf16_patch output, lda = its padded row count (a multiple of 128)
-            if (p.lda % 128 != 0 || p.lda < p.M) return (int)hipErrorInvalidValue;
+            // bf16: A = c2m_pack_weights_bf16_patch output, lda = its padded row count (a multiple of 128); X is bf16
+            if (p.lda % 128 != 0 || p.lda < p.M || !p.xh) return (int)hipErrorInvalidValue;
             if (p.M <= 32)      return launch_patch_bf16<32>(p, splits, s);
             else if (p.M <= 64) return launch_patch_bf16<64>(p, splits, s);
             else                return launch_patch_bf16<128>(p, splits, s);
         }
+        if (p.xh || p.yh) return (int)hipErrorInvalidValue;        // the fp32 kernels read and write fp32
         if (p.M <= 32)      return launch_patch<32, 256, 1, 4>(p, splits, s);
         else if (p.M <= 64) return launch_patch<64, 128, 2, 2>(p, splits, s);
         else                return launch_patch<128, 128, 2, 2>(p, splits, s);
     }
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2 && p.ncls == 1) {      // thin output: vector-ALU kernel
+        if (p.xh || p.yh) return (int)hipErrorInvalidValue;        // fp32 in, fp32 out (the host casts bf16 activations)
         // g[35] = +-KW: 2-D stride-1 square KW x KW tap set in row-major order (dx ascending / descending)
         const int kw = (int)(g[35] < 0 ? -g[35] : g[35]);
         if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
@@ -1171,28 +1230,33 @@ C2M_API int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_in
         return launch_thin_fwd<4>(p, s);
     }
     const bool bf16 = g[34] == 1;                          // operand precision: 0 fp32 (exact), 1 bf16 (fp32 accumulate)
+    if (bf16 ? !p.xh : (p.xh || p.yh)) return (int)hipErrorInvalidValue;   // bf16 kernels gather bf16 X; fp32 kernels are fp32 only
     if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s, bf16);
     else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s, bf16);
     else                return launch_igemm<128, 128, 2, 2>(p, ns, splits, s, bf16);
 }
 
-C2M_API int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits,
-                              long chan_stride, int M, int act, float slope, void* stream) {
+C2M_API int c2m_splitk_reduce(const float* slab, void* out, const float* bias, long total, int splits,
+                              long chan_stride, int M, int act, float slope, int dt, void* stream) {
     C2M_ENTER();
     if (total <= 0) return 0;
-    if ((total & 3) == 0 && (!bias || (chan_stride & 3) == 0) && ((((uintptr_t)slab) | ((uintptr_t)out)) & 15) == 0) {
-        if (total / 4 < (1L << 31))
-            hipLaunchKernelGGL(splitk_reduce_vec_kernel<unsigned>, dim3(c2m_grid(total / 4, 256)), dim3(256), 0,
-                               (hipStream_t)stream, reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias,
-                               total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
-        else
-            hipLaunchKernelGGL(splitk_reduce_vec_kernel<long>, dim3(c2m_grid(total / 4, 256)), dim3(256), 0,
-                               (hipStream_t)stream, reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(out), bias,
-                               total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
-        return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, out,
-                       bias, total, splits, chan_stride, M, act, slope);
+    const uintptr_t omask = dt == C2M_BF16 ? 7 : 15;
+    const bool vec = (total & 3) == 0 && (!bias || (chan_stride & 3) == 0) && (((uintptr_t)slab) & 15) == 0 &&
+                     (((uintptr_t)out) & omask) == 0;
+    const dim3 grid(c2m_grid(vec ? total / 4 : total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    C2M_DISPATCH_DT(dt,
+        if (vec) {
+            if (total / 4 < (1L << 31))
+                hipLaunchKernelGGL((splitk_reduce_vec_kernel<unsigned, T>), grid, dim3(256), 0, s, reinterpret_cast<const float4*>(slab),
+                                   (T*)out, bias, total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
+            else
+                hipLaunchKernelGGL((splitk_reduce_vec_kernel<long, T>), grid, dim3(256), 0, s, reinterpret_cast<const float4*>(slab),
+                                   (T*)out, bias, total / 4, splits, bias ? chan_stride / 4 : 1, M, act, slope);
+        } else {
+            hipLaunchKernelGGL(splitk_reduce_kernel<T>, grid, dim3(256), 0, s, slab, (T*)out, bias, total, splits, chan_stride, M,
+                               act, slope);
+        });
     return (int)hipGetLastError();
 }
 
@@ -1249,6 +1313,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[AROWS], rb[BROWSW];
+    // BF: dY and X are bf16 tensors in HBM (the bf16 data path; the host casts fp32 operands once): 2-byte gathers, widened
+    // to fp32 registers by a shift (exact), rounded back (exactly) when they are staged into the bf16 LDS image
+    constexpr int XES = BF ? 2 : 4;
+    auto ldv = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, int soff_elems) -> float {
+        if constexpr (BF) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, soff_elems * 2, 0) << 16);
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff_elems * 4, 0));
+    };
     // raw buffer descriptors: per-lane byte offset = this lane's pixel (out of range for dead lanes -> reads 0),
     // scalar offset = row / channel offset (SALU): no per-element VALU
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
@@ -1259,13 +1330,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
         int n, ot, oy, ox;
         decompose_pix(live ? pix : pend - 1, p, n, ot, oy, ox);
         const int sp = (ot * p.Ho + oy) * p.Wo + ox;
-        const unsigned yvo = live ? (unsigned)(n * (int)p.dy_sn + sp) * 4u : C2M_OOB;
-        const unsigned ximg = (unsigned)(n * (int)p.in_sn) * 4u;
+        const unsigned yvo = live ? (unsigned)(n * (int)p.dy_sn + sp) * (unsigned)XES : C2M_OOB;
+        const unsigned ximg = (unsigned)(n * (int)p.in_sn) * (unsigned)XES;
         const int ots = ot * p.st, oys = oy * p.sh, oxs = ox * p.sw;
 #pragma unroll
         for (int s = 0; s < AROWS; ++s) {
             const int row = m0 + wave * AROWS + s;            // rows >= M give columns that are never stored
-            ra[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, yvo, row * (int)p.dy_sc * 4, 0));
+            ra[s] = ldv(yrsrc, yvo, row * (int)p.dy_sc);
         }
 #pragma unroll
         for (int gq = 0; gq < BGROUPS; ++gq) {
@@ -1276,7 +1347,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int so = spatial_off(jd[1 + q], ots, oys, oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
-                vo[q] = (live && so >= 0) ? ximg + (unsigned)so * 4u : C2M_OOB;
+                vo[q] = (live && so >= 0) ? ximg + (unsigned)so * (unsigned)XES : C2M_OOB;
             }
             if (hdr.y == -2) {                                   // ones row (bias gradient); wave-uniform branch
 #pragma unroll
@@ -1286,8 +1357,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
                 for (int s = 0; s < 16; ++s) {
                     const int slot = s / CK, cc = s % CK;         // compile-time
                     // channels >= nvalid produce columns the reduction never reads
-                    rb[gq * 16 + s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        xrsrc, vo[slot], (hdr.x + cc * p.in_sc) * 4, 0));
+                    rb[gq * 16 + s] = ldv(xrsrc, vo[slot], hdr.x + cc * p.in_sc);
                 }
             }
         }
@@ -1302,8 +1372,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
         int n, ot, oy, ox;
         decompose_pix(c.live ? pix : pend - 1, p, n, ot, oy, ox);
         const int sp = (ot * p.Ho + oy) * p.Wo + ox;
-        c.yvo = c.live ? (unsigned)(n * (int)p.dy_sn + sp) * 4u : C2M_OOB;
-        c.ximg = (unsigned)(n * (int)p.in_sn) * 4u;
+        c.yvo = c.live ? (unsigned)(n * (int)p.dy_sn + sp) * (unsigned)XES : C2M_OOB;
+        c.ximg = (unsigned)(n * (int)p.in_sn) * (unsigned)XES;
         c.ots = ot * p.st; c.oys = oy * p.sh; c.oxs = ox * p.sw;
         return c;
     };
@@ -1311,7 +1381,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int s = s0; s < s1; ++s) {
             const int row = m0 + wave * AROWS + s;
-            ra[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrsrc, c.yvo, row * (int)p.dy_sc * 4, 0));
+            ra[s] = ldv(yrsrc, c.yvo, row * (int)p.dy_sc);
         }
     };
     auto load_b_group = [&](const PixCtx& c, int gq) {
@@ -1323,13 +1393,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int so = spatial_off(jd[1 + q], c.ots, c.oys, c.oxs, p.Ti, p.Hi, p.Wi, in_st, in_sh, p.reflect, p.is3d);
-            vo[q] = (c.live && so >= 0 && !ones) ? c.ximg + (unsigned)so * 4u : C2M_OOB;
+            vo[q] = (c.live && so >= 0 && !ones) ? c.ximg + (unsigned)so * (unsigned)XES : C2M_OOB;
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int slot = s / CK, cc = s % CK;
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                xrsrc, vo[slot], (hdr.x + cc * p.in_sc) * 4, 0));       // ones group: every offset is out of range -> 0
+            const float v = ldv(xrsrc, vo[slot], hdr.x + cc * p.in_sc);       // ones group: every offset is out of range -> 0
             rb[gq * 16 + s] = (s == 0 && ones) ? 1.f : v;
         }
     };
@@ -2060,11 +2129,11 @@ C2M_API int c2m_conv_wgrad_rows(int M, int ngroups) {
     return c2m_cdiv(ngroups * 16, BN) * BN;
 }
 
-C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
+C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW, float* db, const int* jtab,
                            const int64_t* g, void* stream) {
     C2M_ENTER();
     WgradP p;
-    p.dY = dY; p.X = X; p.slab = slab; p.jtab = reinterpret_cast<const int4*>(jtab);
+    p.dY = (const float*)dY; p.X = (const float*)X; p.slab = slab; p.jtab = reinterpret_cast<const int4*>(jtab);
     p.M = (int)g[0]; p.J = (int)g[1];
     p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
     p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
@@ -2087,7 +2156,9 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
     const int Seff = c2m_cdiv(p.Npix, per);   // <= S; unused slabs are never read
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.J / BN, c2m_cdiv(p.M, BM), Seff);
+    const bool xh = g[90] == 1;                           // dY and X are bf16 tensors (bf16 kernels only)
     if (p.M <= 4 && p.Npix >= 16384) {                    // thin output: vector-ALU kernels, same slab layout
+        if (xh) return (int)hipErrorInvalidValue;         // fp32 operands (the host casts bf16 activations)
         // g[35] = KW: 2-D stride-1 square KW x KW tap set in row-major order -> row-blocked kernel
         const int kw = (int)g[35];
         if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
@@ -2137,6 +2208,7 @@ C2M_API int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* 
         return launch_wgrad_reduce(total2, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Sthin);
     }
     const bool bf16 = g[34] == 1;
+    if (bf16 != xh) return (int)hipErrorInvalidValue;  // the bf16 kernel gathers bf16 tensors, the fp32 kernel fp32 ones
     const dim3 grid1(grid.x * grid.y * grid.z);       // 1-D launch, decoded XCD-aware in the kernel (common.h)
 #define C2M_WG(BMv, BNv, WGMv, WGNv)                                                                                  \
     do {                                                                                                              \
@@ -2174,7 +2246,8 @@ __device__ __forceinline__ int fold_sources(int i, int I, int p, int* src) {
     return n;
 }
 
-__global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
+template <class T>
+__global__ void reflect_fold_kernel(const T* __restrict__ dXp, T* __restrict__ dX, const FoldP f) {
     const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < f.total; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % f.W); long r = idx / f.W;
@@ -2183,12 +2256,12 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dXp, float* __rest
         int st[3], sy[3], sx[3];
         const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy),
                   nx = fold_sources(x, f.W, f.pw, sx);
-        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        const T* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
         float acc = 0.f;
         for (int a = 0; a < nt; ++a)
             for (int b = 0; b < ny; ++b)
-                for (int c = 0; c < nx; ++c) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
-        dX[idx] = acc;
+                for (int c = 0; c < nx; ++c) acc += c2m_ld(base, ((long)st[a] * Hp + sy[b]) * Wp + sx[c]);
+        c2m_st(dX, idx, acc);
     }
 }
 
@@ -2230,7 +2303,8 @@ __global__ void reflect_fold_vec_kernel(const float* __restrict__ dXp, float* __
 
 // In-place variant for the two-target dgrad: dX already holds the direct term, add the mirrored pad-ring terms
 // (only pixels within `pad` of a border have any).  Generic form: every element looks for extra sources.
-__global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
+template <class T>
+__global__ void reflect_border_add_kernel(const T* __restrict__ dXp, T* __restrict__ dX, const FoldP f) {
     const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < f.total; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % f.W); long r = idx / f.W;
@@ -2240,13 +2314,13 @@ __global__ void reflect_border_add_kernel(const float* __restrict__ dXp, float* 
         const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy),
                   nx = fold_sources(x, f.W, f.pw, sx);
         if (nt * ny * nx == 1) continue;
-        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        const T* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
         float acc = 0.f;
         for (int a = 0; a < nt; ++a)
             for (int b = 0; b < ny; ++b)
                 for (int c = 0; c < nx; ++c)
-                    if (a + b + c > 0) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
-        dX[idx] += acc;
+                    if (a + b + c > 0) acc += c2m_ld(base, ((long)st[a] * Hp + sy[b]) * Wp + sx[c]);
+        c2m_st(dX, idx, c2m_ld(dX, idx) + acc);
     }
 }
 
@@ -2261,7 +2335,8 @@ __device__ __forceinline__ int offband_index(int k, int L, int p) {
     return k == 0 ? 0 : (k == L - 2 * p - 1 ? L - 1 : k + p);
 }
 
-__global__ void reflect_border_only_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f,
+template <class T>
+__global__ void reflect_border_only_kernel(const T* __restrict__ dXp, T* __restrict__ dX, const FoldP f,
                                            const int r1, const int r2, const int r3, const long NC) {
     const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
     const int per = r1 + r2 + r3;
@@ -2288,45 +2363,50 @@ __global__ void reflect_border_only_kernel(const float* __restrict__ dXp, float*
         int st[3], sy[3], sx[3];
         const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy),
                   nx = fold_sources(x, f.W, f.pw, sx);
-        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        const T* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
         float acc = 0.f;
         for (int a = 0; a < nt; ++a)
             for (int b = 0; b < ny; ++b)
                 for (int c = 0; c < nx; ++c)
-                    if (a + b + c > 0) acc += base[((long)st[a] * Hp + sy[b]) * Wp + sx[c]];
-        dX[(nc * f.T + t) * (long)f.H * f.W + (long)y * f.W + x] += acc;
+                    if (a + b + c > 0) acc += c2m_ld(base, ((long)st[a] * Hp + sy[b]) * Wp + sx[c]);
+        const long di = (nc * f.T + t) * (long)f.H * f.W + (long)y * f.W + x;
+        c2m_st(dX, di, c2m_ld(dX, di) + acc);
     }
 }
 
-C2M_API int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
-                                   void* stream) {
+C2M_API int c2m_reflect_border_add(const void* dXpad, void* dX, long NC, int T_, int H, int W, int pt, int ph, int pw,
+                                   int dt, void* stream) {
     C2M_ENTER();
-    FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
+    FoldP f{T_, H, W, pt, ph, pw, NC * (long)T_ * H * W};
     if (f.total <= 0) return 0;
-    const bool roomy = (pt == 0 || T >= 2 * pt + 2) && (ph == 0 || H >= 2 * ph + 2) && (pw == 0 || W >= 2 * pw + 2);
-    const long per_l = (long)T * H * 2 * pw + (long)T * 2 * ph * (W - 2 * pw) + 2L * pt * (H - 2 * ph) * (W - 2 * pw);
-    if (roomy && per_l > 0 && per_l < (1L << 30)) {
-        const int r1 = T * H * 2 * pw, r2 = T * 2 * ph * (W - 2 * pw), r3 = 2 * pt * (H - 2 * ph) * (W - 2 * pw);
-        hipLaunchKernelGGL(reflect_border_only_kernel, dim3(c2m_grid(NC * per_l, 256)), dim3(256), 0,
-                           (hipStream_t)stream, dXpad, dX, f, r1, r2, r3, NC);
-        return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(reflect_border_add_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dXpad, dX, f);
+    const bool roomy = (pt == 0 || T_ >= 2 * pt + 2) && (ph == 0 || H >= 2 * ph + 2) && (pw == 0 || W >= 2 * pw + 2);
+    const long per_l = (long)T_ * H * 2 * pw + (long)T_ * 2 * ph * (W - 2 * pw) + 2L * pt * (H - 2 * ph) * (W - 2 * pw);
+    C2M_DISPATCH_DT(dt,
+        if (roomy && per_l > 0 && per_l < (1L << 30)) {
+            const int r1 = T_ * H * 2 * pw; const int r2 = T_ * 2 * ph * (W - 2 * pw); const int r3 = 2 * pt * (H - 2 * ph) * (W - 2 * pw);
+            hipLaunchKernelGGL(reflect_border_only_kernel<T>, dim3(c2m_grid(NC * per_l, 256)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)dXpad, (T*)dX, f, r1, r2, r3, NC);
+        } else {
+            hipLaunchKernelGGL(reflect_border_add_kernel<T>, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const T*)dXpad, (T*)dX, f);
+        });
     return (int)hipGetLastError();
 }
 
-C2M_API int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
-                             void* stream) {
+C2M_API int c2m_reflect_fold(const void* dXpad, void* dX, long NC, int T_, int H, int W, int pt, int ph, int pw,
+                             int dt, void* stream) {
     C2M_ENTER();
-    FoldP f{T, H, W, pt, ph, pw, NC * (long)T * H * W};
+    FoldP f{T_, H, W, pt, ph, pw, NC * (long)T_ * H * W};
     if (f.total <= 0) return 0;
-    if ((W & 3) == 0 && ((uintptr_t)dX & 15) == 0)
+    if (dt == C2M_BF16)
+        hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dXpad, (bf16_t*)dX, f);
+    else if ((W & 3) == 0 && ((uintptr_t)dX & 15) == 0)
         hipLaunchKernelGGL(reflect_fold_vec_kernel, dim3(c2m_grid(f.total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                           dXpad, dX, f);
+                           (const float*)dXpad, (float*)dX, f);
     else
-        hipLaunchKernelGGL(reflect_fold_kernel, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream, dXpad, dX,
-                           f);
+        hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dXpad, (float*)dX, f);
     return (int)hipGetLastError();
 }
 

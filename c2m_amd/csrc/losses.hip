@@ -5,6 +5,7 @@
 // Reductions are two-stage and deterministic: per-block partial sums (fp32 in-thread, fp64 across the block) and a
 // fixed-order final sum in fp64 by a single wave; no float atomics.
 #include "common.h"
+#include "dtype.h"
 
 #define RED_BLOCKS 1024
 
@@ -18,13 +19,14 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const double* __restrict
 }
 
 // a, b: [outer][C][inner]; mask (optional): [outer][inner] broadcast over C
-__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <class T>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                           const float* __restrict__ mask, long total, int C, long inner,
                                                           double* __restrict__ part) {
     __shared__ double sm[4];
     float s = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float va = a[i], vb = b[i];
+        float va = c2m_ld(a, i), vb = c2m_ld(b, i);
         if (mask) {
             const long o = i / (inner * C), r = i % inner;
             const float m = mask[o * inner + r];
@@ -37,25 +39,27 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
 }
 
 // workspace: RED_BLOCKS doubles
-C2M_API int c2m_l1_mean_fwd(const float* a, const float* b, const float* mask, float* out, long total, int C, long inner,
-                            void* workspace, void* stream) {
+C2M_API int c2m_l1_mean_fwd(const void* a, const void* b, const float* mask, float* out, long total, int C, long inner,
+                            void* workspace, int dt, void* stream) {
     C2M_ENTER();
     if (total <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     int blocks = c2m_grid(total, 256); if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, s, a, b, mask, total, C, inner, (double*)workspace);
+    C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(l1_partial_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)a, (const T*)b, mask,
+                                           total, C, inner, (double*)workspace););
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, blocks, 1.0 / (double)total,
                        out);
     return (int)hipGetLastError();
 }
 
 // ga = gscale * sign(a*m - b*m) * m / total ; gb = -ga  (either may be null); gscale is a device scalar
-__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask,
-                              const float* __restrict__ gscale, float* __restrict__ ga, float* __restrict__ gb,
+template <class T>
+__global__ void l1_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ mask,
+                              const float* __restrict__ gscale, T* __restrict__ ga, T* __restrict__ gb,
                               long total, int C, long inner) {
     const float g = gscale[0] / (float)total;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float va = a[i], vb = b[i], m = 1.f;
+        float va = c2m_ld(a, i), vb = c2m_ld(b, i), m = 1.f;
         if (mask) {
             const long o = i / (inner * C), r = i % inner;
             m = mask[o * inner + r];
@@ -64,17 +68,17 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
         const float d = va - vb;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         const float v = g * sgn * m;
-        if (ga) ga[i] = v;
-        if (gb) gb[i] = -v;
+        if (ga) c2m_st(ga, i, v);
+        if (gb) c2m_st(gb, i, -v);
     }
 }
 
-C2M_API int c2m_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gscale, float* ga, float* gb,
-                            long total, int C, long inner, void* stream) {
+C2M_API int c2m_l1_mean_bwd(const void* a, const void* b, const float* mask, const float* gscale, void* ga, void* gb,
+                            long total, int C, long inner, int dt, void* stream) {
     C2M_ENTER();
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, mask, gscale,
-                       ga, gb, total, C, inner);
+    C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)a, (const T*)b, mask, gscale, (T*)ga, (T*)gb, total, C, inner););
     return (int)hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 // mean, then centred sum of squares) -> Chan combination in a fixed order -> mean / invstd (+ running stats).
 // Backward: one reduction pass (sum g', sum g'*xhat, and the SPADE gamma/beta map gradients) + one apply pass.
 #include "common.h"
+#include "dtype.h"
 
 #define NORM_CHUNK 8192
 
@@ -22,36 +23,37 @@ struct NormShape { int N, C; long S; int mode; int chunks; };
 static inline int norm_chunks(long S) { return (int)((S + NORM_CHUNK - 1) / NORM_CHUNK); }
 
 // partial[(plane*chunks + chunk)*2 + {0: mean, 1: M2}]
-__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+template <class T>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                             long S, int chunks) {
     __shared__ float sm[4];
     const long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const long beg = (long)chunk * NORM_CHUNK;
     const long end = beg + NORM_CHUNK < S ? beg + NORM_CHUNK : S;
-    const float* __restrict__ p = x + plane * S;
+    const T* __restrict__ p = x + plane * S;
     const int cnt = (int)(end - beg);
-    const bool vec = (S & 3) == 0 && ((uintptr_t)x & 15) == 0;      // chunk bounds are multiples of 4 then
+    const bool vec = (S & 3) == 0 && ((uintptr_t)x & C2mVec4<T>::mask) == 0;      // chunk bounds are multiples of 4 then
     float s = 0.f;
     if (vec) {
         for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float4 v = c2m_ld4(p + i);
             s += (v.x + v.y) + (v.z + v.w);
         }
     } else {
-        for (long i = beg + threadIdx.x; i < end; i += 256) s += p[i];
+        for (long i = beg + threadIdx.x; i < end; i += 256) s += c2m_ld(p, i);
     }
     s = block_sum_256(s, sm);
     const float mean = s / (float)cnt;
     float m2 = 0.f;
     if (vec) {
         for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float4 v = c2m_ld4(p + i);
             const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
             m2 += (a * a + b * b) + (c * c + d * d);
         }
     } else {
-        for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = p[i] - mean; m2 += d * d; }
+        for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = c2m_ld(p, i) - mean; m2 += d * d; }
     }
     m2 = block_sum_256(m2, sm);
     if (threadIdx.x == 0) {
@@ -142,14 +144,14 @@ __global__ __launch_bounds__(256) void norm_finalize_bn_kernel(const float* __re
 
 C2M_API long c2m_norm_workspace_floats(int N, int C, long S) { return (long)N * C * norm_chunks(S) * 4; }
 
-C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                           float* workspace, int N, int C, long S, int mode, float eps, float momentum, void* stream) {
+C2M_API int c2m_norm_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                           float* workspace, int N, int C, long S, int mode, float eps, float momentum, int dt, void* stream) {
     C2M_ENTER();
     if ((long)N * C * S <= 0) return 0;
     NormShape sh{N, C, S, mode, norm_chunks(S)};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(norm_partial_kernel, dim3((unsigned)((long)N * C * sh.chunks)), dim3(256), 0, s, x, workspace, S,
-                       sh.chunks);
+    C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(norm_partial_kernel<T>, dim3((unsigned)((long)N * C * sh.chunks)), dim3(256), 0, s,
+                                           (const T*)x, workspace, S, sh.chunks););
     const int nstat = mode == 0 ? N * C : C;
     if (mode == 1 && N * sh.chunks >= 16)
         hipLaunchKernelGGL(norm_finalize_bn_kernel, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, workspace, mean, invstd,
@@ -163,13 +165,15 @@ C2M_API int c2m_norm_stats(const float* x, float* mean, float* invstd, float* ru
 // ------------------------------------------------------------------------------------------- apply (forward)
 // y = act( xhat * scale + shift ), xhat = (x - mean)*invstd
 //   affine: scale = gamma[c], shift = beta[c];  plain: 1, 0;  SPADE: scale = 1 + gb[n, c, s], shift = gb[n, C + c, s]
+template <class T>
 struct ApplyP {
-    const float* x; const float* mean; const float* invstd; const float* gamma; const float* beta; const float* gb;
-    float* y;
+    const T* x; const float* mean; const float* invstd; const float* gamma; const float* beta; const T* gb;
+    T* y;
     int N, C; long S; int mode; int act; float slope;
 };
 
-__global__ void norm_apply_kernel(const ApplyP p) {
+template <class T>
+__global__ void norm_apply_kernel(const ApplyP<T> p) {
     const long total = (long)p.N * p.C * p.S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long plane = i / p.S;
@@ -177,25 +181,24 @@ __global__ void norm_apply_kernel(const ApplyP p) {
         const int c = (int)(plane % p.C);
         const int n = (int)(plane / p.C);
         const int st = p.mode == 0 ? (int)plane : c;
-        const float xhat = (p.x[i] - p.mean[st]) * p.invstd[st];
+        const float xhat = (c2m_ld(p.x, i) - p.mean[st]) * p.invstd[st];
         float v;
         if (p.gb) {
             const long gbase = ((long)n * 2 * p.C + c) * p.S + s;
-            v = xhat * (1.0f + p.gb[gbase]) + p.gb[gbase + (long)p.C * p.S];
+            v = xhat * (1.0f + c2m_ld(p.gb, gbase)) + c2m_ld(p.gb, gbase + (long)p.C * p.S);
         } else if (p.gamma) {
             v = xhat * p.gamma[c] + p.beta[c];
         } else {
             v = xhat;
         }
-        p.y[i] = c2m_act(v, p.act, p.slope);
+        c2m_st(p.y, i, c2m_act(v, p.act, p.slope));
     }
 }
 
 // Large planes (S >= 1024, S % 4 == 0): one workgroup per (plane, 8192-element chunk), 16-byte accesses, the plane's
 // statistics and affine parameters in registers -- no per-element index arithmetic.
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-__global__ __launch_bounds__(256) void norm_apply_vec_kernel(const ApplyP p, int chunks) {
+template <class T>
+__global__ __launch_bounds__(256) void norm_apply_vec_kernel(const ApplyP<T> p, int chunks) {
     const long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const long beg = (long)chunk * NORM_CHUNK;
@@ -205,58 +208,61 @@ __global__ __launch_bounds__(256) void norm_apply_vec_kernel(const ApplyP p, int
     const int st = p.mode == 0 ? (int)plane : c;
     const float mean = p.mean[st], invstd = p.invstd[st];
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
-    const float* __restrict__ x = p.x + plane * p.S;
-    float* __restrict__ y = p.y + plane * p.S;
-    const float* __restrict__ g0 = p.gb ? p.gb + ((long)n * 2 * p.C + c) * p.S : nullptr;
-    const float* __restrict__ g1 = p.gb ? g0 + (long)p.C * p.S : nullptr;
+    const T* __restrict__ x = p.x + plane * p.S;
+    T* __restrict__ y = p.y + plane * p.S;
+    const T* __restrict__ g0 = p.gb ? p.gb + ((long)n * 2 * p.C + c) * p.S : nullptr;
+    const T* __restrict__ g1 = p.gb ? g0 + (long)p.C * p.S : nullptr;
     for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
-        const float4 v = ld4(x + i);
+        const float4 v = c2m_ld4(x + i);
         float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
         if (p.gb) {
-            const float4 a = ld4(g0 + i);
+            const float4 a = c2m_ld4(g0 + i);
             sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
-            sh = ld4(g1 + i);
+            sh = c2m_ld4(g1 + i);
         }
         float4 o;
         o.x = c2m_act((v.x - mean) * invstd * sc.x + sh.x, p.act, p.slope);
         o.y = c2m_act((v.y - mean) * invstd * sc.y + sh.y, p.act, p.slope);
         o.z = c2m_act((v.z - mean) * invstd * sc.z + sh.z, p.act, p.slope);
         o.w = c2m_act((v.w - mean) * invstd * sc.w + sh.w, p.act, p.slope);
-        *reinterpret_cast<float4*>(y + i) = o;
+        c2m_st4(y + i, o);
     }
 }
 
-static inline bool norm_vec_ok(long S, const void* a, const void* b, const void* c, const void* d) {
+static inline bool norm_vec_ok(long S, const void* a, const void* b, const void* c, const void* d, int dt) {
     return S >= 1024 && (S & 3) == 0 &&
-           ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+           ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & (dt == C2M_BF16 ? 7 : 15)) == 0;
 }
 
-C2M_API int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
-                           const float* beta, const float* gb, float* y, int N, int C, long S, int mode, int act,
-                           float slope, void* stream) {
+C2M_API int c2m_norm_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const void* gb, void* y, int N, int C, long S, int mode, int act,
+                           float slope, int dt, void* stream) {
     C2M_ENTER();
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
-    ApplyP p{x, mean, invstd, gamma, beta, gb, y, N, C, S, mode, act, slope};
-    if (norm_vec_ok(S, x, y, gb, nullptr)) {
-        const int chunks = norm_chunks(S);
-        hipLaunchKernelGGL(norm_apply_vec_kernel, dim3((unsigned)((long)N * C * chunks)), dim3(256), 0,
-                           (hipStream_t)stream, p, chunks);
-        return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    const bool vec = norm_vec_ok(S, x, y, gb, nullptr, dt);
+    C2M_DISPATCH_DT(dt,
+        ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, (const T*)gb, (T*)y, N, C, S, mode, act, slope};
+        if (vec) {
+            const int chunks = norm_chunks(S);
+            hipLaunchKernelGGL(norm_apply_vec_kernel<T>, dim3((unsigned)((long)N * C * chunks)), dim3(256), 0,
+                               (hipStream_t)stream, p, chunks);
+        } else {
+            hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+        });
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------- backward
+template <class T>
 struct BwdP {
-    const float* x; const float* gy; const float* mean; const float* invstd; const float* gamma; const float* beta;
-    const float* gb;
-    float* ggb;      // SPADE map gradients [N,2C,S] (written in the reduce pass)
+    const T* x; const T* gy; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    const T* gb;
+    T* ggb;          // SPADE map gradients [N,2C,S] (written in the reduce pass)
     float* partial;  // [(plane*chunks + chunk)*2]: sum g'*m, sum g'*m*xhat  (m = 1+gamma_map for SPADE else 1)
     float* coef;     // [nstat*2]: c1, c2 of dx = invstd*(g'*scale - c1 - xhat*c2)
     float* dgamma; float* dbeta;
-    float* dx;
+    T* dx;
     int N, C; long S; int mode; int act; float slope; int chunks;
 };
 
@@ -268,7 +274,8 @@ __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
+template <class T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP<T> p) {
     __shared__ float sm[4];
     const long plane = blockIdx.x / p.chunks;
     const int chunk = blockIdx.x % p.chunks;
@@ -280,19 +287,19 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
     const float mean = p.mean[st], invstd = p.invstd[st];
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    const bool vec = (p.S & 3) == 0 && (((uintptr_t)p.x | (uintptr_t)p.gy | (uintptr_t)p.gb | (uintptr_t)p.ggb) & 15) == 0;
+    const bool vec = (p.S & 3) == 0 && (((uintptr_t)p.x | (uintptr_t)p.gy | (uintptr_t)p.gb | (uintptr_t)p.ggb) & C2mVec4<T>::mask) == 0;
     if (vec) {                       // 16-byte accesses; element order inside a thread is fixed -> deterministic sums
-        const float* __restrict__ xp = p.x + plane * p.S;
-        const float* __restrict__ gp = p.gy + plane * p.S;
+        const T* __restrict__ xp = p.x + plane * p.S;
+        const T* __restrict__ gp = p.gy + plane * p.S;
         const long gplane = ((long)n * 2 * p.C + c) * p.S, goff = (long)p.C * p.S;
         for (long s = beg + threadIdx.x * 4; s < end; s += 1024) {
-            const float4 xv = *reinterpret_cast<const float4*>(xp + s);
-            const float4 gv = *reinterpret_cast<const float4*>(gp + s);
+            const float4 xv = c2m_ld4(xp + s);
+            const float4 gv = c2m_ld4(gp + s);
             float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
             if (p.gb) {
-                const float4 a = *reinterpret_cast<const float4*>(p.gb + gplane + s);
+                const float4 a = c2m_ld4(p.gb + gplane + s);
                 sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
-                sh = *reinterpret_cast<const float4*>(p.gb + gplane + goff + s);
+                sh = c2m_ld4(p.gb + gplane + goff + s);
             }
             const float xh[4] = {(xv.x - mean) * invstd, (xv.y - mean) * invstd, (xv.z - mean) * invstd, (xv.w - mean) * invstd};
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, gyv[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -304,25 +311,25 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
                 else { s1 += g[e]; s2 += g[e] * xh[e]; }
             }
             if (p.gb) {
-                *reinterpret_cast<float4*>(p.ggb + gplane + s) = make_float4(g[0] * xh[0], g[1] * xh[1], g[2] * xh[2], g[3] * xh[3]);
-                *reinterpret_cast<float4*>(p.ggb + gplane + goff + s) = make_float4(g[0], g[1], g[2], g[3]);
+                c2m_st4(p.ggb + gplane + s, make_float4(g[0] * xh[0], g[1] * xh[1], g[2] * xh[2], g[3] * xh[3]));
+                c2m_st4(p.ggb + gplane + goff + s, make_float4(g[0], g[1], g[2], g[3]));
             }
         }
     } else
     for (long s = beg + threadIdx.x; s < end; s += 256) {
         const long i = plane * p.S + s;
-        const float xhat = (p.x[i] - mean) * invstd;
+        const float xhat = (c2m_ld(p.x, i) - mean) * invstd;
         float scale = ga, shift = be;
         long gbase = 0;
         if (p.gb) {
             gbase = ((long)n * 2 * p.C + c) * p.S + s;
-            scale = 1.0f + p.gb[gbase];
-            shift = p.gb[gbase + (long)p.C * p.S];
+            scale = 1.0f + c2m_ld(p.gb, gbase);
+            shift = c2m_ld(p.gb, gbase + (long)p.C * p.S);
         }
-        const float g = p.gy[i] * act_grad(xhat * scale + shift, p.act, p.slope);
+        const float g = c2m_ld(p.gy, i) * act_grad(xhat * scale + shift, p.act, p.slope);
         if (p.gb) {
-            p.ggb[gbase] = g * xhat;
-            p.ggb[gbase + (long)p.C * p.S] = g;
+            c2m_st(p.ggb, gbase, g * xhat);
+            c2m_st(p.ggb, gbase + (long)p.C * p.S, g);
             s1 += g * scale; s2 += g * scale * xhat;
         } else {
             s1 += g; s2 += g * xhat;
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const BwdP p) {
     }
 }
 
-__global__ void norm_bwd_finalize_kernel(const BwdP p) {
+template <class T>
+__global__ void norm_bwd_finalize_kernel(const BwdP<T> p) {
     const int nstat = p.mode == 0 ? p.N * p.C : p.C;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (p.mode == 1) {
@@ -378,7 +386,8 @@ __global__ void norm_bwd_finalize_kernel(const BwdP p) {
 
 // One wave per channel (see norm_finalize_bn_kernel): batch mode sums all N * chunks partials of the channel; instance
 // mode gives each lane whole planes (their coefficients) and sums the lane totals for the affine gradients.
-__global__ __launch_bounds__(256) void norm_bwd_finalize_wave_kernel(const BwdP p) {
+template <class T>
+__global__ __launch_bounds__(256) void norm_bwd_finalize_wave_kernel(const BwdP<T> p) {
     const int lane = threadIdx.x & 63;
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= p.C) return;
@@ -414,7 +423,8 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_wave_kernel(const BwdP 
     if (p.dgamma) { p.dgamma[ch] = (float)s2; p.dbeta[ch] = (float)s1; }
 }
 
-__global__ void norm_bwd_apply_kernel(const BwdP p) {
+template <class T>
+__global__ void norm_bwd_apply_kernel(const BwdP<T> p) {
     const long total = (long)p.N * p.C * p.S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long plane = i / p.S;
@@ -423,19 +433,20 @@ __global__ void norm_bwd_apply_kernel(const BwdP p) {
         const int n = (int)(plane / p.C);
         const int st = p.mode == 0 ? (int)plane : c;
         const float invstd = p.invstd[st];
-        const float xhat = (p.x[i] - p.mean[st]) * invstd;
+        const float xhat = (c2m_ld(p.x, i) - p.mean[st]) * invstd;
         float scale = p.gamma ? p.gamma[c] : 1.f, shift = p.gamma ? p.beta[c] : 0.f;
         if (p.gb) {
             const long gbase = ((long)n * 2 * p.C + c) * p.S + s;
-            scale = 1.0f + p.gb[gbase];
-            shift = p.gb[gbase + (long)p.C * p.S];
+            scale = 1.0f + c2m_ld(p.gb, gbase);
+            shift = c2m_ld(p.gb, gbase + (long)p.C * p.S);
         }
-        const float g = p.gy[i] * act_grad(xhat * scale + shift, p.act, p.slope);
-        p.dx[i] = invstd * (g * scale - p.coef[st * 2 + 0] - xhat * p.coef[st * 2 + 1]);
+        const float g = c2m_ld(p.gy, i) * act_grad(xhat * scale + shift, p.act, p.slope);
+        c2m_st(p.dx, i, invstd * (g * scale - p.coef[st * 2 + 0] - xhat * p.coef[st * 2 + 1]));
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP p) {
+template <class T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP<T> p) {
     const long plane = blockIdx.x / p.chunks;
     const int chunk = blockIdx.x % p.chunks;
     const long beg = (long)chunk * NORM_CHUNK;
@@ -445,18 +456,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP p) {
     const int st = p.mode == 0 ? (int)plane : c;
     const float mean = p.mean[st], invstd = p.invstd[st], c1 = p.coef[st * 2 + 0], c2 = p.coef[st * 2 + 1];
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
-    const float* __restrict__ xp = p.x + plane * p.S;
-    const float* __restrict__ gp = p.gy + plane * p.S;
-    float* __restrict__ dp = p.dx + plane * p.S;
+    const T* __restrict__ xp = p.x + plane * p.S;
+    const T* __restrict__ gp = p.gy + plane * p.S;
+    T* __restrict__ dp = p.dx + plane * p.S;
     const long gplane = ((long)n * 2 * p.C + c) * p.S, goff = (long)p.C * p.S;
     for (long s = beg + threadIdx.x * 4; s < end; s += 1024) {
-        const float4 xv = *reinterpret_cast<const float4*>(xp + s);
-        const float4 gv = *reinterpret_cast<const float4*>(gp + s);
+        const float4 xv = c2m_ld4(xp + s);
+        const float4 gv = c2m_ld4(gp + s);
         float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
         if (p.gb) {
-            const float4 a = *reinterpret_cast<const float4*>(p.gb + gplane + s);
+            const float4 a = c2m_ld4(p.gb + gplane + s);
             sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
-            sh = *reinterpret_cast<const float4*>(p.gb + gplane + goff + s);
+            sh = c2m_ld4(p.gb + gplane + goff + s);
         }
         const float xh[4] = {(xv.x - mean) * invstd, (xv.y - mean) * invstd, (xv.z - mean) * invstd, (xv.w - mean) * invstd};
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, gyv[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -466,55 +477,43 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP p) {
             const float g = gyv[e] * act_grad(xh[e] * scv[e] + shv[e], p.act, p.slope);
             o[e] = invstd * (g * scv[e] - c1 - xh[e] * c2);
         }
-        *reinterpret_cast<float4*>(dp + s) = make_float4(o[0], o[1], o[2], o[3]);
+        c2m_st4(dp + s, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
 // workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
-C2M_API int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
-                         const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
-                         float* workspace, int N, int C, long S, int mode, int act, float slope, void* stream) {
+C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx,
+                         float* workspace, int N, int C, long S, int mode, int act, float slope, int dt, void* stream) {
     C2M_ENTER();
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    BwdP p;
-    p.x = x; p.gy = gy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.gb = gb; p.ggb = ggb;
-    p.chunks = norm_chunks(S);
-    p.partial = workspace;
-    p.coef = workspace + (long)N * C * p.chunks * 2;
-    p.dgamma = dgamma; p.dbeta = dbeta; p.dx = dx;
-    p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
-    const int nthreads = mode == 0 ? N * C : C;
-    if (N * p.chunks >= 16 && (mode == 1 || dgamma))
-        hipLaunchKernelGGL(norm_bwd_finalize_wave_kernel, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
-    if (norm_vec_ok(S, x, gy, gb, dx))
-        hipLaunchKernelGGL(norm_bwd_apply_vec_kernel, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p);
+    const bool vec = norm_vec_ok(S, x, gy, gb, dx, dt);
+    C2M_DISPATCH_DT(dt,
+        BwdP<T> p;
+        p.x = (const T*)x; p.gy = (const T*)gy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+        p.gb = (const T*)gb; p.ggb = (T*)ggb;
+        p.chunks = norm_chunks(S);
+        p.partial = workspace;
+        p.coef = workspace + (long)N * C * p.chunks * 2;
+        p.dgamma = dgamma; p.dbeta = dbeta; p.dx = (T*)dx;
+        p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
+        const int nthreads = mode == 0 ? N * C : C;
+        if (N * p.chunks >= 16 && (mode == 1 || dgamma))
+            hipLaunchKernelGGL(norm_bwd_finalize_wave_kernel<T>, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL(norm_bwd_finalize_kernel<T>, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
+        if (vec)
+            hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<T>, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p););
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------- activation backward
 // For conv epilogue activations (no norm in between): gradient from the OUTPUT y.
-__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx,
-                               long total, int act, float slope) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const float v = y[i], g = gy[i];
-        float d;
-        switch (act) {
-            case C2M_ACT_RELU: d = v > 0.f ? 1.f : 0.f; break;
-            case C2M_ACT_LRELU: d = v > 0.f ? 1.f : slope; break;
-            case C2M_ACT_SIGMOID: d = v * (1.f - v); break;
-            default: d = 1.f;
-        }
-        gx[i] = g * d;
-    }
-}
-
 __device__ __forceinline__ float act_bwd_elem(float v, float g, int act, float slope) {
     switch (act) {
         case C2M_ACT_RELU: return v > 0.f ? g : 0.f * g;
@@ -524,25 +523,34 @@ __device__ __forceinline__ float act_bwd_elem(float v, float g, int act, float s
     }
 }
 
-__global__ void act_bwd_vec_kernel(const float4* __restrict__ y, const float4* __restrict__ gy, float4* __restrict__ gx,
-                                   long total4, int act, float slope) {
+template <class T>
+__global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx, long total, int act,
+                               float slope) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        c2m_st(gx, i, act_bwd_elem(c2m_ld(y, i), c2m_ld(gy, i), act, slope));
+}
+
+template <class T>
+__global__ void act_bwd_vec_kernel(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx, long total4,
+                                   int act, float slope) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const float4 v = y[i], g = gy[i];
-        gx[i] = make_float4(act_bwd_elem(v.x, g.x, act, slope), act_bwd_elem(v.y, g.y, act, slope),
-                            act_bwd_elem(v.z, g.z, act, slope), act_bwd_elem(v.w, g.w, act, slope));
+        const float4 v = c2m_ld4(y + 4 * i), g = c2m_ld4(gy + 4 * i);
+        c2m_st4(gx + 4 * i, make_float4(act_bwd_elem(v.x, g.x, act, slope), act_bwd_elem(v.y, g.y, act, slope),
+                                        act_bwd_elem(v.z, g.z, act, slope), act_bwd_elem(v.w, g.w, act, slope)));
     }
 }
 
-C2M_API int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream) {
+C2M_API int c2m_act_bwd(const void* y, const void* gy, void* gx, long total, int act, float slope, int dt, void* stream) {
     C2M_ENTER();
     if (total <= 0) return 0;
-    if ((total & 3) == 0 && ((((uintptr_t)y) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0) {
-        hipLaunchKernelGGL(act_bwd_vec_kernel, dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(gy),
-                           reinterpret_cast<float4*>(gx), total / 4, act, slope);
-        return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, gy, gx, total,
-                       act, slope);
+    const uintptr_t mask = dt == C2M_BF16 ? 7 : 15;
+    const bool vec = (total & 3) == 0 && ((((uintptr_t)y) | ((uintptr_t)gy) | ((uintptr_t)gx)) & mask) == 0;
+    C2M_DISPATCH_DT(dt,
+        if (vec)
+            hipLaunchKernelGGL(act_bwd_vec_kernel<T>, dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const T*)y, (const T*)gy, (T*)gx, total / 4, act, slope);
+        else
+            hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                               (const T*)gy, (T*)gx, total, act, slope););
     return (int)hipGetLastError();
 }

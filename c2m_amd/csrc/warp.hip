@@ -12,6 +12,7 @@
 // Layout NCHW; a wave covers 64 consecutive x of one row, so the 4 bilinear taps of a smooth flow are coalesced
 // row segments; coordinates/weights are computed once per pixel and reused across a chunk of channels.
 #include "common.h"
+#include "dtype.h"
 
 __device__ __forceinline__ float lin_m1_1(int i, int steps) {
     if (steps <= 1) return -1.0f;
@@ -49,8 +50,9 @@ __device__ __forceinline__ WarpCoord warp_coord(float fx, float fy, int x, int y
 }
 
 // grid: x = pixel blocks over N*H*W, y = channel chunk
-__global__ void flow_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
-                                     const float* __restrict__ occ, float* __restrict__ out, int N, int C, int H, int W,
+template <class T>
+__global__ void flow_warp_fwd_kernel(const T* __restrict__ img, const float* __restrict__ flow,
+                                     const float* __restrict__ occ, T* __restrict__ out, int N, int C, int H, int W,
                                      int cchunk) {
     const long HW = (long)H * W;
     const long total = (long)N * HW;
@@ -66,17 +68,17 @@ __global__ void flow_warp_fwd_kernel(const float* __restrict__ img, const float*
         const long i00 = (long)k.y0 * W + k.x0, i01 = (long)k.y0 * W + k.x1, i10 = (long)k.y1 * W + k.x0,
                    i11 = (long)k.y1 * W + k.x1;
         for (int c = c0; c < c1; ++c) {
-            const float* __restrict__ pl = img + ((long)n * C + c) * HW;
-            const float vnw = pl[i00];
-            const float vne = k.okx1 ? pl[i01] : 0.0f;
-            const float vsw = k.oky1 ? pl[i10] : 0.0f;
-            const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
+            const T* __restrict__ pl = img + ((long)n * C + c) * HW;
+            const float vnw = c2m_ld(pl, i00);
+            const float vne = k.okx1 ? c2m_ld(pl, i01) : 0.0f;
+            const float vsw = k.oky1 ? c2m_ld(pl, i10) : 0.0f;
+            const float vse = (k.okx1 && k.oky1) ? c2m_ld(pl, i11) : 0.0f;
             float v = vnw * k.nw;
             v = fmaf(vne, k.ne, v);
             v = fmaf(vsw, k.sw, v);
             v = fmaf(vse, k.se, v);
             if (occ) v = v * o;
-            out[((long)n * C + c) * HW + sp] = v;
+            c2m_st(out, ((long)n * C + c) * HW + sp, v);
         }
     }
 }
@@ -219,10 +221,11 @@ __global__ __launch_bounds__(1024) void warp_inv_sort_big_kernel(const int* __re
 }
 
 // grid: x = source-pixel blocks over N*H*W, y = channel chunk.  Every element of gimg is written (no zero-init needed).
-__global__ void flow_warp_bwd_img_kernel(const float* __restrict__ gout, const float* __restrict__ occ,
+template <class T>
+__global__ void flow_warp_bwd_img_kernel(const T* __restrict__ gout, const float* __restrict__ occ,
                                          const int* __restrict__ count, const int* __restrict__ offset,
                                          const int* __restrict__ keys, const float* __restrict__ vals,
-                                         float* __restrict__ gimg, int N, int C, int HW, int cchunk) {
+                                         T* __restrict__ gimg, int N, int C, int HW, int cchunk) {
     constexpr int FAST = 8;
     const long total = (long)N * HW;
     const int c0 = blockIdx.y * cchunk;
@@ -244,23 +247,24 @@ __global__ void flow_warp_bwd_img_kernel(const float* __restrict__ gout, const f
 #pragma unroll
         for (int e = 0; e < FAST; ++e) oc[e] = (occ && e < cnt) ? occ[n * HW + d[e]] : 1.0f;
         for (int c = c0; c < c1; ++c) {
-            const float* __restrict__ g = gout + (n * C + c) * (long)HW;
+            const T* __restrict__ g = gout + (n * C + c) * (long)HW;
             float acc = 0.0f;
 #pragma unroll
             for (int e = 0; e < FAST; ++e)
-                if (e < cnt) acc += (g[d[e]] * oc[e]) * w[e];
+                if (e < cnt) acc += (c2m_ld(g, d[e]) * oc[e]) * w[e];
             for (int e = FAST; e < cnt; ++e) {          // strongly converging flow: the tail of a long list
                 const int de = keys[o + e] >> 2;
-                acc += (g[de] * (occ ? occ[n * HW + de] : 1.0f)) * vals[o + e];
+                acc += (c2m_ld(g, de) * (occ ? occ[n * HW + de] : 1.0f)) * vals[o + e];
             }
-            gimg[(n * C + c) * (long)HW + sp] = acc;
+            c2m_st(gimg, (n * C + c) * (long)HW + sp, acc);
         }
     }
 }
 
 // d(flow): partial sums per channel chunk -> gfpart[chunk][n][2][HW] (or straight into gflow when there is one chunk)
-__global__ void flow_warp_bwd_flow_kernel(const float* __restrict__ img, const float* __restrict__ flow,
-                                          const float* __restrict__ occ, const float* __restrict__ gout,
+template <class T>
+__global__ void flow_warp_bwd_flow_kernel(const T* __restrict__ img, const float* __restrict__ flow,
+                                          const float* __restrict__ occ, const T* __restrict__ gout,
                                           float* __restrict__ dst, int N, int C, int H, int W, int cchunk) {
     const long HW = (long)H * W;
     const long total = (long)N * HW;
@@ -279,12 +283,12 @@ __global__ void flow_warp_bwd_flow_kernel(const float* __restrict__ img, const f
         float gix = 0.0f, giy = 0.0f;
         for (int c = c0; c < c1; ++c) {
             const long pb = ((long)n * C + c) * HW;
-            const float g = gout[pb + sp] * o;
-            const float* __restrict__ pl = img + pb;
-            const float vnw = pl[i00];
-            const float vne = k.okx1 ? pl[i01] : 0.0f;
-            const float vsw = k.oky1 ? pl[i10] : 0.0f;
-            const float vse = (k.okx1 && k.oky1) ? pl[i11] : 0.0f;
+            const float g = c2m_ld(gout, pb + sp) * o;
+            const T* __restrict__ pl = img + pb;
+            const float vnw = c2m_ld(pl, i00);
+            const float vne = k.okx1 ? c2m_ld(pl, i01) : 0.0f;
+            const float vsw = k.oky1 ? c2m_ld(pl, i10) : 0.0f;
+            const float vse = (k.okx1 && k.oky1) ? c2m_ld(pl, i11) : 0.0f;
             gix += g * (k.s_ * (vne - vnw) + k.n_ * (vse - vsw));
             giy += g * (k.e_ * (vsw - vnw) + k.w_ * (vse - vne));
         }
@@ -312,14 +316,14 @@ static void warp_grid(int N, int C, int H, int W, dim3& grid, int& cchunk) {
     grid = dim3(gx, (C + cchunk - 1) / cchunk);
 }
 
-C2M_API int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H,
-                              int W, void* stream) {
+C2M_API int c2m_flow_warp_fwd(const void* img, const float* flow, const float* occ, void* out, int N, int C, int H,
+                              int W, int dt, void* stream) {
     C2M_ENTER();
     if ((long)N * C * H * W <= 0) return 0;
     dim3 grid; int cchunk;
     warp_grid(N, C, H, W, grid, cchunk);
-    hipLaunchKernelGGL(flow_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, flow, occ, out, N, C, H, W,
-                       cchunk);
+    C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(flow_warp_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)img, flow,
+                                           occ, (T*)out, N, C, H, W, cchunk););
     return (int)hipGetLastError();
 }
 
@@ -335,8 +339,8 @@ C2M_API long c2m_flow_warp_bwd_workspace_bytes(int N, int C, int H, int W, int w
     return b > 0 ? b : 4;
 }
 
-C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
-                              float* gflow, int N, int C, int H, int W, void* workspace, void* stream) {
+C2M_API int c2m_flow_warp_bwd(const void* img, const float* flow, const float* occ, const void* gout, void* gimg,
+                              float* gflow, int N, int C, int H, int W, void* workspace, int dt, void* stream) {
     C2M_ENTER();
     if ((long)N * C * H * W <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -364,12 +368,13 @@ C2M_API int c2m_flow_warp_bwd(const float* img, const float* flow, const float* 
                            nbig, biglist);
         hipLaunchKernelGGL(warp_inv_sort_big_kernel, dim3(64), dim3(1024), 0, s, count, offset, keys, vals, (int)HW, nbig,
                            biglist);
-        hipLaunchKernelGGL(flow_warp_bwd_img_kernel, grid, dim3(256), 0, s, gout, occ, count, offset, keys, vals, gimg, N,
-                           C, (int)HW, cchunk);
+        C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(flow_warp_bwd_img_kernel<T>, grid, dim3(256), 0, s, (const T*)gout, occ, count,
+                                               offset, keys, vals, (T*)gimg, N, C, (int)HW, cchunk););
     }
     if (gflow) {
         float* dst = grid.y > 1 ? (float*)ws : gflow;
-        hipLaunchKernelGGL(flow_warp_bwd_flow_kernel, grid, dim3(256), 0, s, img, flow, occ, gout, dst, N, C, H, W, cchunk);
+        C2M_DISPATCH_DT(dt, hipLaunchKernelGGL(flow_warp_bwd_flow_kernel<T>, grid, dim3(256), 0, s, (const T*)img, flow, occ,
+                                               (const T*)gout, dst, N, C, H, W, cchunk););
         if (grid.y > 1)
             hipLaunchKernelGGL(warp_flow_chunk_sum_kernel, dim3(c2m_grid(px * 2, 256)), dim3(256), 0, s, dst, gflow,
                                px * 2, (int)grid.y);
@@ -400,18 +405,18 @@ __device__ __forceinline__ Lerp lerp_src(int o, int in, float scale, bool align)
         else hipLaunchKernelGGL((KERNEL<long>), grid, dim3(256), 0, stream, __VA_ARGS__);                  \
     } while (0)
 
-template <typename I>
-__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi,
+template <typename I, class T = float>
+__global__ void resize_bilinear_kernel(const T* __restrict__ in, T* __restrict__ out, long NC, int Hi, int Wi,
                                        int Ho, int Wo, float sh, float sw, int align, float mul) {
     const I total = (I)(NC * Ho * Wo);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
         const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
         const Lerp ly = lerp_src(oy, Hi, sh, align), lx = lerp_src(ox, Wi, sw, align);
-        const float* __restrict__ p = in + (long)nc * Hi * Wi;
-        const float v = ly.l0 * (lx.l0 * p[ly.i0 * Wi + lx.i0] + lx.l1 * p[ly.i0 * Wi + lx.i1]) +
-                        ly.l1 * (lx.l0 * p[ly.i1 * Wi + lx.i0] + lx.l1 * p[ly.i1 * Wi + lx.i1]);
-        out[i] = v * mul;
+        const T* __restrict__ p = in + (long)nc * Hi * Wi;
+        const float v = ly.l0 * (lx.l0 * c2m_ld(p, ly.i0 * Wi + lx.i0) + lx.l1 * c2m_ld(p, ly.i0 * Wi + lx.i1)) +
+                        ly.l1 * (lx.l0 * c2m_ld(p, ly.i1 * Wi + lx.i0) + lx.l1 * c2m_ld(p, ly.i1 * Wi + lx.i1));
+        c2m_st(out, (long)i, v * mul);
     }
 }
 
@@ -421,14 +426,27 @@ static float area_scale(int in, int out, int align, double scale_factor) {
     return (float)in / (float)out;
 }
 
-C2M_API int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
-                                double scale_factor, void* stream) {
-    C2M_ENTER();
+static int resize_bilinear_launch(const void* in, void* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
+                                  double scale_factor, int dt, void* stream) {
     const long total = NC * Ho * Wo;
     if (total <= 0) return 0;
-    C2M_IDX_DISPATCH(total, resize_bilinear_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi,
-                     Ho, Wo, area_scale(Hi, Ho, align, scale_factor), area_scale(Wi, Wo, align, scale_factor), align, 1.0f);
+    const float sh = area_scale(Hi, Ho, align, scale_factor), sw = area_scale(Wi, Wo, align, scale_factor);
+    const dim3 grid(c2m_grid(total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dt == C2M_BF16) {
+        if (total < (1L << 31)) hipLaunchKernelGGL((resize_bilinear_kernel<unsigned, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, NC, Hi, Wi, Ho, Wo, sh, sw, align, 1.0f);
+        else hipLaunchKernelGGL((resize_bilinear_kernel<long, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, NC, Hi, Wi, Ho, Wo, sh, sw, align, 1.0f);
+    } else {
+        if (total < (1L << 31)) hipLaunchKernelGGL((resize_bilinear_kernel<unsigned, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, NC, Hi, Wi, Ho, Wo, sh, sw, align, 1.0f);
+        else hipLaunchKernelGGL((resize_bilinear_kernel<long, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, NC, Hi, Wi, Ho, Wo, sh, sw, align, 1.0f);
+    }
     return (int)hipGetLastError();
+}
+
+C2M_API int c2m_resize_bilinear(const void* in, void* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
+                                double scale_factor, int dt, void* stream) {
+    C2M_ENTER();
+    return resize_bilinear_launch(in, out, NC, Hi, Wi, Ho, Wo, align, scale_factor, dt, stream);
 }
 
 // x2 upsample (align_corners=False; up_block.py:10): one thread per INPUT pixel writes its 2x2 outputs as two 8-byte
@@ -457,7 +475,8 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
 }
 
 // adjoint of the x2 (align_corners=False, scale 0.5) upsample, gather form (deterministic, no atomics)
-__device__ __forceinline__ float upsample2x_bwd_pixel(const float* __restrict__ g, int y, int x, int Hi, int Wi) {
+template <class T = float>
+__device__ __forceinline__ float upsample2x_bwd_pixel(const T* __restrict__ g, int y, int x, int Hi, int Wi) {
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     float wy[4], wx[4];
 #pragma unroll
@@ -476,20 +495,20 @@ __device__ __forceinline__ float upsample2x_bwd_pixel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int ox = 2 * x - 1 + b;
-            if (wx[b] != 0.0f) row += wx[b] * g[oy * Wo + ox];
+            if (wx[b] != 0.0f) row += wx[b] * c2m_ld(g, oy * Wo + ox);
         }
         acc += wy[a] * row;
     }
     return acc;
 }
 
-template <typename I>
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long NC, int Hi, int Wi) {
+template <typename I, class T = float>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ gout, T* __restrict__ gin, long NC, int Hi, int Wi) {
     const I total = (I)(NC * Hi * Wi);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
         const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
-        gin[i] = upsample2x_bwd_pixel(gout + (long)nc * (4L * Hi * Wi), y, x, Hi, Wi);
+        c2m_st(gin, (long)i, upsample2x_bwd_pixel<T>(gout + (long)nc * (4L * Hi * Wi), y, x, Hi, Wi));
     }
 }
 
@@ -584,19 +603,29 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* _
     }
 }
 
-C2M_API int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+C2M_API int c2m_upsample2x_fwd(const void* in_, void* out_, long NC, int Hi, int Wi, int dt, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    if ((((uintptr_t)out) & 7) != 0) return c2m_resize_bilinear(in, out, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, stream);
+    // bf16 activations: the generic bilinear kernel (same lerp_src weights) on 2-byte elements
+    if (dt == C2M_BF16 || (((uintptr_t)out_) & 7) != 0)
+        return resize_bilinear_launch(in_, out_, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, dt, stream);
+    const float* in = (const float*)in_; float* out = (float*)out_;
     C2M_IDX_DISPATCH(total * 4, upsample2x_fwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi);
     return (int)hipGetLastError();
 }
 
-C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+C2M_API int c2m_upsample2x_bwd(const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
+    if (dt == C2M_BF16) {
+        const dim3 grid(c2m_grid(total, 256));
+        if (total * 4 < (1L << 31)) hipLaunchKernelGGL((upsample2x_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+        else hipLaunchKernelGGL((upsample2x_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+        return (int)hipGetLastError();
+    }
+    const float* gout = (const float*)gout_; float* gin = (float*)gin_;
     if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31)) {
         const int tx = Wi >= 64 ? 64 : 32;
         const long tiles = (long)c2m_cdiv(Wi, tx) * c2m_cdiv(Hi, UB_TY) * NC;
@@ -619,22 +648,22 @@ C2M_API int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, i
 }
 
 // ------------------------------------------------------------------------------------------- maxpool 2x2 / 2
-template <typename I>
-__global__ void maxpool2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi) {
+template <typename I, class T = float>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, long NC, int Hi, int Wi) {
     const int Ho = Hi / 2, Wo = Wi / 2;
     const I total = (I)(NC * Ho * Wo);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
         const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
-        const float* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
-        out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Wi], p[Wi + 1]));
+        const T* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
+        c2m_st(out, (long)i, fmaxf(fmaxf(c2m_ld(p, 0), c2m_ld(p, 1)), fmaxf(c2m_ld(p, Wi), c2m_ld(p, Wi + 1))));
     }
 }
 
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
-template <typename I>
-__global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
-                                    float* __restrict__ gin, long NC, int Hi, int Wi) {
+template <typename I, class T = float>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restrict__ gout,
+                                    T* __restrict__ gin, long NC, int Hi, int Wi) {
     const int Ho = Hi / 2, Wo = Wi / 2;
     const I total = (I)(NC * Hi * Wi);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
@@ -643,21 +672,28 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* _
         const int oy = y / 2, ox = x / 2;
         float g = 0.0f;
         if (oy < Ho && ox < Wo) {
-            const float* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
-            const float v[4] = {p[0], p[1], p[Wi], p[Wi + 1]};
+            const T* __restrict__ p = in + (long)nc * Hi * Wi + (2 * oy) * Wi + 2 * ox;
+            const float v[4] = {c2m_ld(p, 0), c2m_ld(p, 1), c2m_ld(p, Wi), c2m_ld(p, Wi + 1)};
             int arg = 0; float m = v[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
-            if (arg == (y & 1) * 2 + (x & 1)) g = gout[(long)nc * Ho * Wo + oy * Wo + ox];
+            if (arg == (y & 1) * 2 + (x & 1)) g = c2m_ld(gout, (long)nc * Ho * Wo + oy * Wo + ox);
         }
-        gin[i] = g;
+        c2m_st(gin, (long)i, g);
     }
 }
 
-C2M_API int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream) {
+C2M_API int c2m_maxpool2x2_fwd(const void* in_, void* out_, long NC, int Hi, int Wi, int dt, void* stream) {
     C2M_ENTER();
     const long total = NC * (Hi / 2) * (Wi / 2);
     if (total <= 0) return 0;
+    if (dt == C2M_BF16) {
+        const dim3 grid(c2m_grid(total, 256));
+        if (NC * Hi * Wi < (1L << 31)) hipLaunchKernelGGL((maxpool2_fwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (bf16_t*)out_, NC, Hi, Wi);
+        else hipLaunchKernelGGL((maxpool2_fwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (bf16_t*)out_, NC, Hi, Wi);
+        return (int)hipGetLastError();
+    }
+    const float* in = (const float*)in_; float* out = (float*)out_;
     C2M_IDX_DISPATCH(NC * Hi * Wi, maxpool2_fwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi);
     return (int)hipGetLastError();
 }
@@ -684,10 +720,17 @@ __global__ void maxpool2_bwd_win_kernel(const float* __restrict__ in, const floa
     }
 }
 
-C2M_API int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream) {
+C2M_API int c2m_maxpool2x2_bwd(const void* in_, const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream) {
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
+    if (dt == C2M_BF16) {
+        const dim3 grid(c2m_grid(total, 256));
+        if (total < (1L << 31)) hipLaunchKernelGGL((maxpool2_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+        else hipLaunchKernelGGL((maxpool2_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+        return (int)hipGetLastError();
+    }
+    const float* in = (const float*)in_; const float* gout = (const float*)gout_; float* gin = (float*)gin_;
     if ((Hi & 1) == 0 && (Wi & 1) == 0 && ((((uintptr_t)in) | ((uintptr_t)gin)) & 7) == 0) {
         C2M_IDX_DISPATCH(total, maxpool2_bwd_win_kernel, dim3(c2m_grid(total / 4, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
         return (int)hipGetLastError();

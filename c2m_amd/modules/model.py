@@ -36,6 +36,20 @@ def _stack_time(x):
     return x.permute(0, 2, 1, 3, 4).reshape(b, t * c, h, w)
 
 
+def _linear_input_cast(module, args):
+    x = args[0]
+    return (x.to(module.weight.dtype),) if x.dtype != module.weight.dtype else None
+
+
+def _cast_linear_inputs(root):
+    """bf16 data path (ops.set_conv_precision("bf16")): convolution outputs are bf16 while the few nn.Linear layers of the
+    path (VAE heads, RoI regressors, GNN) keep fp32 weights and run on torch's GEMM; their inputs are widened at the boundary
+    ([B, 4096]-sized vectors).  A no-op in fp32 mode."""
+    for m in root.modules():
+        if isinstance(m, nn.Linear):
+            m.register_forward_pre_hook(_linear_input_cast)
+
+
 class GeneratorFullModel(nn.Module):
     def __init__(self, train_params=None, model_params=None, is_inference=False, dataset="cityscape"):
         super().__init__()
@@ -50,6 +64,7 @@ class GeneratorFullModel(nn.Module):
         self.criterionFeat = torch.nn.L1Loss()
         self.generator = OcclusionAwareGenerator(mp["generator"], mp["flow_embedder"],
                                                  input_channel=mp["common_params"]["image_channel"], dataset=dataset)
+        _cast_linear_inputs(self)
         if is_inference:
             return
         self.objective_func = losses.TrainingLosses(tp, mp)

@@ -42,8 +42,8 @@ def _dev(*ts):
             continue
         if not t.is_cuda:
             raise RuntimeError("c2m_amd ops need tensors on a HIP device (no CPU fallback by design)")
-        if t.dtype != torch.float32:
-            raise RuntimeError(f"c2m_amd ops compute in fp32, got {t.dtype}")
+        if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+            raise RuntimeError(f"c2m_amd ops take fp32 (or, on the bf16 data path, bf16) tensors, got {t.dtype}")
         if cur is None:
             cur = _cur_device()
         if t.device.index != cur:       # kernels are launched on the CURRENT device's stream (see _stream)
@@ -53,6 +53,27 @@ def _dev(*ts):
 
 def _f(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+BF16 = torch.bfloat16
+
+
+def _dt(t):
+    """Element-type code of the C ABI (csrc/dtype.h): 0 = fp32, 1 = bf16."""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _as(t, dtype):
+    """t in `dtype`, contiguous (None passes through)."""
+    if t is None:
+        return None
+    return _f(t if t.dtype == dtype else t.to(dtype))
+
+
+def _thin(M, splits, npix, two_target=False, ncls=1):
+    """The dispatch rule of c2m_conv_igemm for the <= 4-output-row vector-ALU kernels (conv_igemm.hip): those are fp32 in,
+    fp32 out in either precision mode, so the host must hand them fp32 tensors."""
+    return M <= 4 and splits == 1 and npix >= 16384 and not two_target and ncls == 1
 
 
 # =============================================================================================== convolution
@@ -69,9 +90,13 @@ _WINO_WGRAD = os.environ.get("C2M_WINOGRAD_WGRAD", "auto")      # "auto" | "off"
 
 
 def set_conv_precision(precision):
-    """"fp32" (default: exact fp32 MFMA) or "bf16": conv operands (activations, weights, output gradients) are rounded to
-    bf16 while staged into LDS and multiplied on the bf16 MFMA with fp32 accumulation; tensors in HBM, norms, warps and
-    losses stay fp32.  BASELINE configs[2-4] ("bf16") run in this mode.  Returns the previous setting."""
+    """"fp32" (default: exact fp32 MFMA, fp32 tensors) or "bf16" (BASELINE configs[2-4]): the bf16 data path.  Convolutions
+    multiply bf16 operands on the bf16 MFMA with fp32 accumulation AND write bf16 activations (NCHW, as PyTorch lays them
+    out); norm / activation / up-sampling / pooling / warping kernels read and write bf16 with fp32 arithmetic in registers;
+    gradients of those activations are bf16 as well.  Stays fp32: weights and their gradients (the optimizer's master copy),
+    norm statistics, losses, flows / occlusion / index masks (bit-exact paths), the <= 4-channel heads (flow, occlusion,
+    RGB).  An fp32 tensor handed to a bf16-mode convolution is cast once (RNE), so old call sites keep working.
+    Returns the previous setting."""
     global _conv_bf16
     if precision not in ("fp32", "bf16"):
         raise ValueError(f"unknown conv precision {precision!r}")
@@ -631,9 +656,20 @@ def _packed(w, frozen, kind, build):
     return A
 
 
-def _conv_dgrad(pl, w, gy, frozen_w):
+def _set_io(geom, x, ydt):
+    """Per-call element types / bounds of a c2m_conv_igemm geom: X bytes (buffer range check), X type, Y type."""
+    geom[32] = x.numel() * x.element_size()
+    geom[90] = _dt(x)
+    geom[91] = 1 if ydt == BF16 else 0
+    return geom
+
+
+def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
     """Data gradient of the convolution described by plan `pl` (= the transposed convolution of gy with w): shared by
-    _ConvFn.backward and conv_transpose2d.  gy contiguous [N, Cout, (To,) Ho, Wo]; returns [N, Cin, (Ti,) Hi, Wi]."""
+    _ConvFn.backward and conv_transpose2d.  gy contiguous [N, Cout, (To,) Ho, Wo]; returns [N, Cin, (Ti,) Hi, Wi] in
+    `out_dtype` (the dtype of the forward input: bf16 on the bf16 data path, fp32 for fp32 inputs)."""
+    if not pl.bf16:
+        gy = _as(gy, torch.float32)
     L = _lib.lib()
     N, Cin, Cout = pl.dims[0:3]
     Ti_, Hi_, Wi_ = pl.dims[3:6]
@@ -656,7 +692,7 @@ def _conv_dgrad(pl, w, gy, frozen_w):
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad 3-D")
         if pl.reflect:
             Ti, Hi, Wi = pl.dims[3:6]
-            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, _stream()), "reflect fold 3-D")
+            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, 0, _stream()), "reflect fold 3-D")
         if dM < Cin:
             gx[:, dM:].zero_()
     elif pl.wino_dgrad:
@@ -672,19 +708,33 @@ def _conv_dgrad(pl, w, gy, frozen_w):
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad")
         if pl.reflect:
             Ti, Hi, Wi = pl.dims[3:6]
-            _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, _stream()),
+            _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, 0, _stream()),
                        "reflect border add")
     else:
         S = pl.dgrad_splits
         folded = pl.reflect and any(pl.pad)
         two_target = folded and S == 1 and not pl.dgrad_needs_zero
         alloc = torch.zeros if pl.dgrad_needs_zero else torch.empty
-        tgt = alloc(pl.dgrad_target, device=dev, dtype=torch.float32)
-        gx = torch.empty(xshape, device=dev, dtype=torch.float32) if folded else tgt.view(xshape)
+        cb = pl.cls_batch
+        # bf16 data path: the bf16 kernels gather gy as bf16 and write `kdt`; the <= 4-row vector-ALU kernels (dgrad of a
+        # <= 4-channel input) are fp32 in, fp32 out -- if any launch of this layer is one of those, the layer's target is fp32
+        gy_b = gy_f = None
+        thin_of = {}
+        kdt = torch.float32
+        if pl.bf16:
+            if cb is None:
+                thin_of = {id(c): _thin(pl.dM, S, c["npix"], two_target, 1) for c in pl.classes}
+            any_thin = any(thin_of.values())
+            kdt = BF16 if (out_dtype == BF16 and not any_thin) else torch.float32
+            if cb is not None or not all(thin_of.values()):
+                gy_b = _as(gy, BF16)
+            if any_thin:
+                gy_f = _as(gy, torch.float32)
+        tgt = alloc(pl.dgrad_target, device=dev, dtype=kdt)
+        gx = torch.empty(xshape, device=dev, dtype=kdt) if folded else tgt.view(xshape)
         dst = tgt if S == 1 else alloc(S * tgt.numel(), device=dev, dtype=torch.float32)
         st, sh, sw = pl.stride
         w5 = w if pl.is3d else w.unsqueeze(2)
-        cb = pl.cls_batch
         if cb is not None:
             kt, kh, kw = pl.dims[9:12]
             A = _packed(w, frozen_w, ("dgrad-all", cb["ck"], pl.stride), lambda: _pack_native(
@@ -693,9 +743,11 @@ def _conv_dgrad(pl, w, gy, frozen_w):
                 Ag = A[grp["first"] * Cin:]
                 tag = ("dgrad", Cin, Cout * cb["taps"], grp["npix"] * grp["ncls"], pl.dims[9:12], pl.stride,
                        pl.reflect, S)
+                gin = gy_b if pl.bf16 else gy
+                _set_io(grp["geom"], gin, kdt)
                 _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm",
                                   pl.dgrad_flops * cb["taps"] * grp["npix"] * grp["ncls"] / pl.dgrad_work,
-                                  lambda: L.c2m_conv_igemm(_p(Ag), _p(gy), _p(dst), _p(gx) if two_target else None,
+                                  lambda: L.c2m_conv_igemm(_p(Ag), _p(gin), _p(dst), _p(gx) if two_target else None,
                                                            None, _p(grp["tab"]), _gp(grp["geom"]), 0, 0.0,
                                                            _stream()), tag,
                                   4 * (gy.numel() * grp["ncls"] // cb["ncls"] + w.numel() +
@@ -714,21 +766,23 @@ def _conv_dgrad(pl, w, gy, frozen_w):
                 w, frozen_w, ("dgrad", c["ck"], pl.stride, c["r"]), lambda: _pack_rows(
                     w5[:, :, rt::st, ry::sh, rx::sw].reshape(Cout, Cin, c["taps"]).transpose(0, 1), c["ck"]))
             tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
+            gin = (gy_f if thin_of.get(id(c)) else gy_b) if pl.bf16 else gy
+            _set_io(c["geom"], gin, torch.float32 if thin_of.get(id(c)) else kdt)
             _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
-                              lambda: L.c2m_conv_igemm(_p(A), _p(gy), _p(dst), _p(gx) if two_target else None, None,
+                              lambda: L.c2m_conv_igemm(_p(A), _p(gin), _p(dst), _p(gx) if two_target else None, None,
                                                        _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
                               4 * (gy.numel() + w.numel() + xnumel) // len(pl.classes)), "conv_igemm dgrad")
         if S > 1:
-            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _stream()),
+            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _dt(tgt), _stream()),
                        "splitk_reduce dgrad")
         if folded:
             Ti, Hi, Wi = pl.dims[3:6]
             fold = L.c2m_reflect_border_add if two_target else L.c2m_reflect_fold
-            _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _stream()),
+            _lib.check(fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, pl.pad[0], pl.pad[1], pl.pad[2], _dt(tgt), _stream()),
                        "reflect fold")
         if pl.dM < Cin:
             gx[:, pl.dM:].zero_()            # channels declared gradient-free by the caller (dgrad_rows)
-    return gx
+    return gx if gx.dtype == out_dtype else gx.to(out_dtype)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -741,6 +795,9 @@ class _ConvFn(torch.autograd.Function):
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
         ctx.frozen_w = not ctx.needs_input_grad[1]
+        ctx.x_dtype = x.dtype
+        if not pl.bf16:
+            x = _as(x, torch.float32)            # the fp32 kernels are fp32 in, fp32 out
         if pl.wino_fwd:
             if pl.wino3d:      # virtual channels (kt, ci): [Cout][3*Cin][3][3]
                 U = _packed(w, ctx.frozen_w, ("wino-fwd3d",), lambda: _wino_filter(
@@ -760,17 +817,27 @@ class _ConvFn(torch.autograd.Function):
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-patch",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 9))
         else:
             A = _packed(w, ctx.frozen_w, ("fwd", pl.ck), lambda: _pack_native(w, Cout, Cin, pl.ck, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
-        y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
         S = pl.fwd_splits
+        ydt = torch.float32
+        if pl.bf16:
+            # bf16 data path: bf16 in (an fp32 input is cast once), bf16 out -- except the <= 4-channel heads (flow, occlusion,
+            # RGB), which stay fp32 and run on the fp32 vector-ALU kernels when the launch is big enough for them
+            if _thin(Cout, S, int(pl.fwd_geom[3])):
+                x = _as(x, torch.float32)
+            else:
+                x = _as(x, BF16)
+                ydt = BF16 if Cout > 4 else torch.float32
+        y = torch.empty(pl.out_shape, device=x.device, dtype=ydt)
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
+        _set_io(pl.fwd_geom, x, ydt)
         _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                           lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
                                                    ACT[act], slope, _stream()), tag,
-                          4 * (x.numel() + w.numel() + y.numel())), "conv_igemm fwd")
+                          x.element_size() * x.numel() + 4 * w.numel() + y.element_size() * y.numel()), "conv_igemm fwd")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
-                                           slope, _stream()), "splitk_reduce")
+                                           slope, _dt(y), _stream()), "splitk_reduce")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
         return y
@@ -781,13 +848,16 @@ class _ConvFn(torch.autograd.Function):
         pl, L = ctx.pl, _lib.lib()
         gy = _f(gy)
         if ACT[ctx.act]:
+            gy = _as(gy, y.dtype)
             g = torch.empty_like(gy)
-            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], ctx.slope, _stream()), "act_bwd")
+            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], ctx.slope, _dt(y), _stream()), "act_bwd")
             gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w)
+            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype)
+        if not pl.bf16:
+            gy = _as(gy, torch.float32)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:
             S = pl.wino_wg_splits
             Ti, Hi, Wi = pl.dims[3:6]
@@ -820,10 +890,16 @@ class _ConvFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
+            # bf16 data path: the MFMA kernel gathers bf16 dY and X; the <= 4-output-channel heads run on the fp32 vector-ALU
+            # kernels (c2m_conv_wgrad's own rule: M <= 4 and >= 16384 pixels)
+            wdt = BF16 if (pl.bf16 and not (Cout <= 4 and int(pl.wg_geom[3]) >= 16384)) else torch.float32
+            xg, gyw = _as(x, wdt), _as(gy, wdt)
+            pl.wg_geom[32], pl.wg_geom[33] = xg.numel() * xg.element_size(), gyw.numel() * gyw.element_size()
+            pl.wg_geom[90] = _dt(xg)
             _lib.check(_timed("wgrad_bf16" if pl.bf16 else "wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
-                              lambda: L.c2m_conv_wgrad(_p(gy), _p(x), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
+                              lambda: L.c2m_conv_wgrad(_p(gyw), _p(xg), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
                                                        _gp(pl.wg_geom), _stream()), tag,
-                              4 * (gy.numel() + x.numel() + w.numel())), "conv_wgrad")
+                              xg.element_size() * (gyw.numel() + xg.numel()) + 4 * w.numel()), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
         return gx, gw, gb, None, None, None, None, None, None
 
@@ -875,8 +951,9 @@ def conv_transpose2d(x, w, b=None, stride=2, padding=1, act=None, slope=LRELU_SL
     if pl.out_shape != (N, Ci, H, W):
         raise ValueError(f"conv_transpose2d: inconsistent geometry {tuple(x.shape)} vs {pl.out_shape}")
     with torch.no_grad():
-        y = _conv_dgrad(pl, w, x, True)
+        y = _conv_dgrad(pl, w, x, True, x.dtype)
         if b is not None or ACT[act]:
+            y = _as(y, torch.float32)
             _lib.check(_lib.lib().c2m_bias_act(_p(y), _p(b), N, Co, Ho * Wo, ACT[act], float(slope), _stream()), "bias_act")
     return y
 
@@ -912,7 +989,9 @@ class _NormActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum):
         _dev(x, gamma, beta, gb)
         x = _f(x)
-        gb = _f(gb) if gb is not None else None
+        ctx.gb_dtype = gb.dtype if gb is not None else None
+        gb = _as(gb, x.dtype)                   # the SPADE map shares the activation type (bf16 on the bf16 data path)
+        dt = _dt(x)
         N, C = x.shape[0], x.shape[1]
         S = x.numel() // (N * C)
         L = _lib.lib()
@@ -921,10 +1000,10 @@ class _NormActFn(torch.autograd.Function):
         invstd = torch.empty_like(mean)
         ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
         _lib.check(L.c2m_norm_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), N, C, S, mode,
-                                    eps, momentum, _stream()), "norm_stats")
+                                    eps, momentum, dt, _stream()), "norm_stats")
         y = torch.empty_like(x)
         _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(y), N, C, S, mode,
-                                    ACT[act], LRELU_SLOPE, _stream()), "norm_apply")
+                                    ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
         ctx.cfg = (N, C, S, mode, act)
         ctx.save_for_backward(x, gamma, beta, gb, mean, invstd)
         return y
@@ -934,14 +1013,17 @@ class _NormActFn(torch.autograd.Function):
         x, gamma, beta, gb, mean, invstd = ctx.saved_tensors
         N, C, S, mode, act = ctx.cfg
         L = _lib.lib()
-        gy = _f(gy)
+        gy = _as(gy, x.dtype)
         dx = torch.empty_like(x)
         ggb = torch.empty_like(gb) if gb is not None else None
         dgamma = torch.empty_like(gamma) if gamma is not None else None
         dbeta = torch.empty_like(beta) if gamma is not None else None
         ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
         _lib.check(L.c2m_norm_bwd(_p(x), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(ggb), _p(dgamma),
-                                  _p(dbeta), _p(dx), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _stream()), "norm_bwd")
+                                  _p(dbeta), _p(dx), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _dt(x), _stream()),
+                   "norm_bwd")
+        if ggb is not None and ggb.dtype != ctx.gb_dtype:
+            ggb = ggb.to(ctx.gb_dtype)
         return dx, dgamma, dbeta, ggb, None, None, None, None, None, None
 
 
@@ -963,13 +1045,15 @@ class _FlowWarpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, flow, occ):
         _dev(img, flow, occ)
-        img, flow = _f(img), _f(flow)
-        occ = _f(occ) if occ is not None else None
+        ctx.flow_dtype = flow.dtype
+        img, flow = _f(img), _as(flow, torch.float32)        # coordinates are never rounded to bf16
+        occ = _as(occ, torch.float32)
         N, C, H, W = img.shape
         assert flow.shape == (N, 2, H, W), f"flow {tuple(flow.shape)} vs image {tuple(img.shape)}"
         assert occ is None or occ.shape == (N, 1, H, W)
         out = torch.empty_like(img)
-        _lib.check(_lib.lib().c2m_flow_warp_fwd(_p(img), _p(flow), _p(occ), _p(out), N, C, H, W, _stream()), "flow_warp")
+        _lib.check(_lib.lib().c2m_flow_warp_fwd(_p(img), _p(flow), _p(occ), _p(out), N, C, H, W, _dt(img), _stream()),
+                   "flow_warp")
         ctx.save_for_backward(img, flow, occ)
         return out
 
@@ -983,8 +1067,10 @@ class _FlowWarpFn(torch.autograd.Function):
         if gimg is not None or gflow is not None:
             ws = torch.empty(L.c2m_flow_warp_bwd_workspace_bytes(N, C, H, W, int(gimg is not None), int(gflow is not None)),
                              device=img.device, dtype=torch.uint8)
-            _lib.check(L.c2m_flow_warp_bwd(_p(img), _p(flow), _p(occ), _p(_f(gout)), _p(gimg), _p(gflow), N, C, H, W,
-                                           _p(ws), _stream()), "flow_warp_bwd")
+            _lib.check(L.c2m_flow_warp_bwd(_p(img), _p(flow), _p(occ), _p(_as(gout, img.dtype)), _p(gimg), _p(gflow), N, C, H,
+                                           W, _p(ws), _dt(img), _stream()), "flow_warp_bwd")
+        if gflow is not None and gflow.dtype != ctx.flow_dtype:
+            gflow = gflow.to(ctx.flow_dtype)
         return gimg, gflow, None
 
 
@@ -1038,16 +1124,17 @@ class _Upsample2xFn(torch.autograd.Function):
         _dev(x)
         x = _f(x)
         N, C, H, W = x.shape
-        y = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _stream()), "upsample2x")
+        y = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _dt(x), _stream()), "upsample2x")
         ctx.shape = (N, C, H, W)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         N, C, H, W = ctx.shape
-        gx = torch.empty(N, C, H, W, device=gy.device, dtype=torch.float32)
-        _lib.check(_lib.lib().c2m_upsample2x_bwd(_p(_f(gy)), _p(gx), N * C, H, W, _stream()), "upsample2x_bwd")
+        gy = _f(gy)
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
+        _lib.check(_lib.lib().c2m_upsample2x_bwd(_p(gy), _p(gx), N * C, H, W, _dt(gy), _stream()), "upsample2x_bwd")
         return gx
 
 
@@ -1063,9 +1150,9 @@ def resize_bilinear(x, size, align_corners=False):
     x = _f(x)
     N, C, H, W = x.shape
     Ho, Wo = int(size[0]), int(size[1])
-    y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
     _lib.check(_lib.lib().c2m_resize_bilinear(_p(x), _p(y), N * C, H, W, Ho, Wo, 1 if align_corners else 0, 0.0,
-                                              _stream()), "resize_bilinear")
+                                              _dt(x), _stream()), "resize_bilinear")
     return y
 
 
@@ -1075,8 +1162,8 @@ class _MaxPool2Fn(torch.autograd.Function):
         _dev(x)
         x = _f(x)
         N, C, H, W = x.shape
-        y = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().c2m_maxpool2x2_fwd(_p(x), _p(y), N * C, H, W, _stream()), "maxpool")
+        y = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.lib().c2m_maxpool2x2_fwd(_p(x), _p(y), N * C, H, W, _dt(x), _stream()), "maxpool")
         ctx.save_for_backward(x)
         return y
 
@@ -1085,7 +1172,8 @@ class _MaxPool2Fn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         N, C, H, W = x.shape
         gx = torch.empty_like(x)
-        _lib.check(_lib.lib().c2m_maxpool2x2_bwd(_p(x), _p(_f(gy)), _p(gx), N * C, H, W, _stream()), "maxpool_bwd")
+        _lib.check(_lib.lib().c2m_maxpool2x2_bwd(_p(x), _p(_as(gy, x.dtype)), _p(gx), N * C, H, W, _dt(x), _stream()),
+                   "maxpool_bwd")
         return gx
 
 
@@ -1097,7 +1185,8 @@ class _RoiAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, boxes, ph, pw, scale):
         _dev(feat, boxes)
-        feat, boxes = _f(feat), _f(boxes)
+        ctx.feat_dtype = feat.dtype
+        feat, boxes = _as(feat, torch.float32), _as(boxes, torch.float32)      # a [B,64,32,64] map: fp32 kernel, cast once
         N, C, H, W = feat.shape
         K = boxes.shape[0]
         out = torch.empty(K, C, ph, pw, device=feat.device, dtype=torch.float32)
@@ -1112,9 +1201,9 @@ class _RoiAlignFn(torch.autograd.Function):
         (boxes,) = ctx.saved_tensors
         N, C, H, W, K, ph, pw, scale = ctx.cfg
         gfeat = torch.empty(N, C, H, W, device=gout.device, dtype=torch.float32)
-        _lib.check(_lib.lib().c2m_roi_align_bwd(_p(boxes), _p(_f(gout)), _p(gfeat), N, K, C, H, W, ph, pw, scale, _stream()),
-                   "roi_align_bwd")
-        return gfeat, None, None, None, None
+        _lib.check(_lib.lib().c2m_roi_align_bwd(_p(boxes), _p(_as(gout, torch.float32)), _p(gfeat), N, K, C, H, W, ph, pw,
+                                                scale, _stream()), "roi_align_bwd")
+        return gfeat if gfeat.dtype == ctx.feat_dtype else gfeat.to(ctx.feat_dtype), None, None, None, None
 
 
 def roi_align(feat, boxes, output_size, spatial_scale=1.0):
@@ -1127,7 +1216,7 @@ def roi_align(feat, boxes, output_size, spatial_scale=1.0):
 def sparse_raster(instance, obj_id, obj_batch, thetas):
     """instance [B,H,W] float ids, obj_id/obj_batch [K], thetas [K,T,6] -> (bw [B,2,T,H,W], fw, bin [B,1,T,H,W])."""
     _dev(instance, thetas)
-    instance, thetas = _f(instance), _f(thetas.detach())
+    instance, thetas = _as(instance, torch.float32), _as(thetas.detach(), torch.float32)
     B, H, W = instance.shape
     K, T = thetas.shape[0], thetas.shape[1]
     oid = obj_id.to(device=instance.device, dtype=torch.int32).contiguous()
@@ -1143,7 +1232,7 @@ def sparse_raster(instance, obj_id, obj_batch, thetas):
 def occlusion_splat(flow, want_map=True, want_clip=False):
     """get_occlusion_map for [B,2,H,W] or, frame-batched, [B,2,T,H,W] flows -> ([B,1,(T,)H,W] map, clip_mask) ."""
     _dev(flow)
-    flow = _f(flow.detach())
+    flow = _as(flow.detach(), torch.float32)
     five = flow.dim() == 5
     if five:
         B, _, T, H, W = flow.shape
@@ -1167,16 +1256,18 @@ class _L1MeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, mask):
         _dev(a, b, mask)
-        a, b = _f(a), _f(b)
+        ctx.b_dtype = b.dtype
+        a = _f(a)
+        b = _as(b, a.dtype)
         assert a.shape == b.shape
         C, inner = 1, 1
         if mask is not None:
-            mask = _f(mask)
+            mask = _as(mask, torch.float32)
             assert mask.shape[0] == a.shape[0] and mask.shape[1] == 1 and mask.shape[2:] == a.shape[2:]
             C, inner = a.shape[1], a[0, 0].numel()
         out = torch.empty((), device=a.device, dtype=torch.float32)
         ws = torch.empty(1024, device=a.device, dtype=torch.float64)
-        _lib.check(_lib.lib().c2m_l1_mean_fwd(_p(a), _p(b), _p(mask), _p(out), a.numel(), C, inner, _p(ws), _stream()),
+        _lib.check(_lib.lib().c2m_l1_mean_fwd(_p(a), _p(b), _p(mask), _p(out), a.numel(), C, inner, _p(ws), _dt(a), _stream()),
                    "l1_mean")
         ctx.cfg = (C, inner)
         ctx.save_for_backward(a, b, mask)
@@ -1190,7 +1281,9 @@ class _L1MeanFn(torch.autograd.Function):
         gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
         g = _f(g.reshape(1).float())
         _lib.check(_lib.lib().c2m_l1_mean_bwd(_p(a), _p(b), _p(mask), _p(g), _p(ga), _p(gb), a.numel(), C, inner,
-                                              _stream()), "l1_mean_bwd")
+                                              _dt(a), _stream()), "l1_mean_bwd")
+        if gb is not None and gb.dtype != ctx.b_dtype:
+            gb = gb.to(ctx.b_dtype)
         return ga, gb, None
 
 
@@ -1203,7 +1296,8 @@ class _SsimFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
         _dev(x, y)
-        x, y = _f(x), _f(y)
+        ctx.x_dtype = x.dtype
+        x, y = _as(x, torch.float32), _as(y, torch.float32)
         N, C, H, W = x.shape
         out = torch.empty((), device=x.device, dtype=torch.float32)
         ws = torch.empty(1024, device=x.device, dtype=torch.float64)
@@ -1219,7 +1313,7 @@ class _SsimFn(torch.autograd.Function):
         coef = torch.empty(N * C * (H - 2) * (W - 2) * 3, device=x.device, dtype=torch.float32)
         _lib.check(_lib.lib().c2m_ssim_bwd(_p(x), _p(y), _p(_f(g.reshape(1).float())), _p(gx), _p(coef), N * C, H, W,
                                            _stream()), "ssim_bwd")
-        return gx, None
+        return gx if gx.dtype == ctx.x_dtype else gx.to(ctx.x_dtype), None
 
 
 def ssim_loss(x, y):
@@ -1235,5 +1329,5 @@ def norm_apply_eval(x, mean, invstd, gamma, beta, act=None):
     S = x.numel() // (N * C)
     y = torch.empty_like(x)
     _lib.check(_lib.lib().c2m_norm_apply(_p(x), _p(_f(mean)), _p(_f(invstd)), _p(gamma), _p(beta), None, _p(y), N, C, S, 1,
-                                         ACT[act], LRELU_SLOPE, _stream()), "norm_apply(eval)")
+                                         ACT[act], LRELU_SLOPE, _dt(x), _stream()), "norm_apply(eval)")
     return y

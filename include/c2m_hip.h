@@ -38,8 +38,11 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  *   24 NS (1, 2 or 4)   25 in_sc (channel stride)   26 splits (from c2m_conv_igemm_splits, or 1)
  *   27 slab_stride (elements between split-K slabs)   28 Cin 29 taps 30 tap groups per chunk 31 real groups (wgrad)
  *   32 x_bytes 33 dy_bytes (wgrad; buffer-load bounds, < 2 GiB)
- *   34 operand precision: 0 = fp32 (exact v_mfma_f32_32x32x2_f32), 1 = bf16 operands rounded RNE while staged, fp32
- *      accumulation (v_mfma_f32_32x32x16_bf16); tensors in memory are fp32 in both modes
+ *   34 operand precision: 0 = fp32 (exact v_mfma_f32_32x32x2_f32), 1 = bf16 operands, fp32 accumulation
+ *      (v_mfma_f32_32x32x16_bf16).  Element types in memory (the bf16 data path, BASELINE configs[2-4]): geom[90] X
+ *      (wgrad: X and dY), geom[91] Y / Y_interior -- 0 = fp32, 1 = bf16.  The bf16 kernels gather bf16 X ALWAYS (the host
+ *      casts an fp32 input once) and write bf16 or fp32 results; split-K slabs are fp32 (c2m_splitk_reduce's `dt` picks the
+ *      final type).  The fp32 kernels and the <= 4-output-channel vector-ALU kernels are fp32 in, fp32 out.
  *   36..51 two-target epilogue (reflect-pad dgrad, Y_interior != NULL): padded coordinate = o*ps + po per dim
  *      (36-38 ps, 39-41 po); outputs inside [lo, lo+ext) (42-44 lo, 45-47 ext) are stored to Y_interior with strides
  *      48 sn 49 sc 50 st 51 sh, the pad ring to Y; c2m_reflect_border_add then folds the ring.
@@ -50,10 +53,10 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
  * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
 int c2m_conv_igemm_splits(int M, int nk, int Npix);
-int c2m_conv_igemm(const float* A, const float* X, float* Y, float* Y_interior, const float* bias, const int* ktab,
+int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_interior, const float* bias, const int* ktab,
                    const int64_t* geom, int act, float slope, void* stream);
-int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long total, int splits, long chan_stride,
-                      int M, int act, float slope, void* stream);
+int c2m_splitk_reduce(const float* slab, void* out, const float* bias, long total, int splits, long chan_stride,
+                      int M, int act, float slope, int dt /* element type of out */, void* stream);
 
 /* dW[m][c][tap] (+ db[m]) = sum_pix dY[m][pix] * G(row,pix): rows in the same (chunk, tap group, slot, channel)
  * order as the forward K, plus one ones-row group (bias gradient), padded to c2m_conv_wgrad_rows(M, groups+1).
@@ -61,7 +64,7 @@ int c2m_splitk_reduce(const float* slab, float* out, const float* bias, long tot
  * writes dW in the native [Cout][Cin][taps] layout.  geom: 0 M, 1 J, 16 dy_sn, 17 dy_sc, 24 NS, 28..31 as above. */
 int c2m_conv_wgrad_splits(int M, int J, int Npix);
 int c2m_conv_wgrad_rows(int M, int ngroups);
-int c2m_conv_wgrad(const float* dY, const float* X, float* slab, float* dW, float* db, const int* jtab,
+int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW, float* db, const int* jtab,
                    const int64_t* geom, void* stream);
 
 /* Native conv weights ([Cout][Cin][kt][kh][kw]) -> the packed K order above, one launch; also the per-parity-class
@@ -109,41 +112,45 @@ int c2m_conv_wino_wgrad3d(const float* dY, const float* X, float* slab, float* d
 
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
-int c2m_reflect_border_add(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
-                           void* stream);
-int c2m_reflect_fold(const float* dXpad, float* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
-                     void* stream);
+int c2m_reflect_border_add(const void* dXpad, void* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
+                           int dt, void* stream);
+int c2m_reflect_fold(const void* dXpad, void* dX, long NC, int T, int H, int W, int pt, int ph, int pw,
+                     int dt, void* stream);
 
 /* ---- normalisation + activation (norm.hip) -----------------------------------------------------------------
  * BatchNorm2d/3d(train) / InstanceNorm2d / SPADE + LeakyReLU/ReLU:
  *   down_block.py:19-22,44-47  same_block.py:19-22,41-44,64-67  up_block.py:11-12  residual_block.py:20-28,56-70
  *   spade_block.py:68-77.   mode 0 = per (n,c) plane, 1 = per channel over N*S.                              */
+/* `dt` = element type of the ACTIVATION tensors (x, y, gy, dx, the SPADE maps gb / ggb): 0 fp32, 1 bf16 (csrc/dtype.h);
+ * statistics, affine parameters and their gradients are fp32 in either case, all arithmetic is fp32 in registers.      */
 long c2m_norm_workspace_floats(int N, int C, long S);
-int c2m_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                   float* workspace, int N, int C, long S, int mode, float eps, float momentum, void* stream);
-int c2m_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                   const float* gb, float* y, int N, int C, long S, int mode, int act, float slope, void* stream);
-int c2m_norm_bwd(const float* x, const float* gy, const float* mean, const float* invstd, const float* gamma,
-                 const float* beta, const float* gb, float* ggb, float* dgamma, float* dbeta, float* dx,
-                 float* workspace, int N, int C, long S, int mode, int act, float slope, void* stream);
-int c2m_act_bwd(const float* y, const float* gy, float* gx, long total, int act, float slope, void* stream);
+int c2m_norm_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                   float* workspace, int N, int C, long S, int mode, float eps, float momentum, int dt, void* stream);
+int c2m_norm_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const void* gb, void* y, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
+int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx,
+                 float* workspace, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
+int c2m_act_bwd(const void* y, const void* gy, void* gx, long total, int act, float slope, int dt, void* stream);
 
 /* ---- optical-flow warping / resampling (warp.hip) -----------------------------------------------------------
  * utils/ops.py:183-202 resample()/get_grid()/grid_sample() and its backward; callers generator.py:86,
  * motion_autoencoder.py:125 (fused "* occlusion"), losses.py:219, model.py:204,208.                          */
-int c2m_flow_warp_fwd(const float* img, const float* flow, const float* occ, float* out, int N, int C, int H, int W,
-                      void* stream);
+/* `dt` = element type of the image-side tensors (img, out, gout, gimg / in, out): 0 fp32, 1 bf16; flow, occlusion and the
+ * flow gradient are fp32 (coordinates are never rounded to bf16).                                                  */
+int c2m_flow_warp_fwd(const void* img, const float* flow, const float* occ, void* out, int N, int C, int H, int W,
+                      int dt, void* stream);
 /* backward of the above (ATen grid_sampler_2d_backward: a float-atomic scatter on GPUs).  Deterministic here: d(image) is
  * gathered through an inverted tap list built in `workspace`, d(flow) is summed in a fixed channel order; neither
  * output needs zero-initialisation and either may be NULL.                                                      */
 long c2m_flow_warp_bwd_workspace_bytes(int N, int C, int H, int W, int want_gimg, int want_gflow);
-int c2m_flow_warp_bwd(const float* img, const float* flow, const float* occ, const float* gout, float* gimg,
-                      float* gflow, int N, int C, int H, int W, void* workspace, void* stream);
+int c2m_flow_warp_bwd(const void* img, const float* flow, const float* occ, const void* gout, void* gimg,
+                      float* gflow, int N, int C, int H, int W, void* workspace, int dt, void* stream);
 /* F.interpolate(bilinear) (utils/utils.py:349 align_corners=True; motion_autoencoder.py:123, up_block.py:10).  */
-int c2m_resize_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
-                        double scale_factor, void* stream);
-int c2m_upsample2x_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
-int c2m_upsample2x_bwd(const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
+int c2m_resize_bilinear(const void* in, void* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
+                        double scale_factor, int dt, void* stream);
+int c2m_upsample2x_fwd(const void* in, void* out, long NC, int Hi, int Wi, int dt, void* stream);
+int c2m_upsample2x_bwd(const void* gout, void* gin, long NC, int Hi, int Wi, int dt, void* stream);
 /* torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), appearance_encoder/appearance_encoder.py:67-69.
  * boxes [K,5] = (batch, x1, y1, x2, y2) stay on the device; the backward gathers per feature pixel in a fixed order (no
  * float atomics, no zero-initialisation of gfeat [N,C,H,W]).                                                       */
@@ -152,8 +159,8 @@ int c2m_roi_align_fwd(const float* feat, const float* boxes, float* out, int K, 
 int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int N, int K, int C, int H, int W, int PH,
                       int PW, float spatial_scale, void* stream);
 /* VGG-19 max pools (layers/vgg.py, torchvision features 4/9/18/27).                                           */
-int c2m_maxpool2x2_fwd(const float* in, float* out, long NC, int Hi, int Wi, void* stream);
-int c2m_maxpool2x2_bwd(const float* in, const float* gout, float* gin, long NC, int Hi, int Wi, void* stream);
+int c2m_maxpool2x2_fwd(const void* in, void* out, long NC, int Hi, int Wi, int dt, void* stream);
+int c2m_maxpool2x2_bwd(const void* in, const void* gout, void* gin, long NC, int Hi, int Wi, int dt, void* stream);
 
 /* ---- FlowNet2 operators of the online target-flow path (flownet_ops.hip) -----------------------------
  * Replace the reference's CUDA extensions, forward only (the flow net runs frozen under no_grad, flow_net.py:32,66-67):
@@ -180,10 +187,10 @@ int c2m_occlusion_splat(const float* flow, long sb, long sc, long st, int B, int
 
 /* ---- loss reductions (losses.hip) ---------------------------------------------------------------------------
  * losses/losses.py:180-189 L1MaskedLoss (also :60-65 VGG L1, model.py:118-121 feature matching); :152-177 SSIM. */
-int c2m_l1_mean_fwd(const float* a, const float* b, const float* mask, float* out, long total, int C, long inner,
-                    void* workspace /* 8 KiB */, void* stream);
-int c2m_l1_mean_bwd(const float* a, const float* b, const float* mask, const float* gscale, float* ga, float* gb,
-                    long total, int C, long inner, void* stream);
+int c2m_l1_mean_fwd(const void* a, const void* b, const float* mask, float* out, long total, int C, long inner,
+                    void* workspace /* 8 KiB */, int dt /* a, b */, void* stream);
+int c2m_l1_mean_bwd(const void* a, const void* b, const float* mask, const float* gscale, void* ga, void* gb,
+                    long total, int C, long inner, int dt /* a, b, ga, gb */, void* stream);
 int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int W, void* workspace /* 8 KiB */,
                  void* stream);
 int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,
