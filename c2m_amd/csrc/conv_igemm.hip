@@ -22,6 +22,7 @@
 // Tiling: 256 threads = 4 waves, BK = 16, register-prefetched + double-buffered LDS, one barrier per K-step.
 #include "common.h"
 #include "dtype.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1527,6 +1528,160 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
     }
 }
 
+// ---- bf16 data path: weight gradient with 16-byte loads (round 3) -------------------------------------------------------
+// On bf16 NCHW tensors the pixel axis -- the K dimension of this GEMM -- is the contiguous one, so a lane can fetch EIGHT
+// consecutive pixels of a row with one 16-byte load and put them into the [row][pixel] LDS image with one ds_write_b128: no
+// transposition, no conversion.  conv_wgrad_kernel<BF> (lane = pixel) issues 64 two-byte loads + 64 ds_write_b16 per lane for
+// the 16 MFMAs of a 64-pixel step and is bound by exactly that; here the same step costs 8 loads + 8 LDS writes.
+// A wave-instruction covers 8 rows x 8 pixel groups (lane = rsub * 8 + grp).  X rows are (tap, channel) pairs read at the
+// tap's offset: with unit x stride the 8 input pixels of a group are contiguous, at a 2-byte-granular address (unaligned
+// 16-byte buffer loads are exact and full speed on gfx950: tools/micro/unaligned_b128.hip).  Only groups at a row end
+// reach into the padding (taps with dx = -1 / +1): those load the aligned neighbour group and shift by one element in
+// registers (v_alignbit_b32), the vacated element being 0 (zeros) or the mirrored pixel (reflect).  Rows / frames outside
+// the image are whole-group zeros or mirrored by address.  Eligibility (host): sw == 1, Wi == Wo, Wo % 8 == 0, |dx| <= 1.
+// Same row order, slab layout and reduction as conv_wgrad_kernel.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_wide_bf16_kernel(const WgradP p, const int ns) {
+    constexpr int BK = 64, LDH = BK + 8;
+    constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
+    constexpr int AROWS = BM / 4, BROWSW = BN / 4, AP = AROWS / 8, BP = BROWSW / 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) __bf16 hA[BM][LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[BN][LDH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const C2mBlock blk = c2m_xcd_block((unsigned)p.J / BN, (unsigned)(p.M + BM - 1) / BM, 0);
+    const int m0 = blk.y * BM, j0 = blk.x * BN;
+    const int split = blk.z;
+    const int pbeg = split * p.pix_per_split;
+    int pend = pbeg + p.pix_per_split; pend = pend < p.Npix ? pend : p.Npix;
+    const int grp = lane & 7, rsub = lane >> 3;
+    const int ck = 16 / ns;
+
+    // per-lane row constants (fixed over the K loop)
+    unsigned arow_off[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) arow_off[i] = (unsigned)((m0 + wave * AROWS + 8 * i + rsub) * (int)p.dy_sc) * 2u;
+    unsigned b_off[BP];                                      // channel offset of the row (bytes)
+    int b_dt[BP], b_dy[BP], b_dx[BP];
+    bool b_on[BP], b_ones[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int j = j0 + wave * BROWSW + 8 * i + rsub;     // < J by construction of the grid
+        const int4* __restrict__ jd = p.jtab + (long)(j >> 4) * (1 + ns);
+        const int4 hdr = jd[0];
+        const int s16 = j & 15, slot = s16 / ck, cc = s16 - slot * ck;
+        const int4 tp = jd[1 + slot];
+        b_ones[i] = hdr.y == -2 && s16 == 0;
+        b_on[i] = hdr.y > 0 && tp.w != 0;                    // a real (tap, channel) row; channels >= nvalid are never read back
+        b_off[i] = (unsigned)((hdr.x + cc * p.in_sc)) * 2u;
+        b_dt[i] = tp.x; b_dy[i] = tp.y; b_dx[i] = tp.z;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    u32x4 ra[AP], rb[BP];
+    int redge[BP];                                           // -1: the group starts one pixel left of the row, +1: ends one past it
+    auto issue = [&](int pk) {
+        const int pix = pk + 8 * grp;
+        const bool live = pix < pend;
+        int n, ot, oy, ox;
+        decompose_pix(live ? pix : pend - 8, p, n, ot, oy, ox);
+        const unsigned yvo = (unsigned)(n * (int)p.dy_sn + (ot * p.Ho + oy) * p.Wo + ox) * 2u;
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, live ? yvo + arow_off[i] : C2M_OOB, 0, 0));
+        const unsigned ximg = (unsigned)(n * (int)p.in_sn) * 2u;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            int it = p.is3d ? ot * p.st + b_dt[i] : 0, iy = oy * p.sh + b_dy[i];
+            const int ix0 = ox + b_dx[i];
+            bool ok = live && b_on[i];
+            if (p.reflect) {
+                if (p.is3d) { it = it < 0 ? -it : it; it = it >= p.Ti ? 2 * p.Ti - 2 - it : it; }
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            }
+            ok = ok && (unsigned)iy < (unsigned)p.Hi && (!p.is3d || (unsigned)it < (unsigned)p.Ti);
+            const int e = ix0 < 0 ? -1 : (ix0 + 8 > p.Wi ? 1 : 0);
+            redge[i] = ok ? e : 0;
+            const unsigned vo = ximg + b_off[i] + (unsigned)(it * (int)p.in_st + iy * (int)p.in_sh + (ix0 - e)) * 2u;
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? vo : C2M_OOB, 0, 0));
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<u32x4*>(&hA[wave * AROWS + 8 * i + rsub][8 * grp]) = ra[i];
+        bool any_edge = false;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) any_edge = any_edge || redge[i] != 0;
+        if (__any(any_edge)) {                               // wave-uniform: most K-steps of a wide map hold no row end
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const u32x4 v = rb[i];
+                // left end: (pad, x0 .. x6) from the aligned load x0 .. x7; pad = x1 (reflect) or 0
+                const unsigned padl = p.reflect ? v.x >> 16 : 0u;
+                const u32x4 L = {(v.x << 16) | padl, __builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                 __builtin_amdgcn_alignbit(v.w, v.z, 16)};
+                // right end: (x[W-7] .. x[W-1], pad) from x[W-8] .. x[W-1]; pad = x[W-2] (reflect) or 0
+                const unsigned padr = p.reflect ? v.w << 16 : 0u;
+                const u32x4 R = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                 __builtin_amdgcn_alignbit(v.w, v.z, 16), (v.w >> 16) | padr};
+                rb[i] = redge[i] < 0 ? L : (redge[i] > 0 ? R : v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8 (bias gradient row)
+            *reinterpret_cast<u32x4*>(&hB[wave * BROWSW + 8 * i + rsub][8 * grp]) = b_ones[i] ? ones : rb[i];
+        }
+    };
+
+    issue(pbeg);
+    for (int pk = pbeg; pk < pend; pk += BK) {
+        __syncthreads();                                     // the previous step's fragment reads are done
+        stash();
+        __syncthreads();
+        if (pk + BK < pend) issue(pk + BK);                  // in flight during the MFMAs below
+#pragma unroll
+        for (int kq = 0; kq < BK / 16; ++kq) {
+            const int kc = kq * 16 + 8 * (lane >> 5);
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&hA[wm * TM + i * 32 + (lane & 31)][kc]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&hB[wn * TN + j * 32 + (lane & 31)][kc]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* __restrict__ out = p.slab + (long)split * p.M * p.J;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = j0 + wn * TN + j * 32 + (lane & 31);
+        if (col >= p.J) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) out[(long)row * p.J + col] = acc[i][j][r];
+            }
+    }
+}
+
 // dW[m][c*taps + tap] = sum_s slab[s][m][col(c, tap)] with the (chunk, tap group, slot, channel) row order;
 // db[m] = sum_s slab[s][m][ones_col]
 // One workgroup = 64 consecutive outputs in the slab's own (m, column) order x G groups of splits (G = 4, or 16 from 64
@@ -2210,6 +2365,17 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
     const bool bf16 = g[34] == 1;
     if (bf16 != xh) return (int)hipErrorInvalidValue;  // the bf16 kernel gathers bf16 tensors, the fp32 kernel fp32 ones
     const dim3 grid1(grid.x * grid.y * grid.z);       // 1-D launch, decoded XCD-aware in the kernel (common.h)
+    // g[92] = 1: the layer qualifies for the 16-byte-load form (host: unit x stride, Wi == Wo, Wo % 8 == 0, |tap dx| <= 1)
+    if (bf16 && g[92] == 1 && !getenv("C2M_WGRAD_NARROW")) {
+        if (p.sw != 1 || p.Wi != p.Wo || (p.Wo & 7) || p.Wi < 8 || (p.dy_sc & 7) || (p.pix_per_split & 63)) return (int)hipErrorInvalidValue;
+        if (p.M <= 32)      hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<32, 128, 1, 4>), grid1, dim3(256), 0, s, p, NS);
+        else if (p.M > 64)  hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<128, 128, 2, 2>), grid1, dim3(256), 0, s, p, NS);
+        else                hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<64, C2M_WG64_BN, 2, 2>), grid1, dim3(256), 0, s, p, NS);
+        int rcw = (int)hipGetLastError();
+        if (rcw) return rcw;
+        const long totalw = (long)p.M * (ngroups + 1) * 16;
+        return launch_wgrad_reduce(totalw, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Seff);
+    }
 #define C2M_WG(BMv, BNv, WGMv, WGNv)                                                                                  \
     do {                                                                                                              \
         if (bf16) {                                                                                                   \

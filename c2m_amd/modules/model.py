@@ -19,7 +19,7 @@ from .appearance_encoder.appearance_encoder import AppearanceEncoder
 from .motion_estimator.dense_motion import DenseMotionNetwork
 from .generator.generator import OcclusionAwareGenerator
 from .discriminator import discriminator
-from .layers.common import fold_time, unfold_time
+from .layers.common import fold_time, unfold_time, deferred_batch_counters
 
 
 def get_norm_layer(norm_type='instance'):
@@ -150,6 +150,10 @@ class GeneratorFullModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------ training forward
     def forward(self, data_batch):
+        with deferred_batch_counters():          # the BatchNorm step counters: one multi-tensor add per forward
+            return self._forward(data_batch)
+
+    def _forward(self, data_batch):
         tp = self.train_params
         t_in = tp["num_input_frames"]
         v = self._resize_inputs(data_batch.get)

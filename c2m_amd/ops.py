@@ -474,6 +474,10 @@ class _ConvPlan:
         self.wg_geom[[0, 1, 16, 17]] = (Cout, self.J, Cout * osp, osp)
         self.wg_geom[[28, 29, 30, 31]] = (Cin, taps, ntg, nk)
         self.wg_geom[33] = 4 * N * Cout * osp
+        # bf16 data path: the 16-byte-load weight-gradient kernel (conv_wgrad_wide_bf16_kernel) takes layers whose 8-pixel
+        # groups stay inside an input row up to one pad pixel: unit x stride, same-width output, |tap dx| <= 1
+        self.wg_geom[92] = int(bf16 and sw == 1 and Wi == Wo and Wo % 8 == 0 and Wi >= 8 and kw in (1, 3)
+                               and pw == (kw - 1) // 2 and osp % 8 == 0)
         self.wg_splits = L.c2m_conv_wgrad_splits(Cout, self.J, N * osp)
         # ---- dgrad: one launch per stride-parity class
         Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)
