@@ -2434,8 +2434,20 @@ __global__ void reflect_fold_kernel(const T* __restrict__ dXp, T* __restrict__ d
 // W % 4 == 0: a thread owns four consecutive x.  Their direct sources are four consecutive floats of the padded row (one
 // 4-byte aligned 16-byte load); mirrored x sources exist only for elements within `pad` of a border and are added per
 // element.  Same per-element summation order as the scalar kernel ((t, y) sources outer, x sources inner).
-__global__ void reflect_fold_vec_kernel(const float* __restrict__ dXp, float* __restrict__ dX, const FoldP f) {
+__device__ __forceinline__ f32x4 fold_ld4u(const float* __restrict__ p) {      // 4-byte aligned 16-byte load
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    return *reinterpret_cast<const f32x4u*>(p);
+}
+__device__ __forceinline__ f32x4 fold_ld4u(const bf16_t* __restrict__ p) {     // 2-byte aligned 8-byte load (unaligned access mode)
+    uint2 r;
+    __builtin_memcpy(&r, p, 8);
+    const f32x4 v = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u)};
+    return v;
+}
+
+template <class T>
+__global__ void reflect_fold_vec_kernel(const T* __restrict__ dXp, T* __restrict__ dX, const FoldP f) {
     typedef float f32x4a __attribute__((ext_vector_type(4)));
     const int Tp = f.T + 2 * f.pt, Hp = f.H + 2 * f.ph, Wp = f.W + 2 * f.pw;
     const int W4 = f.W >> 2;
@@ -2446,24 +2458,24 @@ __global__ void reflect_fold_vec_kernel(const float* __restrict__ dXp, float* __
         const int t = (int)(r % f.T); const long nc = r / f.T;
         int st[3], sy[3];
         const int nt = fold_sources(t, f.T, f.pt, st), ny = fold_sources(y, f.H, f.ph, sy);
-        const float* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
+        const T* __restrict__ base = dXp + nc * (long)Tp * Hp * Wp;
         const bool xband = f.pw > 0 && (x0 <= f.pw || x0 + 3 >= f.W - 1 - f.pw);     // some element has mirrored x sources
         f32x4a acc = {0.f, 0.f, 0.f, 0.f};
         for (int a = 0; a < nt; ++a)
             for (int b = 0; b < ny; ++b) {
-                const float* __restrict__ row = base + ((long)st[a] * Hp + sy[b]) * Wp;
-                f32x4a v = *reinterpret_cast<const f32x4u*>(row + x0 + f.pw);
+                const T* __restrict__ row = base + ((long)st[a] * Hp + sy[b]) * Wp;
+                f32x4a v = fold_ld4u(row + x0 + f.pw);
                 if (xband) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         int sx[3];
                         const int nx = fold_sources(x0 + e, f.W, f.pw, sx);
-                        for (int c = 1; c < nx; ++c) v[e] += row[sx[c]];
+                        for (int c = 1; c < nx; ++c) v[e] += c2m_ld(row, sx[c]);
                     }
                 }
                 acc += v;
             }
-        *reinterpret_cast<f32x4a*>(dX + i4 * 4) = acc;
+        c2m_st4(dX + i4 * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
@@ -2564,11 +2576,14 @@ C2M_API int c2m_reflect_fold(const void* dXpad, void* dX, long NC, int T_, int H
     C2M_ENTER();
     FoldP f{T_, H, W, pt, ph, pw, NC * (long)T_ * H * W};
     if (f.total <= 0) return 0;
-    if (dt == C2M_BF16)
+    if (dt == C2M_BF16 && (W & 3) == 0 && ((uintptr_t)dX & 7) == 0)
+        hipLaunchKernelGGL(reflect_fold_vec_kernel<bf16_t>, dim3(c2m_grid(f.total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dXpad, (bf16_t*)dX, f);
+    else if (dt == C2M_BF16)
         hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dXpad, (bf16_t*)dX, f);
     else if ((W & 3) == 0 && ((uintptr_t)dX & 15) == 0)
-        hipLaunchKernelGGL(reflect_fold_vec_kernel, dim3(c2m_grid(f.total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(reflect_fold_vec_kernel<float>, dim3(c2m_grid(f.total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dXpad, (float*)dX, f);
     else
         hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(c2m_grid(f.total, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -27,6 +27,18 @@ __device__ __forceinline__ void c2m_st4(bf16_t* __restrict__ p, float4 v) {
     const bf16x4_t q = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
     *reinterpret_cast<bf16x4_t*>(p) = q;
 }
+// two consecutive elements (8 B of fp32 / 4 B of bf16, aligned to that)
+__device__ __forceinline__ float2 c2m_ld2(const float* __restrict__ p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 c2m_ld2(const bf16_t* __restrict__ p) {
+    const unsigned r = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u));
+}
+__device__ __forceinline__ void c2m_st2(float* __restrict__ p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void c2m_st2(bf16_t* __restrict__ p, float2 v) {
+    typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t q = {(bf16_t)v.x, (bf16_t)v.y};
+    *reinterpret_cast<bf16x2_t*>(p) = q;
+}
 // alignment (bytes) a pointer needs for c2m_ld4 / c2m_st4
 template <class T> struct C2mVec4 { static constexpr uintptr_t mask = 4 * sizeof(T) - 1; };
 

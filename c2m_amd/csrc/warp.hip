@@ -451,25 +451,27 @@ C2M_API int c2m_resize_bilinear(const void* in, void* out, long NC, int Hi, int 
 
 // x2 upsample (align_corners=False; up_block.py:10): one thread per INPUT pixel writes its 2x2 outputs as two 8-byte
 // stores; the arithmetic is the generic kernel's expression with the same lerp_src weights -> bit-identical results.
-template <typename I>
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long NC, int Hi, int Wi) {
+template <typename I, class T = float>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, long NC, int Hi, int Wi) {
     const int Wo = 2 * Wi;
     const I total = (I)(NC * Hi * Wi);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int x = (int)(i % (I)Wi); const I r = i / (I)Wi;
         const int y = (int)(r % (I)Hi); const I nc = r / (I)Hi;
-        const float* __restrict__ p = in + (long)nc * Hi * Wi;
-        float* __restrict__ o = out + (long)nc * 4 * Hi * Wi + (long)(2 * y) * Wo + 2 * x;
+        const T* __restrict__ p = in + (long)nc * Hi * Wi;
+        T* __restrict__ o = out + (long)nc * 4 * Hi * Wi + (long)(2 * y) * Wo + 2 * x;
         const Lerp lx0 = lerp_src(2 * x, Wi, 0.5f, false), lx1 = lerp_src(2 * x + 1, Wi, 0.5f, false);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const Lerp ly = lerp_src(2 * y + a, Hi, 0.5f, false);
-            const float* __restrict__ r0 = p + ly.i0 * Wi;
-            const float* __restrict__ r1 = p + ly.i1 * Wi;
+            const T* __restrict__ r0 = p + ly.i0 * Wi;
+            const T* __restrict__ r1 = p + ly.i1 * Wi;
+            const float a00 = c2m_ld(r0, lx0.i0), a01 = c2m_ld(r0, lx0.i1), a10 = c2m_ld(r1, lx0.i0), a11 = c2m_ld(r1, lx0.i1);
+            const float b00 = c2m_ld(r0, lx1.i0), b01 = c2m_ld(r0, lx1.i1), b10 = c2m_ld(r1, lx1.i0), b11 = c2m_ld(r1, lx1.i1);
             float2 v;
-            v.x = ly.l0 * (lx0.l0 * r0[lx0.i0] + lx0.l1 * r0[lx0.i1]) + ly.l1 * (lx0.l0 * r1[lx0.i0] + lx0.l1 * r1[lx0.i1]);
-            v.y = ly.l0 * (lx1.l0 * r0[lx1.i0] + lx1.l1 * r0[lx1.i1]) + ly.l1 * (lx1.l0 * r1[lx1.i0] + lx1.l1 * r1[lx1.i1]);
-            *reinterpret_cast<float2*>(o + (long)a * Wo) = v;
+            v.x = ly.l0 * (lx0.l0 * a00 + lx0.l1 * a01) + ly.l1 * (lx0.l0 * a10 + lx0.l1 * a11);
+            v.y = ly.l0 * (lx1.l0 * b00 + lx1.l1 * b01) + ly.l1 * (lx1.l0 * b10 + lx1.l1 * b11);
+            c2m_st2(o + (long)a * Wo, v);
         }
     }
 }
@@ -550,8 +552,8 @@ __global__ void upsample2x_bwd_pair_kernel(const float* __restrict__ gout, float
 // elements are stored as 0 and carry weight 0).
 // UB_TX = 64 (two outputs per lane) for wide maps, 32 (one per lane) for the 32- and 48-wide ones.
 constexpr int UB_TY = 8, UB_LR = 2 * UB_TY + 2;
-template <int UB_TX>
-__global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* __restrict__ gout, float* __restrict__ gin,
+template <int UB_TX, class T = float>
+__global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const T* __restrict__ gout, T* __restrict__ gin,
                                                                   int Hi, int Wi) {
     constexpr int UB_LC = 2 * UB_TX + 2, UB_LS = UB_LC + 2;
     __shared__ __attribute__((aligned(8))) float tile[UB_LR][UB_LS];
@@ -562,11 +564,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* _
     const int ty = tb % tiles_y; const unsigned nc = tb / tiles_y;
     const int y0 = ty * UB_TY, x0 = tx * UB_TX;
     const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
-    const float* __restrict__ g = gout + (long)nc * Ho * Wo;
+    const T* __restrict__ g = gout + (long)nc * Ho * Wo;
     for (int e = threadIdx.x; e < UB_LR * UB_LC; e += 256) {
         const int r = e / UB_LC, c = e - r * UB_LC;
         const int gy = gy0 + r, gx = gx0 + c;
-        tile[r][c] = ((unsigned)gy < (unsigned)Ho && (unsigned)gx < (unsigned)Wo) ? g[gy * Wo + gx] : 0.0f;
+        tile[r][c] = ((unsigned)gy < (unsigned)Ho && (unsigned)gx < (unsigned)Wo) ? c2m_ld(g, gy * Wo + gx) : 0.0f;
     }
     __syncthreads();
     const int ly = threadIdx.x >> 5, l = threadIdx.x & 31;
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const float* _
             row += wx[0] * v0.x; row += wx[1] * v0.y; row += wx[2] * v1.x; row += wx[3] * v1.y;
             acc += wy[a] * row;
         }
-        gin[((long)nc * Hi + y) * Wi + x] = acc;
+        c2m_st(gin, ((long)nc * Hi + y) * Wi + x, acc);
     }
 }
 
@@ -607,9 +609,13 @@ C2M_API int c2m_upsample2x_fwd(const void* in_, void* out_, long NC, int Hi, int
     C2M_ENTER();
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
-    // bf16 activations: the generic bilinear kernel (same lerp_src weights) on 2-byte elements
-    if (dt == C2M_BF16 || (((uintptr_t)out_) & 7) != 0)
-        return resize_bilinear_launch(in_, out_, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, dt, stream);
+    if ((((uintptr_t)out_) & 7) != 0) return resize_bilinear_launch(in_, out_, NC, Hi, Wi, 2 * Hi, 2 * Wi, 0, 2.0, dt, stream);
+    if (dt == C2M_BF16) {                  // same kernel on 2-byte elements: 4-byte stores of output pixel pairs
+        const dim3 grid(c2m_grid(total, 256));
+        if (total * 4 < (1L << 31)) hipLaunchKernelGGL((upsample2x_fwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (bf16_t*)out_, NC, Hi, Wi);
+        else hipLaunchKernelGGL((upsample2x_fwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (bf16_t*)out_, NC, Hi, Wi);
+        return (int)hipGetLastError();
+    }
     const float* in = (const float*)in_; float* out = (float*)out_;
     C2M_IDX_DISPATCH(total * 4, upsample2x_fwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, out, NC, Hi, Wi);
     return (int)hipGetLastError();
@@ -620,6 +626,15 @@ C2M_API int c2m_upsample2x_bwd(const void* gout_, void* gin_, long NC, int Hi, i
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     if (dt == C2M_BF16) {
+        if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31)) {            // LDS-tiled form (fp32 window in LDS)
+            const int tx = Wi >= 64 ? 64 : 32;
+            const long tiles = (long)c2m_cdiv(Wi, tx) * c2m_cdiv(Hi, UB_TY) * NC;
+            if (tiles < (1L << 31)) {
+                if (tx == 64) hipLaunchKernelGGL((upsample2x_bwd_tile_kernel<64, bf16_t>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, Hi, Wi);
+                else hipLaunchKernelGGL((upsample2x_bwd_tile_kernel<32, bf16_t>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, Hi, Wi);
+                return (int)hipGetLastError();
+            }
+        }
         const dim3 grid(c2m_grid(total, 256));
         if (total * 4 < (1L << 31)) hipLaunchKernelGGL((upsample2x_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
         else hipLaunchKernelGGL((upsample2x_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
@@ -700,23 +715,23 @@ C2M_API int c2m_maxpool2x2_fwd(const void* in_, void* out_, long NC, int Hi, int
 
 // even sizes, 8-byte aligned tensors: one thread per 2x2 window (every input is read once: a thread per input pixel reads
 // each window four times), two 8-byte loads + one gradient, two 8-byte stores
-template <typename I>
-__global__ void maxpool2_bwd_win_kernel(const float* __restrict__ in, const float* __restrict__ gout,
-                                        float* __restrict__ gin, long NC, int Hi, int Wi) {
+template <typename I, class T = float>
+__global__ void maxpool2_bwd_win_kernel(const T* __restrict__ in, const T* __restrict__ gout,
+                                        T* __restrict__ gin, long NC, int Hi, int Wi) {
     const int Ho = Hi / 2, Wo = Wi / 2;
     const I total = (I)(NC * Ho * Wo);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
         const int ox = (int)(i % (I)Wo); const I r = i / (I)Wo;
         const int oy = (int)(r % (I)Ho); const I nc = r / (I)Ho;
         const long base = (long)nc * Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
-        const float2 a = *reinterpret_cast<const float2*>(in + base), b = *reinterpret_cast<const float2*>(in + base + Wi);
+        const float2 a = c2m_ld2(in + base), b = c2m_ld2(in + base + Wi);
         const float v[4] = {a.x, a.y, b.x, b.y};
         int arg = 0; float m = v[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
-        const float g = gout[i];
-        *reinterpret_cast<float2*>(gin + base) = make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f);
-        *reinterpret_cast<float2*>(gin + base + Wi) = make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f);
+        const float g = c2m_ld(gout, (long)i);
+        c2m_st2(gin + base, make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f));
+        c2m_st2(gin + base + Wi, make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f));
     }
 }
 
@@ -725,6 +740,11 @@ C2M_API int c2m_maxpool2x2_bwd(const void* in_, const void* gout_, void* gin_, l
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     if (dt == C2M_BF16) {
+        if ((Hi & 1) == 0 && (Wi & 1) == 0 && ((((uintptr_t)in_) | ((uintptr_t)gin_)) & 3) == 0 && total < (1L << 31)) {
+            hipLaunchKernelGGL((maxpool2_bwd_win_kernel<unsigned, bf16_t>), dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+            return (int)hipGetLastError();
+        }
         const dim3 grid(c2m_grid(total, 256));
         if (total < (1L << 31)) hipLaunchKernelGGL((maxpool2_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
         else hipLaunchKernelGGL((maxpool2_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);

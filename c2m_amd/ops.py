@@ -251,8 +251,12 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
         return False
     fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
     if C < 128:
-        return M <= 64 and fill <= 1.2
-    return fill <= 1.15 or (fill <= 1.4 and C >= 256)
+        return (M <= 64 or _PATCH_SMALLC) and fill <= 1.2
+    return fill <= _PATCH_FILL[0] or (fill <= _PATCH_FILL[1] and C >= 256)
+
+
+_PATCH_FILL = tuple(float(v) for v in os.environ.get("C2M_PATCH_FILL", "1.15,1.4").split(","))     # tuning knobs (A/B runs)
+_PATCH_SMALLC = os.environ.get("C2M_PATCH_SMALLC", "0") == "1"
 
 
 def _pack_bf16_patch(w, M, C, s_m, s_c):
@@ -264,10 +268,22 @@ def _pack_bf16_patch(w, M, C, s_m, s_c):
     return out
 
 
-def _patch_splits(L, M, C, npix):
+_BF16_SPLIT_DIV = float(os.environ.get("C2M_BF16_SPLIT_DIV", "4"))      # bf16 kernels: a quarter of the fp32 rule's K splits (A/B on configs[2,3], graph mode: 1 -> 60.0 / 93.7 ms, 2 -> 58.4 / 92.5, 4 -> 58.0 / 91.2, no splits -> 65.4 / 98.2)
+
+
+def _splits(L, M, nk, npix, bf16):
+    """c2m_conv_igemm_splits, optionally thinned out for the bf16 kernels (every split still owns >= 1 K-step)."""
+    S = L.c2m_conv_igemm_splits(M, nk, npix)
+    if bf16 and _BF16_SPLIT_DIV != 1 and S > 1:
+        S = max(1, int(S / _BF16_SPLIT_DIV))
+        S = _cdiv(nk, _cdiv(nk, S))
+    return S
+
+
+def _patch_splits(L, M, C, npix, bf16=False):
     """Split-K count for the patch kernel: whole 16-channel chunks per split, every split non-empty."""
     nch = _cdiv(C, 16)
-    s0 = L.c2m_conv_igemm_splits(M, nch * 9, npix)
+    s0 = _splits(L, M, nch * 9, npix, bf16)
     return _cdiv(nch, _cdiv(nch, s0))
 
 
@@ -451,8 +467,8 @@ class _ConvPlan:
         nk = nch * ntg
         self.nk = nk
         self.fwd_tab = torch.from_numpy(tab.reshape(-1)).to(device)
-        self.fwd_splits = _patch_splits(L, Cout, Cin, N * osp) if self.fwd_patch else \
-            L.c2m_conv_igemm_splits(Cout, nk, N * osp)
+        self.fwd_splits = _patch_splits(L, Cout, Cin, N * osp, bf16) if self.fwd_patch else \
+            _splits(L, Cout, nk, N * osp, bf16)
         self.fwd_geom = _geom(M=Cout, nk=nk, lda=nk * 16, Npix=N * osp, To=To, Ho=Ho, Wo=Wo, Ti=Ti, Hi=Hi, Wi=Wi, st=st,
                               sh=sh, sw=sw, in_sn=Cin * in_sc, in_st=Hi * Wi, in_sh=Wi, out_sn=Cout * osp, out_sc=osp,
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
@@ -537,14 +553,14 @@ class _ConvPlan:
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
-        S = min(L.c2m_conv_igemm_splits(dM, c["nk"], c["npix"]) for c in self.classes) if self.classes else 1
+        S = min(_splits(L, dM, c["nk"], c["npix"], bf16) for c in self.classes) if self.classes else 1
         if S > 1:
             for c in self.classes:
                 if _cdiv(c["nk"], _cdiv(c["nk"], S)) != S:
                     S = 1
                     break
         if any(c["patch"] for c in self.classes):        # stride-1 3x3: a single class
-            S = _patch_splits(L, dM, Cout, self.classes[0]["npix"])
+            S = _patch_splits(L, dM, Cout, self.classes[0]["npix"], bf16)
         self.dgrad_splits = S
         for c in self.classes:
             c["geom"][26] = S
@@ -575,7 +591,7 @@ class _ConvPlan:
                 runs.append((i, j + 1))
                 i = j + 1
             nk0, ck0 = cl[0]["nk"], cl[0]["ck"]
-            SB = min(L.c2m_conv_igemm_splits(Cin, nk0, cl[a]["npix"] * (b - a)) for a, b in runs)
+            SB = min(_splits(L, Cin, nk0, cl[a]["npix"] * (b - a), bf16) for a, b in runs)
             groups = []
             for a, b in runs:
                 g = cl[a]["geom"].copy()
