@@ -1209,7 +1209,10 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
             // bf16: A = c2m_pack_weights_bf16_patch output, lda = its padded row count (a multiple of 128); X is bf16
             if (p.lda % 128 != 0 || p.lda < p.M || !p.xh) return (int)hipErrorInvalidValue;
             if (p.M <= 32)      return launch_patch_bf16<32>(p, splits, s);
-            else if (p.M <= 64) return launch_patch_bf16<64>(p, splits, s);
+            // 64-row tiles keep TWO workgroups on a CU (59 KB of LDS each; the 128-row tile's 95 KB leave one wave per SIMD
+            // with nothing to hide its stalls): +5...14 % up to 256 input channels, -5 % at 512 (the weight image is
+            // streamed twice as often) -- A/B on one box, bf16 tensors
+            else if (p.M <= 64 || p.cin <= 256) return launch_patch_bf16<64>(p, splits, s);
             else                return launch_patch_bf16<128>(p, splits, s);
         }
         if (p.xh || p.yh) return (int)hipErrorInvalidValue;        // the fp32 kernels read and write fp32
@@ -2433,7 +2436,9 @@ __global__ void reflect_fold_kernel(const T* __restrict__ dXp, T* __restrict__ d
 
 // W % 4 == 0: a thread owns four consecutive x.  Their direct sources are four consecutive floats of the padded row (one
 // 4-byte aligned 16-byte load); mirrored x sources exist only for elements within `pad` of a border and are added per
-// element.  Same per-element summation order as the scalar kernel ((t, y) sources outer, x sources inner).
+// element.  Summation order: per (t, y) source pair the direct x term plus its mirrored x terms first, then the pairs in
+// (t, y) order -- NOT the scalar kernel's strictly sequential order (the mirrored x terms are added to the direct term
+// before the pair joins the running sum), so the two kernels agree to rounding, not bit for bit; either is deterministic.
 __device__ __forceinline__ f32x4 fold_ld4u(const float* __restrict__ p) {      // 4-byte aligned 16-byte load
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     return *reinterpret_cast<const f32x4u*>(p);

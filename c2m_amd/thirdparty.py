@@ -27,11 +27,29 @@ class GATv2Conv(nn.Module):
         self.lin_l.bias.data.zero_()
         self.lin_r.bias.data.zero_()
 
+    DENSE_MAX_NODES = 64
+
     def forward(self, x, edge_index):
         N, H, C = x.shape[0], self.heads, self.out_channels
         xl = self.lin_l(x).view(N, H, C)
         xr = self.lin_r(x).view(N, H, C)
         src, dst = edge_index[0].long(), edge_index[1].long()
+        if N <= self.DENSE_MAX_NODES:
+            # Dense form for the few-object scene graphs of the path (3 objects x batch): logits for ALL ordered pairs, the
+            # edge MULTIPLICITY matrix A[i, j] (edges j -> i) as the mask and weight of the softmax.  No scatter / index_add
+            # (whose float atomics are the one run-to-run nondeterminism torch would add to the step), and a formulation
+            # independent of the edge-list restatement the oracle uses (oracle/thirdparty.py::gatv2_conv), so comparing the two
+            # is a real check of both.
+            A = torch.zeros(N, N, dtype=x.dtype, device=x.device).index_put_((dst, src), torch.ones_like(dst, dtype=x.dtype),
+                                                                            accumulate=True)
+            e = F.leaky_relu(xl.unsqueeze(0) + xr.unsqueeze(1), self.negative_slope)          # [i, j, H, C]
+            logit = (e * self.att).sum(-1)                                                     # [i, j, H]
+            logit = logit.masked_fill(A.unsqueeze(-1) == 0, float("-inf"))
+            mx = logit.max(dim=1).values
+            mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)                        # nodes without incoming edges
+            ex = (logit - mx.unsqueeze(1).detach()).exp() * A.unsqueeze(-1)
+            alpha = ex / (ex.sum(1, keepdim=True) + 1e-16)
+            return torch.einsum("ijh,jhc->ihc", alpha, xl).mean(dim=1) + self.bias
         e = F.leaky_relu(xl[src] + xr[dst], self.negative_slope)
         logit = (e * self.att).sum(-1)
         mx = torch.full((N, H), float("-inf"), dtype=x.dtype, device=x.device)

@@ -113,6 +113,7 @@ def test_bench_baseline_config_presets(config, expect):
         assert frag in r["config"]["workload"], (frag, r["config"]["workload"])
     assert r["config"]["global_batch"] == (2 if config == 4 else 1)
     assert r["roofline"]["peak"] == 2500.0 and 0 < r["roofline"]["frac"] < 1
+    assert r["hip_graph"] is False and r["hip_graph_replay"]["value"] > 0       # the eager line + the replay side object
 
 
 def test_bench_graph_side_measurement():

@@ -131,3 +131,27 @@ def test_stream_batch_windows_stack_along_the_batch_axis():
     assert torch.equal(b["video"], ref["video"]) and torch.equal(b["instance_mask"], ref["instance_mask"])
     with pytest.raises(ValueError):
         make_stream_batch(streams=1, windows=0)
+
+
+def test_gatv2_dense_product_form_vs_edge_list_oracle_form():
+    """torch_geometric's GATv2Conv is an absent third-party dependency (parity unpinned).  The product
+    computes it in DENSE form (all ordered pairs, edge-multiplicity mask), the oracle over the EDGE LIST (scatter /
+    index_add) -- two independent restatements of the published layer that must agree, including duplicate edges, nodes
+    without incoming edges and gradients.  Above DENSE_MAX_NODES the product switches to the edge-list form."""
+    import torch
+    from c2m_amd.thirdparty import GATv2Conv
+    from oracle import thirdparty as TP
+    torch.manual_seed(0)
+    m = GATv2Conv(16, 8, heads=4, concat=False, add_self_loops=False)
+    ei = torch.tensor([[0, 1, 2, 0, 2, 1, 4, 5, 5], [1, 0, 0, 2, 1, 2, 5, 4, 4]])        # 5 -> 4 twice; nodes 3, 6 isolated
+    for n in (7, 70):                                                                    # dense form / edge-list form
+        x = torch.randn(n, 16)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y = m(xa, ei)
+        yr = TP.gatv2_conv(xb, ei, m.lin_l.weight, m.lin_l.bias, m.lin_r.weight, m.lin_r.bias, m.att, m.bias, 4)
+        torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-6)
+        assert torch.equal(y[3], m.bias) and torch.equal(y[6], m.bias)                   # no incoming edge: bias only
+        go = torch.randn_like(y)
+        (y * go).sum().backward()
+        (yr * go).sum().backward()
+        torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6)
