@@ -142,8 +142,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// BF = true: bf16 operands (activations and weights are rounded to bf16, RNE, while they are staged into LDS; fp32
-// accumulation, fp32 output) on v_mfma_f32_32x32x16_bf16 -- one instruction per 16-deep K-step and 32x32 tile.  LDS
+// BF = true: bf16 operands (X is a bf16 tensor in HBM -- the bf16 data path --, weights are rounded to bf16, RNE, while they
+// are staged into LDS; fp32 accumulation; fp32 or bf16 output, ConvP::yh) on v_mfma_f32_32x32x16_bf16 -- one instruction per 16-deep K-step and 32x32 tile.  LDS
 // image [k half h][row][8 bf16] (16 B per lane, conflict-free ds_read_b128).  The K slot order inside a step is
 // permuted identically for A and B so that each gathering thread's values are contiguous: slot(k) = (k % BROWS) *
 // BPASS + k / BROWS (a sum over k does not care about the order).
@@ -754,9 +754,11 @@ static int launch_patch(const ConvP& p, int splits, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------ LDS patch, bf16
 // The bf16 form of the kernel above (BASELINE configs[2-4]): v_mfma_f32_32x32x16_bf16 is 16x the fp32 MFMA rate, so the
 // kernel lives or dies by operand delivery.  Per 16-channel chunk
-//   * the (8+2) x 34 input patch is gathered ONCE from the fp32 NCHW activations (24 coalesced dword loads per thread),
-//     rounded to bf16 (RNE) in registers and stored as [pixel][16 channels] (32 B per pixel): the B fragment of ANY of the
-//     9 taps is then one conflict-free ds_read_b128 at a pixel offset -- no per-tap gather, no per-tap conversion;
+//   * the (8+2) x 34 input patch is gathered ONCE from the bf16 NCHW activations (24 coalesced 2-byte loads per thread: on
+//     NCHW the 8 channels a lane needs sit 2*H*W bytes apart; a 16-byte-load + 4x8 register-transpose form of this fetch was
+//     measured 5-25 % SLOWER, profiles/r03_ab_bf16_patch_wide_vs_narrow.txt), packed in registers and stored as
+//     [pixel][16 channels] (32 B per pixel): the B fragment of ANY of the 9 taps is then one conflict-free ds_read_b128 at a
+//     pixel offset -- no per-tap gather, no conversion;
 //   * the weights arrive pre-packed in bf16 as [chunk][tap][row][16 channels] (c2m_pack_weights_bf16_patch): one 16-byte
 //     load + one ds_write_b128 per 512 MACs of MFMA work, and the A fragment is one ds_read_b128;
 //   * one barrier per chunk (72 MFMAs per wave at BM = 128), next chunk's global loads in flight during the MFMAs.

@@ -122,3 +122,15 @@ def test_bench_graph_side_measurement():
     assert out.returncode == 0, out.stderr[-2000:]
     r = _json_line(out.stdout)
     assert r["hip_graph"] is True and r["value"] > 0 and "roofline" not in r
+
+
+def test_bench_graph_replay_with_the_reducer():
+    """HIP-graph replay of zero_grad + forward + backward with the gradient reducer in place: gradients accumulate into the
+    reducer's static buckets inside the graph, the RCCL all-reduces run eagerly after each replay (1 rank, forced)."""
+    out = subprocess.run([sys.executable, "bench.py", "--force-reducer", "--graph", "--batch", "1", "--steps", "2", "--warmup", "2",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    r = _json_line(out.stdout)
+    assert r["hip_graph"] is True and r["rccl_ranks"] == 1 and r["value"] > 0 and r["allreduce_buckets"] >= 10
+    assert r["allreduce_op"] == "avg"
