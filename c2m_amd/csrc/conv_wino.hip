@@ -48,6 +48,10 @@ struct WinoP {
     // nkt = 0: plain 2-D layer (To = 1, in_st = out_st = 0).
     int To, Ti, nkt, cin, toff, treflect;
     long in_st, out_st;
+    // region shape in Winograd tiles (GEN kernels): th x tw <= 32 tiles, (2 th + 2)(2 tw + 2) <= 192 patch positions.
+    // The fixed 4 x 8 shape (8 x 16 outputs) leaves e.g. the 18 x 34 padded domain of a 16 x 32 reflect data gradient at
+    // 53 % fill (9 regions); 3 x 10 tiles cover it with 6.
+    int th, tw;
 };
 
 constexpr int WR = 8, WC = 16;               // output region rows / cols
@@ -75,7 +79,10 @@ static __device__ __forceinline__ f32x2 pk_b(f32x2 p, f32x2 q) {       // (x2 - 
 // 1 (<= 32 output channels -- the full-resolution heads and the data gradients of 32-channel inputs: 64 accumulators, three
 // workgroups per CU; half the MFMAs per chunk at the same transform / DMA work, which still beats the direct kernels' 32-row
 // tiles).  U is packed per 64 rows either way; MT = 1 reads the fragments of rows 0..31 (every second 1 KB record).
-template <int MT>
+// GEN = region shape from p.th x p.tw instead of the fixed 4 x 8 tiles: same K loop (V is [xi][k][32 tile columns] either
+// way; columns >= th*tw are idle), runtime patch width, and an epilogue that owns one tile row (2 pixels) per thread
+// instead of 4 consecutive pixels (8-byte instead of 16-byte stores).
+template <int MT, bool GEN>
 __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const WinoP p) {
     constexpr int NU = 4 * MT;                       // U fragment records (16 bytes per lane) per wave and chunk
     __shared__ float sP[3][PBUF];                   // input patch [k][PH][PW] (+pad), filled by LDS-DMA two chunks ahead
@@ -86,7 +93,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int regions_x = (p.Wo + WC - 1) / WC, regions_y = (p.Ho + WR - 1) / WR;
+    const int TH = GEN ? p.th : WR / 2, TW = GEN ? p.tw : WC / 2;       // tiles per region
+    const int pw_ = GEN ? 2 * TW + 2 : PW, ppos = GEN ? (2 * TH + 2) * pw_ : PPOS;
+    const int regions_x = (p.Wo + 2 * TW - 1) / (2 * TW), regions_y = (p.Ho + 2 * TH - 1) / (2 * TH);
     // XCD-aware work order: workgroups are handed to the 8 XCDs round-robin by linear id, each XCD has its own L2.  Work
     // item w = region * mtiles + mt (the m-tiles of a region read the SAME input patch, neighbouring regions share its
     // halo); XCD x gets the contiguous range of items [x*q + min(x, r), ...) so those re-reads hit its L2 instead of
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     }
     const int rx = rb % regions_x; rb /= regions_x;
     const int ry = rb % regions_y; const int img = rb / regions_y;
-    const int oy0 = ry * WR, ox0 = rx * WC;
+    const int oy0 = ry * 2 * TH, ox0 = rx * 2 * TW;
 
     // ---- patch addresses of this thread (fixed over the K loop).  A chunk's patch is 8 channels x 3 DMA rows of 64 patch
     // positions (180 used); wave w fetches the three rows of channels 2w and 2w + 1, so a lane owns the three positions
@@ -113,13 +122,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
 #pragma unroll
     for (int sg = 0; sg < 3; ++sg) {
         const int pos = sg * 64 + lane;
-        const int r = pos / PW, c = pos % PW;
+        const int r = pos / pw_, c = pos % pw_;
         int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + c;
         if (p.reflect) {
             iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
             ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
         }
-        const bool ok = pos < PPOS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const bool ok = pos < ppos && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         pvo[sg] = ok ? img_byte + (unsigned)(iy * p.in_sh + ix) * 4u : WINO_OOB;
     }
     // The LDS-DMA is issued through inline asm and TWO chunks ahead (three patch buffers).  hipcc makes the first MFMA
@@ -181,14 +190,17 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
 
     // input-transform role of this thread: tile n (ty, tx), channel k of the chunk
     const int tn = tid & 31, tk = tid >> 5;
-    const int ty = tn >> 3, tx = tn & 7;
-    const int pbase = tk * PCS + (2 * ty) * PW + 2 * tx;
+    int ty = tn >> 3, tx = tn & 7;
+    if (GEN) {                                       // idle tile columns transform tile 0 again (result never stored)
+        ty = tn < TH * TW ? tn / TW : 0; tx = tn < TH * TW ? tn % TW : 0;
+    }
+    const int pbase = tk * PCS + (2 * ty) * pw_ + 2 * tx;
     // V = B^T d B of this thread's (channel, tile) from patch buffer `pb` into V buffer `vb`
     auto read_d = [&](int pb, float (&d)[4][4]) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) d[a][b] = sP[pb][pbase + a * PW + b];
+            for (int b = 0; b < 4; ++b) d[a][b] = sP[pb][pbase + a * pw_ + b];
     };
     auto transform_store = [&](const float (&d)[4][4], int vb) {
         float x[4][4];
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) dr[a][h] = *reinterpret_cast<const f32x2*>(&sP[pnext][pbase + a * PW + 2 * h]);
+            for (int h = 0; h < 2; ++h) dr[a][h] = *reinterpret_cast<const f32x2*>(&sP[pnext][pbase + a * pw_ + 2 * h]);
         float* __restrict__ vdst = sV + (cur ^ 1) * (16 * CKW * 32) + tk * 32 + tn;
         f32x2 xr_[4][2], o01, o23;
         auto row = [&](int i) {
@@ -351,7 +363,71 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // The stores are 4-byte aligned vector stores, so any row length / stride works: a group that crosses the end of its
     // row -- padded domains are W + 2 wide -- is stored per pixel.  (The first version of this path required W % 4 == 0 and
     // left every reflect data gradient on a dword-store form.)
-    {
+    if constexpr (GEN) {
+        // one tile row (2 pixels) per thread: tile column n = tid & 31, row parity, 4 channel groups
+        const int en = tid & 31, rp = (tid >> 5) & 1, cg = tid >> 6;
+        const int ety = en < TH * TW ? en / TW : 0, etx = en < TH * TW ? en % TW : 0;
+        const int oy = oy0 + 2 * ety + rp, ox = ox0 + 2 * etx;
+        const bool inb = en < TH * TW && oy < p.Ho && ox < p.Wo;
+        const bool top = rp == 0;
+        int mode = 0;                                 // 0: Y (vector), 1: Y2 (vector), 2: mixed (per pixel)
+        float* __restrict__ yb0 = p.Y + p.out_off + (long)smp * p.out_sn + (long)frm * p.out_st + (long)oy * p.out_sh + ox;
+        long cs0 = p.out_sc;
+        float* __restrict__ yb1 = yb0;
+        long cs1 = cs0;
+        const int yi = oy - p.lo_y, xi = ox - p.lo_x;
+        if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y) {
+            const bool in0 = (unsigned)xi < (unsigned)p.ext_x, in1 = (unsigned)(xi + 1) < (unsigned)p.ext_x;
+            yb1 = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
+            cs1 = p.y2_sc;
+            mode = (in0 && in1) ? 1 : ((in0 || in1) ? 2 : 0);
+        }
+        if (ox + 1 >= p.Wo && mode == 0) mode = 2;
+        const int ro = top ? 0 : 3 * 16 * 32;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = hf * 8 + rr;
+                    const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                    sR[0 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[0][mi][r] + acc[1][mi][r]) + acc[2][mi][r];
+                    sR[1 * QS + (wave * 16 + rowl) * 32 + (lane & 31)] = (acc[1][mi][r] - acc[2][mi][r]) - acc[3][mi][r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int co = cg + 4 * it;
+                    const int cout = m0 + mi * 32 + hf * 16 + co;
+                    float v[2];
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const float* __restrict__ rr_ = sR + dx * QS + co * 32 + en;
+                        const float r1 = rr_[1 * 16 * 32], r2 = rr_[2 * 16 * 32], rx = rr_[ro];
+                        v[dx] = top ? (rx + r1) + r2 : (r1 - r2) - rx;
+                    }
+                    if (inb && cout < p.M) {
+                        const float bb = p.bias ? p.bias[cout] : 0.f;
+                        v[0] = c2m_act(v[0] + bb, p.act, p.slope); v[1] = c2m_act(v[1] + bb, p.act, p.slope);
+                        if (mode == 2) {
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                if (ox + dx >= p.Wo) continue;
+                                if ((unsigned)(xi + dx) < (unsigned)p.ext_x) yb1[(long)cout * cs1 + dx] = v[dx];
+                                else yb0[(long)cout * cs0 + dx] = v[dx];
+                            }
+                        } else {
+                            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                            const f32x2u vv = {v[0], v[1]};
+                            *reinterpret_cast<f32x2u*>((mode ? yb1 : yb0) + (long)cout * (mode ? cs1 : cs0)) = vv;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
         const int e4 = tid & 3, ey = (tid >> 2) & 7, cg = tid >> 5;
         const int oy = oy0 + ey, ox = ox0 + 4 * e4;
         const bool inb = oy < p.Ho && ox < p.Wo;
@@ -486,6 +562,32 @@ C2M_API int c2m_wino_filter_transform(const float* w, float* upack, int Cout, in
     return (int)hipGetLastError();
 }
 
+// Region shape of a launch over an Ho x Wo output domain: the fixed 4 x 8 tiles (8 x 16 outputs; 16-byte-store epilogue)
+// unless another th x tw (th*tw <= 32 tile columns of the MFMA, (2th+2)(2tw+2) <= 192 = three DMA rows of patch positions)
+// covers the domain with at most 0.9x the regions.  Ties: the wider shape (longer contiguous rows).
+// C2M_WINO_SHAPE=fixed pins 4 x 8 (A/B).
+static void wino_region_shape(int Ho, int Wo, int* th, int* tw) {
+    static const bool fixed = [] { const char* e = getenv("C2M_WINO_SHAPE"); return e && e[0] == 'f'; }();
+    *th = WR / 2; *tw = WC / 2;
+    const long base = (long)c2m_cdiv(Ho, WR) * c2m_cdiv(Wo, WC);
+    if (fixed) return;
+    long best = base;
+    for (int a = 1; a <= 16; ++a)
+        for (int b = 1; b <= 32; ++b) {
+            if (a * b > 32 || (2 * a + 2) * (2 * b + 2) > PCS) continue;
+            const long r = (long)c2m_cdiv(Ho, 2 * a) * c2m_cdiv(Wo, 2 * b);
+            if (10 * r > 9 * base) continue;
+            if (r < best || (r == best && b > *tw)) { best = r; *th = a; *tw = b; }
+        }
+}
+
+// regions per image the launch will use (callers: eligibility / fill estimates)
+C2M_API int c2m_wino_regions(int Ho, int Wo) {
+    int th, tw;
+    wino_region_shape(Ho, Wo, &th, &tw);
+    return c2m_cdiv(Ho, 2 * th) * c2m_cdiv(Wo, 2 * tw);
+}
+
 // geom[] (int64): 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0, 9 reflect, 10 in_sn, 11 in_sc, 12 in_sh,
 //                 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes; with Y_interior: 18 y2_sn, 19 y2_sc, 20 y2_sh,
 //                 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x
@@ -518,11 +620,18 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;
     p.nchunks = c2m_cdiv(p.K, CKW);
     p.mtiles = c2m_cdiv(p.M, 64);
-    const long regions = (long)p.nimg * c2m_cdiv(p.Ho, WR) * c2m_cdiv(p.Wo, WC);
+    wino_region_shape(p.Ho, p.Wo, &p.th, &p.tw);
+    const bool gen = !(p.th == WR / 2 && p.tw == WC / 2);
+    const long regions = (long)p.nimg * c2m_cdiv(p.Ho, 2 * p.th) * c2m_cdiv(p.Wo, 2 * p.tw);
     if (regions * p.mtiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(regions * p.mtiles));
-    if (p.M <= 32) hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else           hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (gen) {
+        if (p.M <= 32) hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else           hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (p.M <= 32) hipLaunchKernelGGL((conv_wino_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else           hipLaunchKernelGGL((conv_wino_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     return (int)hipGetLastError();
 }
 

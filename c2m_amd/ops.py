@@ -183,6 +183,20 @@ class ConvProfiler:
         return sorted(rows, key=lambda r: -r[2])
 
 
+# weight gradient on a side stream: "auto" = bf16 data path only.  Measured (gpurun_out/r03/side*.json -> DESIGN 5.3): bf16
+# configs[3] 65.5 -> 64.7 ms eager, 57.4 -> 55.8 ms as a graph replay; fp32 configs[1] 74.5 -> 75.3 ms (the fp32 Winograd
+# kernels fill the CUs' LDS and registers by themselves, a second resident kernel only adds L2 pressure)
+_WGRAD_SIDE = os.environ.get("C2M_WGRAD_STREAM", "auto")
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _timed(kind, flops, fn, tag=(), nbytes=0):
     prof = ConvProfiler.active
     if prof is None:
@@ -395,8 +409,9 @@ class _ConvPlan:
                     and N * (Hi // 2) * (Wi // 16) >= 8 * max(1, (768 if wrows == 32 else 512) // wg_tiles))):
                 self.wino_wgrad = True
                 self.wino_wg_splits = L.c2m_wino_wgrad_splits(Cout, Cin, N, Hi, Wi)
-            regions = N * _cdiv(Ho, 8) * _cdiv(Wo, 16)
-            fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
+            # regions per image: 8 x 16 outputs, or the th x tw tile shape c2m_conv_wino picks for a badly fitting domain
+            regions = N * L.c2m_wino_regions(Ho, Wo)
+            fit = N * Ho * Wo >= 0.8 * regions * 128
             # rows: 64-row tiles need >= 48 output channels to pay; 17..32 run on the 32-row variant (MT = 1, three
             # workgroups per CU), which beats the direct kernels' 32-row tiles
             rows_ok = lambda m: m >= 48 or 17 <= m <= 32
@@ -408,8 +423,8 @@ class _ConvPlan:
             # data gradient: zero padding -> the unpadded domain; reflect padding -> the padded (H+2)x(W+2) domain with
             # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
-            dregions = N * _cdiv(Hd, 8) * _cdiv(Wd, 16)
-            dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
+            dregions = N * L.c2m_wino_regions(Hd, Wd)
+            dfit = N * Hd * Wd >= _WINO_DFIT * dregions * 128
             if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
                                                    dregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS)):
                 self.wino_dgrad = True
@@ -425,8 +440,8 @@ class _ConvPlan:
         self.wino3d = self.wino_wgrad3d = False
         if not bf16 and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and (pt, ph, pw) == (1, 1, 1):
             rows_ok = lambda m: m >= 48 or 17 <= m <= 32
-            regions = N * To * _cdiv(Ho, 8) * _cdiv(Wo, 16)
-            fit = Ho * Wo >= 0.8 * _cdiv(Ho, 8) * 8 * _cdiv(Wo, 16) * 16
+            regions = N * To * L.c2m_wino_regions(Ho, Wo)
+            fit = N * To * Ho * Wo >= 0.8 * regions * 128
             hw_i, hw_o = Hi * Wi, Ho * Wo
             if _WINO == "force" or (_WINO == "auto" and fit and 3 * Cin >= 32 and rows_ok(Cout) and
                                     regions * _cdiv(Cout, 64) >= _WINO_MIN_WGS):
@@ -436,8 +451,8 @@ class _ConvPlan:
                      0, 4 * N * Cin * in_sc], To=To, in_st=hw_i, out_st=hw_o, cin=Cin, nkt=3, toff=-1, Ti=Ti,
                     treflect=int(reflect))
             Td, Hd, Wd = (Ti + 2, Hi + 2, Wi + 2) if reflect else (Ti, Hi, Wi)
-            dregions = N * Td * _cdiv(Hd, 8) * _cdiv(Wd, 16)
-            dfit = Hd * Wd >= _WINO_DFIT * _cdiv(Hd, 8) * 8 * _cdiv(Wd, 16) * 16
+            dregions = N * Td * L.c2m_wino_regions(Hd, Wd)
+            dfit = N * Td * Hd * Wd >= _WINO_DFIT * dregions * 128
             if _WINO == "force" or (_WINO == "auto" and dfit and 3 * Cout >= 32 and rows_ok(dM) and
                                     dregions * _cdiv(dM, 64) >= _WINO_MIN_WGS):
                 self.wino_dgrad = self.wino3d = True
@@ -874,8 +889,35 @@ class _ConvFn(torch.autograd.Function):
             gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        # The weight gradient and the data gradient of a layer are independent: with both wanted, the weight gradient (and its
+        # split reductions) is issued on a side stream and joined at the end of this node, so the two launches share the chip
+        # -- the tail of one (e.g. 1440 workgroups on 512 slots) is filled by the other and the ~10 us reductions disappear
+        # behind MFMA kernels.  Fork / join are events, so a HIP-graph capture records the same parallel branches.
+        side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and pl.bf16)
+        side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
+        if side is not None:
+            main = torch.cuda.current_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy)
+            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype)
+            main.wait_stream(side)
+            for t in (gw, gb):
+                if t is not None:
+                    t.record_stream(main)       # allocated in the side stream's pool, consumed (and freed) on the main stream
+            return gx, gw, gb, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype)
+        if need_w:
+            gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy)
+        return gx, gw, gb, None, None, None, None, None, None
+
+    @staticmethod
+    def _wgrad(ctx, pl, x, w, gy):
+        L = _lib.lib()
+        N, Cin, Cout = pl.dims[0:3]
+        gw = gb = None
         if not pl.bf16:
             gy = _as(gy, torch.float32)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:
@@ -921,7 +963,7 @@ class _ConvFn(torch.autograd.Function):
                                                        _gp(pl.wg_geom), _stream()), tag,
                               xg.element_size() * (gyw.numel() + xg.numel()) + 4 * w.numel()), "conv_wgrad")
             gb = gb_t if ctx.has_bias else None
-        return gx, gw, gb, None, None, None, None, None, None
+        return gw, gb
 
 
 def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgrad_channels=None, slope=LRELU_SLOPE):

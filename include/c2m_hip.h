@@ -94,6 +94,9 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
  *         otherwise frames outside [0, Ti) are zeros).  geom[] always holds 33 entries.                                */
 long c2m_wino_upack_floats(int M, int K);
 int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
+/* Regions (workgroup tiles of <= 32 Winograd tiles) per image c2m_conv_wino uses for an Ho x Wo output domain: 8 x 16
+ * outputs, or another th x tw tile shape when that covers a badly fitting domain (18 x 34: 9 -> 6) with <= 0.9x as many. */
+int c2m_wino_regions(int Ho, int Wo);
 int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
                   const int64_t* geom, int act, float slope, void* stream);
 

@@ -127,6 +127,12 @@ WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3
     ((3, 40, 6, 48), 70, (3, 3), 1, 1, "zeros"),         # Winograd wgrad: partial channel tiles, 27 regions over 2 splits
     ((2, 130, 16, 32), 136, (3, 3), 1, 1, "reflect"),    # Winograd wgrad: every region touches the border, 3 x 3 channel tiles
     ((2, 64, 32, 64), 96, (3, 3), 1, 1, "reflect"),      # Winograd wgrad: several chunks per workgroup, reflected patches
+    # region shapes other than 8 x 16 (c2m_wino_regions): 18 x 34 padded domain as 3 x 10 tiles on the 32-row kernel
+    # (data gradient of 32 input channels), an 18 x 34 forward domain with <= 32 output channels, 34 x 66 as 6 x 5 tiles
+    ((2, 32, 16, 32), 64, (3, 3), 1, 1, "reflect"),
+    ((2, 40, 18, 34), 32, (3, 3), 1, 1, "zeros"),
+    ((1, 64, 32, 64), 64, (3, 3), 1, 1, "reflect"),
+    ((2, 24, 3, 8, 16), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),    # 3x3x3 data gradient over 10 x 18 frames: 2 regions of 3 x 9 tiles
 ]
 
 

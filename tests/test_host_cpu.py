@@ -35,6 +35,11 @@ def test_abi_host_side_queries(library):
     assert library.c2m_norm_workspace_floats(2, 3, 100000) == 2 * 3 * 13 * 4
     assert library.c2m_occlusion_splat_workspace_bytes(2, 4, 8) == 2 * 32 * 4 * 3 + 2 * 32 * 4 * 4 * 2
     assert library.c2m_flow_warp_bwd_workspace_bytes(40, 512, 4, 8, 1, 1) >= 40 * 32 * 44
+    # Winograd regions per image: 8 x 16 outputs where that fits, another tile shape where it covers the domain with fewer
+    assert library.c2m_wino_regions(16, 32) == 4 and library.c2m_wino_regions(128, 256) == 256
+    assert library.c2m_wino_regions(18, 34) == 6 and library.c2m_wino_regions(10, 18) == 2
+    for h, w in [(1, 1), (9, 11), (34, 66), (66, 130), (130, 258)]:
+        assert 1 <= library.c2m_wino_regions(h, w) <= -(-h // 8) * -(-w // 16)
 
 
 @pytest.mark.parametrize("name", names("e2e_"))
