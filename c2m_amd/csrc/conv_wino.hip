@@ -52,6 +52,12 @@ struct WinoP {
     // The fixed 4 x 8 shape (8 x 16 outputs) leaves e.g. the 18 x 34 padded domain of a 16 x 32 reflect data gradient at
     // 53 % fill (9 regions); 3 x 10 tiles cover it with 6.
     int th, tw;
+    // Temporal reflect padding folded into the data gradient of a 3x3x3 layer (ptab != 0; needs cin % 8 == 0): output frame
+    // t of the UNPADDED time axis sums over its (source frame, time tap) pairs -- 3 in the middle, 2 at the ends, + 1 for the
+    // frames the pad frames mirror onto -- instead of launching over T + 2 frames and folding (T = 5: 7 frames, 29 % of the
+    // launch for two frames that only feed a fold).  ptab[t][11] = {npairs, (source frame, U block) x 5}; cpk = cin / 8.
+    const int* ptab;
+    int cpk;
 };
 
 constexpr int WR = 8, WC = 16;               // output region rows / cols
@@ -118,6 +124,16 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // the other resident workgroup costs 2.5 ... 5 matrix-pipe cycles (tools/micro/mfma_issue.hip).
     const int smp = p.nkt ? img / p.To : img, frm = p.nkt ? img - smp * p.To : 0;       // sample, frame (scalar)
     const unsigned img_byte = (unsigned)(smp * (int)p.in_sn) * 4u;
+    int nchunks = p.nchunks;
+    int pr_src[5] = {0, 0, 0, 0, 0}, pr_ub[5] = {0, 0, 0, 0, 0}, npairs = 0;
+    if (p.ptab) {
+        const int* __restrict__ pt = p.ptab + frm * 11;
+        npairs = pt[0];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { pr_src[j] = pt[1 + 2 * j]; pr_ub[j] = pt[2 + 2 * j]; }
+        nchunks = npairs * p.cpk;
+    }
+    auto sel5 = [&](const int (&a)[5], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : (j == 3 ? a[3] : a[4]))); };
     unsigned pvo[3];
 #pragma unroll
     for (int sg = 0; sg < 3; ++sg) {
@@ -148,8 +164,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // scalar offset and liveness, prepared ONCE per chunk by dma_prepare.  3x3x3 layers keep (time tap, channel) of channel
     // chunk*8 + 2*wave as running counters -- the first version divided by cin in every one of the six DMA rows, ~40 scalar
     // instructions each in front of the next MFMA pair (the 3-D layers ran 20-25 % below 2-D layers of the same depth).
-    int d_kt = 0, d_ci = 2 * wave;                      // channel 2*wave of chunk 0
+    int d_kt = 0, d_ci = 2 * wave;                      // channel 2*wave of chunk 0 (pair mode: d_kt = pair index)
     if (p.nkt) { d_kt = d_ci / p.cin; d_ci -= d_kt * p.cin; }
+    int u_j = 0, u_r = 0;                               // pair mode: (pair, chunk within the pair) of the next U fetch
     int d_soff[2]; bool d_on[2];
     auto dma_prepare = [&](int chunk, bool live) {
 #pragma unroll
@@ -157,7 +174,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
             const int ch = chunk * CKW + 2 * wave + h;
             bool on = live && ch < p.K;
             int soff = ch * p.in_sc * 4;
-            if (p.nkt) {                                // (time tap, channel): all scalar arithmetic
+            if (p.ptab) {                               // (pair, channel); cin % 8 == 0: a chunk never straddles pairs
+                const int tt = sel5(pr_src, d_kt);
+                on = live && d_kt < npairs;
+                soff = (int)(((long)(d_ci + h) * p.in_sc + (long)tt * p.in_st) * 4);
+            } else if (p.nkt) {                         // (time tap, channel): all scalar arithmetic
                 int kt = d_kt, ci = d_ci + h;
                 if (ci >= p.cin) { ci -= p.cin; ++kt; }   // h = 1 wraps at most once (cin >= 1)
                 int tt = frm + kt + p.toff;
@@ -193,7 +214,16 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     const u32x4 urs = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     const unsigned uvo = (unsigned)((((mt * 4 + wave) * 8 * 64) + lane) * 16);
     f32x4 ua[NU];
+    // U chunk of the next K chunk in fetch order (chunks are fetched in order 0, 1, 2, ...): the chunk itself, or in pair mode
+    // block pr_ub[pair] of cpk chunks
+    auto next_uchunk = [&](int chunk) {
+        if (!p.ptab) return chunk;
+        const int uc = sel5(pr_ub, u_j) * p.cpk + u_r;
+        if (++u_r == p.cpk) { u_r = 0; ++u_j; }
+        return uc;
+    };
     auto load_u = [&](int chunk) {
+        chunk = next_uchunk(chunk);
         const f32x4* __restrict__ q = reinterpret_cast<const f32x4*>(ubase + chunk * ustride);
 #pragma unroll
         for (int i = 0; i < NU; ++i) ua[i] = q[(i * 2 / MT) * 64];
@@ -242,12 +272,12 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
 
     // ---- prologue: patches 0 and 1 by DMA, U(0), V(0)
     load_patch(0, 0);
-    if (p.nchunks > 1) load_patch(1, 1);
+    if (nchunks > 1) load_patch(1, 1);
     load_u(0);
 #pragma unroll
     for (int i = 0; i < NU; ++i) asm volatile("" :: "v"(ua[i]));   // retire these loads HERE: a load pending at loop entry
                                                        // costs a vmcnt(0) in front of the first MFMA of EVERY iteration
-    if (p.nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
@@ -263,7 +293,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     // the next chunk is mixed into the remaining MFMAs.
     auto iteration = [&](const int chunk, f32x4 (&ucur)[NU], f32x4 (&unext)[NU]) {
         const int cur = chunk & 1;
-        const bool more = chunk + 1 < p.nchunks;
+        const bool more = chunk + 1 < nchunks;
         // patch(chunk + 1) (this wave's part) has landed: nothing younger is in flight at this point
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();       // V(chunk) complete; patch(chunk+1) complete; everyone is done with V(chunk-1) = buffer cur^1
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
         // U(chunk + 1) by buffer loads: one VGPR offset for all eight, the chunk in the scalar offset, i * 1 KB as the
         // immediate -- a global_load needs a 64-bit VALU add per address, and tools/micro/mfma_issue.hip prices a VALU
         // between MFMAs at 2.5 ... 5 MFMA-pipe cycles and a global load above a buffer load
-        const int usoff0 = (int)((more ? chunk + 1 : chunk) * ustride * 4), usoff1 = usoff0 + 4096;
+        const int usoff0 = (int)((more ? next_uchunk(chunk + 1) : 0) * ustride * 4), usoff1 = usoff0 + 4096;
         auto mfma_pair = [&](int g) {                  // g = kk * 4 + j
             const int kk = g >> 2, j = g & 3;
 #pragma unroll
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
         }
         // patch(chunk + 2) -- always issued, so the iteration is one basic block and the requests sit between MFMAs; past
         // the last chunk they carry zero records (the loads return 0 into a patch buffer nobody reads)
-        const bool pre = chunk + 2 < p.nchunks;
+        const bool pre = chunk + 2 < nchunks;
         const int dbuf = pnext == 2 ? 0 : pnext + 1;
         dma_prepare(chunk + 2, pre);
 #pragma unroll
@@ -361,11 +391,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
     };
     f32x4 ub[NU];
     int chunk = 0;
-    for (; chunk + 1 < p.nchunks; chunk += 2) {
+    for (; chunk + 1 < nchunks; chunk += 2) {
         iteration(chunk, ua, ub);
         iteration(chunk + 1, ub, ua);
     }
-    if (chunk < p.nchunks) iteration(chunk, ua, ub);
+    if (chunk < nchunks) iteration(chunk, ua, ub);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) DMAs of the last iterations must not outlive the block's LDS
     __syncthreads();
 
@@ -610,7 +640,7 @@ C2M_API int c2m_wino_regions(int Ho, int Wo) {
 
 // geom[] (int64): 0 M, 1 K, 2 images, 3 Hi, 4 Wi, 5 Ho, 6 Wo, 7 iy0, 8 ix0, 9 reflect, 10 in_sn, 11 in_sc, 12 in_sh,
 //                 13 out_sn, 14 out_sc, 15 out_sh, 16 out_off, 17 x_bytes; with Y_interior: 18 y2_sn, 19 y2_sc, 20 y2_sh,
-//                 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x
+//                 21 lo_y, 22 lo_x, 23 ext_y, 24 ext_x; 25..32 the 3x3x3 tail; 33 device pointer of the temporal pair table (or 0)
 C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
                           const int64_t* g, int act, float slope, void* stream) {
     C2M_ENTER();
@@ -630,9 +660,15 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.x_bytes = (unsigned)g[17];
     p.To = (int)g[25]; p.in_st = g[26]; p.out_st = g[27]; p.cin = (int)g[28]; p.nkt = (int)g[29]; p.toff = (int)g[30];
     p.Ti = (int)g[31]; p.treflect = (int)g[32];
+    p.ptab = (const int*)(uintptr_t)g[33]; p.cpk = 0;
     if (p.nkt) {
         if (Y_interior || p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
+        if (p.ptab) {
+            if (p.cin % CKW) return (int)hipErrorInvalidValue;
+            p.cpk = p.cin / CKW;
+        }
     } else {
+        if (p.ptab) return (int)hipErrorInvalidValue;
         p.To = 1; p.in_st = p.out_st = 0;
     }
     p.act = act; p.slope = slope;

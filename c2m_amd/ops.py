@@ -83,6 +83,7 @@ _conv_bf16 = False
 # 8x16 regions and still beats the gather kernel by 14-30 % (tools/run_conv.py A/B); the 10x18 domain (35 %) does not
 _WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
 _WINO_MIN_WGS = int(os.environ.get("C2M_WINO_MIN_WGS", "128"))   # smallest Winograd forward / dgrad grid: 160 workgroups of a 1536-deep layer still beat the gather kernel 1.5x
+_WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect data gradient over unpadded frames (A/B knob)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
 # the direct kernel, "off", "force" (tests: every eligible shape).
@@ -358,10 +359,30 @@ def _geom(**kw):
 
 def _wino_geom(head, To=0, in_st=0, out_st=0, cin=0, nkt=0, toff=0, Ti=0, treflect=0):
     """geom[] of c2m_conv_wino (include/c2m_hip.h): 33 entries; the tail describes the time taps of a 3x3x3 layer."""
-    g = np.zeros(33, dtype=np.int64)
+    g = np.zeros(34, dtype=np.int64)
     g[:len(head)] = head
     g[25:33] = (To, in_st, out_st, cin, nkt, toff, Ti, treflect)
     return g
+
+
+def _time_pair_table(T):
+    """Temporal reflect padding (pad 1, 3 taps) folded into the data gradient: output frame t of the unpadded axis sums dY
+    frame `to` through time tap kt for every (to, kt) with reflect(to + kt - 1) == t.  int32 [T][11] = {npairs, (to, U block =
+    2 - kt: the flipped tap order of the packed data-gradient weights) x 5} -- c2m_conv_wino geom[33]."""
+    tab = np.zeros((T, 11), dtype=np.int32)
+    for t in range(T):
+        pairs = []
+        for kt in range(3):
+            for to in range(T):
+                q = to + kt - 1
+                q = -q if q < 0 else (2 * T - 2 - q if q >= T else q)
+                if q == t:
+                    pairs.append((to, 2 - kt))
+        assert 2 <= len(pairs) <= 5
+        tab[t, 0] = len(pairs)
+        for j, (to, ub) in enumerate(pairs):
+            tab[t, 1 + 2 * j], tab[t, 2 + 2 * j] = to, ub
+    return tab
 
 
 class _ConvPlan:
@@ -437,7 +458,7 @@ class _ConvPlan:
         # temporal padding is a per-tap frame index (reflected, or a zero-record descriptor).  Data gradient: virtual
         # channels (flipped time tap, output channel) of dY over the padded (T+2, H+2, W+2) domain (reflect; then one
         # fold pass) or the unpadded one (zeros).
-        self.wino3d = self.wino_wgrad3d = False
+        self.wino3d = self.wino_wgrad3d = self.wino3d_pairs = False
         if not bf16 and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and (pt, ph, pw) == (1, 1, 1):
             rows_ok = lambda m: m >= 48 or 17 <= m <= 32
             regions = N * To * L.c2m_wino_regions(Ho, Wo)
@@ -457,9 +478,17 @@ class _ConvPlan:
                                     dregions * _cdiv(dM, 64) >= _WINO_MIN_WGS):
                 self.wino_dgrad = self.wino3d = True
                 o = -2 if reflect else -1
+                # reflect in time: launched over the Ti real frames with the pad frames' contributions as extra (frame, tap)
+                # pairs of the frames they mirror onto (kernel: WinoP::ptab) -- not over Ti + 2 frames + a fold in time
+                self.wino3d_pairs = bool(reflect and Cout % 8 == 0 and To == Ti and Ti >= 2 and _WINO_TPAIRS)
+                Tl = Ti if self.wino3d_pairs else Td
+                self.wino_dgrad_target = (N, Cin, Tl, Hd, Wd)
                 self.wino_dgrad_geom = _wino_geom(
-                    [dM, 3 * Cout, N * Td, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Td * Hd * Wd, Td * Hd * Wd, Wd,
-                     0, 4 * N * Cout * osp], To=Td, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
+                    [dM, 3 * Cout, N * Tl, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Tl * Hd * Wd, Tl * Hd * Wd, Wd,
+                     0, 4 * N * Cout * osp], To=Tl, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
+                if self.wino3d_pairs:
+                    self.wino_pair_tab = torch.from_numpy(_time_pair_table(Ti).reshape(-1)).to(device)
+                    self.wino_dgrad_geom[33] = self.wino_pair_tab.data_ptr()
             # weight gradient: the 2-D Winograd wgrad kernel over images (sample, frame) and virtual channels (kt, ci)
             wrows = 32 if Cout <= 32 else 64
             wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, wrows)
@@ -718,7 +747,7 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
         U = _packed(w, frozen_w, ("wino-dgrad3d", dM), lambda: _wino_filter(
             w[:, :dM].flip(2).permute(2, 0, 1, 3, 4).reshape(3 * Cout, dM, 3, 3).contiguous(), 3 * Cout, dM, 1))
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
-        tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
+        tgt = torch.empty(pl.wino_dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
         g3 = pl.wino_dgrad_geom
         npix = int(g3[2] * g3[5] * g3[6])
         tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
@@ -727,7 +756,8 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad 3-D")
         if pl.reflect:
             Ti, Hi, Wi = pl.dims[3:6]
-            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, 0, _stream()), "reflect fold 3-D")
+            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0 if pl.wino3d_pairs else 1, 1, 1, 0,
+                                          _stream()), "reflect fold 3-D")
         if dM < Cin:
             gx[:, dM:].zero_()
     elif pl.wino_dgrad:

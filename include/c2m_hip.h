@@ -91,7 +91,11 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
  *         as a 2-D Winograd over virtual channels (time tap kt, channel ci), image = (sample, frame): 25 To (frames per
  *         sample of the output), 26 in_st, 27 out_st (frame strides), 28 cin, 29 nkt (0 = 2-D layer, else 3: K = nkt*cin),
  *         30 toff (source frame = t + kt + toff), 31 Ti (source frames), 32 treflect (reflect the source frame index;
- *         otherwise frames outside [0, Ti) are zeros).  geom[] always holds 33 entries.                                */
+ *         otherwise frames outside [0, Ti) are zeros);
+ *         33 temporal pair table (device pointer as an integer, or 0): the data gradient of a 3x3x3 layer with reflect
+ *         padding in time, launched over the UNPADDED frames -- int32 ptab[To][11] = {npairs, (source frame of dY, U block
+ *         = flipped time tap) x 5}: output frame t sums the pairs (to, kt) with reflect(to + kt - 1) == t (needs cin % 8
+ *         == 0; toff / treflect are ignored).  geom[] always holds 34 entries.                                         */
 long c2m_wino_upack_floats(int M, int K);
 int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
 /* Regions (workgroup tiles of <= 32 Winograd tiles) per image c2m_conv_wino uses for an Ho x Wo output domain: 8 x 16

@@ -132,7 +132,9 @@ WINO_CASES = [c for c in CONV_CASES if len(c[0]) == 4 and c[2] == (3, 3) and c[3
     ((2, 32, 16, 32), 64, (3, 3), 1, 1, "reflect"),
     ((2, 40, 18, 34), 32, (3, 3), 1, 1, "zeros"),
     ((1, 64, 32, 64), 64, (3, 3), 1, 1, "reflect"),
-    ((2, 24, 3, 8, 16), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),    # 3x3x3 data gradient over 10 x 18 frames: 2 regions of 3 x 9 tiles
+    ((2, 24, 3, 8, 16), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),    # 3x3x3 data gradient over 10 x 18 frames: 2 regions of 3 x 9 tiles;
+                                                                             # T = 3: the middle frame sums 5 (frame, tap) pairs
+    ((1, 16, 2, 16, 32), 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),    # T = 2: both frames are mirror targets (3 pairs each)
 ]
 
 
