@@ -818,11 +818,27 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
     f32x4 gy[GY_UNITS], gx[GX_UNITS];
     float dbacc[GY_UNITS] = {};
     const bool want_db = nt == 0;                                   // workgroup-uniform
-    auto fetch = [&](int region) {
-        const int rx = region % regions_x; int t = region / regions_x;
-        const int ry = t % regions_y; const int img = t / regions_y;
+    // Regions are fetched strictly in order rbeg, rbeg + 1, ...: (rx, ry, frame, sample) of the next region are running
+    // counters (the first version decomposed the region index with three scalar divisions + a modulo in every chunk -- ~100
+    // scalar instructions in front of 16 MFMAs), and a region is always stashed before the next one is fetched, so the
+    // border flags the stash needs are those of the last fetch.
+    int f_rx, f_ry, f_frm, f_smp;
+    {
+        f_rx = rbeg % regions_x; const int t = rbeg / regions_x;
+        f_ry = t % regions_y; const int img = t / regions_y;
+        f_smp = img / p.T; f_frm = img - f_smp * p.T;                 // (sample, frame); T = 1 for the 2-D layers
+    }
+    bool s_left = false, s_right = false;
+    auto fetch = [&](int) {
+        const int rx = f_rx, ry = f_ry, smp = f_smp, frm = f_frm;
+        if (++f_rx == regions_x) {
+            f_rx = 0;
+            if (++f_ry == regions_y) {
+                f_ry = 0;
+                if (++f_frm == p.T) { f_frm = 0; ++f_smp; }
+            }
+        }
         const int oy0 = ry * GR, ox0 = rx * GC;
-        const int smp = img / p.T, frm = img - smp * p.T;             // (sample, frame); T = 1 for the 2-D layers
         const int ysoff = (int)(((long)smp * p.dy_sn + (long)frm * HW + (long)oy0 * p.W + ox0) * 4);
 #pragma unroll
         for (int i = 0; i < GY_UNITS; ++i)
@@ -830,6 +846,7 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
         const unsigned roff = (unsigned)(((long)smp * p.x_sn + (long)frm * HW + (long)oy0 * p.W + ox0) * 4);
         const bool top = ry == 0, bot = ry == regions_y - 1, left = rx == 0, right = rx == regions_x - 1; // wave-uniform
         const bool first = is3d && frm == 0, last = is3d && frm == p.T - 1;
+        s_left = left; s_right = right;
 #pragma unroll
         for (int i = 0; i < GX_UNITS; ++i) {
             unsigned vo = xbase[i] + roff;
@@ -849,9 +866,8 @@ __global__ __launch_bounds__(256, NI == 1 ? (MI == 1 ? 3 : 2) : 1) void conv_win
             gx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
         }
     };
-    auto stash = [&](int region, int buf) {
-        const int rx = region % regions_x;
-        const bool left = rx == 0, right = rx == regions_x - 1;                                            // wave-uniform
+    auto stash = [&](int, int buf) {
+        const bool left = s_left, right = s_right;                                                          // wave-uniform
 #pragma unroll
         for (int i = 0; i < GY_UNITS; ++i) {
             float* __restrict__ d = &pY[buf][ydst[i]];
