@@ -8,8 +8,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libc2m_hip.so")
 ARCH = "gfx950"
-# index/mask-path files pin the fp32 operation order: no implicit contraction there
-SOURCES = {"conv_igemm.hip": [], "conv_wino.hip": [], "norm.hip": [], "losses.hip": [], "optim.hip": ["-ffp-contract=off"],
+# index/mask-path files pin the fp32 operation order: no implicit contraction there.
+# conv_igemm.hip is built without the SLP vectoriser: with it conv_thin_wgrad_rows_kernel (accumulators packed into
+# v_pk_fma_f32 pairs) returned wrong partial sums -- in exactly those pairs -- whenever the bf16 gather kernel ran next to it on
+# another stream (tools/dbg_side_stream.py; bit-exact alone), and the packed form was the SLOWER one on the <= 4-row vector-ALU
+# kernels (7x7 head: weight gradient 0.49 -> 0.36 ms, forward 0.34 -> 0.27 ms; every MFMA kernel unchanged).
+SOURCES = {"conv_igemm.hip": ["-fno-slp-vectorize"], "conv_wino.hip": [], "norm.hip": [], "losses.hip": [], "optim.hip": ["-ffp-contract=off"],
            "data_prep.hip": ["-ffp-contract=off"],
            "warp.hip": ["-ffp-contract=off"], "motion_raster.hip": ["-ffp-contract=off"], "events.hip": [],
            "flownet_ops.hip": ["-ffp-contract=off"]}
