@@ -184,9 +184,12 @@ class ConvProfiler:
         return sorted(rows, key=lambda r: -r[2])
 
 
-# weight gradient on a side stream: "auto" = bf16 data path only.  Measured (gpurun_out/r03/side*.json -> DESIGN 5.3): bf16
-# configs[3] 65.5 -> 64.7 ms eager, 57.4 -> 55.8 ms as a graph replay; fp32 configs[1] 74.5 -> 75.3 ms (the fp32 Winograd
-# kernels fill the CUs' LDS and registers by themselves, a second resident kernel only adds L2 pressure)
+# weight gradient on a side stream: "auto" = bf16 data path AND inside a HIP-graph capture; "1" = bf16 and fp32, eager too; "0" off.
+# Measured: graph replays of the bf16 configurations 89.7 -> 86.7 ms (configs[2]), 159.4 -> 152.0 (configs[4]),
+# 55.5 -> 55.2 (configs[3]).  Eager: fork / join cost the host ~25 us per conv node (events, stream switch, record_stream), which a
+# host-bound eager step pays in full (configs[3] 62.0 -> 65.3 ms; configs[4], GPU-bound, 161.6 -> 155.1), and per-kernel HIP-event
+# times of overlapping launches are no kernel measurements any more -- so eager steps stay on one stream.  fp32 configs[1]:
+# 74.5 -> 75.3 ms (the fp32 Winograd kernels fill the CUs' LDS and registers by themselves).
 _WGRAD_SIDE = os.environ.get("C2M_WGRAD_STREAM", "auto")
 _side_streams = {}
 
@@ -924,7 +927,7 @@ class _ConvFn(torch.autograd.Function):
         # split reductions) is issued on a side stream and joined at the end of this node, so the two launches share the chip
         # -- the tail of one (e.g. 1440 workgroups on 512 slots) is filled by the other and the ~10 us reductions disappear
         # behind MFMA kernels.  Fork / join are events, so a HIP-graph capture records the same parallel branches.
-        side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and pl.bf16)
+        side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and pl.bf16 and torch.cuda.is_current_stream_capturing())
         side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
         if side is not None:
             main = torch.cuda.current_stream(x.device)
