@@ -160,3 +160,27 @@ def test_gatv2_dense_product_form_vs_edge_list_oracle_form():
         (y * go).sum().backward()
         (yr * go).sum().backward()
         torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 7])
+def test_time_pair_table_is_the_adjoint_of_reflect_pad_plus_three_taps(T):
+    """ops._time_pair_table (temporal reflect padding folded into the 3x3x3 Winograd data gradient, c2m_conv_wino geom[33]):
+    summing dY frame `to` through tap kt over a frame's pairs must equal autograd through F.pad(reflect) + a 3-tap correlation
+    in time (src/modules/layers/common.py Conv3d call sites use padding_mode='reflect')."""
+    import torch.nn.functional as F
+    from c2m_amd.ops import _time_pair_table
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(1, 1, T, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(1, 1, 3, generator=g, dtype=torch.float64)
+    gy = torch.randn(1, 1, T, generator=g, dtype=torch.float64)
+    y = F.conv1d(F.pad(x, (1, 1), mode="reflect"), w)
+    y.backward(gy)
+    tab = _time_pair_table(T)
+    got = torch.zeros(T, dtype=torch.float64)
+    for t in range(T):
+        n = int(tab[t, 0])
+        assert 2 <= n <= 5 and (tab[t, 1 + 2 * n:] == 0).all()
+        for j in range(n):
+            to, ublock = int(tab[t, 1 + 2 * j]), int(tab[t, 2 + 2 * j])
+            got[t] += gy[0, 0, to] * w[0, 0, 2 - ublock]          # U block = flipped time tap
+    assert torch.allclose(got, x.grad[0, 0], rtol=0, atol=1e-14)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void aggressor(float* out, int iters) {
 }
 
 int main() {
-    const int VB = 2048, AB = 4096, iters = 20000;
+    const int VB = 8192, AB = 4096, iters = 20000;
     float *vo, *ao;
     hipMalloc(&vo, VB * 256 * 4); hipMalloc(&ao, AB * 256 * 4);
     hipStream_t s1, s2;
@@ -53,10 +53,15 @@ int main() {
     std::vector<float> ref(VB * 256), got(VB * 256);
     auto run = [&](bool pk, int aggr) {     // aggr: -1 none, 0 bf16 MFMA, 1 fp32 MFMA
         hipDeviceSynchronize();
-        if (aggr == 0) hipLaunchKernelGGL(aggressor<0>, dim3(AB), dim3(256), 0, s2, ao, 60000);
-        if (aggr == 1) hipLaunchKernelGGL(aggressor<1>, dim3(AB), dim3(256), 0, s2, ao, 30000);
+        // the victim starts FIRST and the neighbour arrives while it runs (the order of the failing case: the weight gradient
+        // was launched on the side stream, then the data gradient on the main one); a few neighbour launches in a row give
+        // several onsets
         if (pk) hipLaunchKernelGGL(victim<true>, dim3(VB), dim3(256), 0, s1, vo, iters);
         else hipLaunchKernelGGL(victim<false>, dim3(VB), dim3(256), 0, s1, vo, iters);
+        for (int k = 0; k < 6; ++k) {
+            if (aggr == 0) hipLaunchKernelGGL(aggressor<0>, dim3(AB / 4), dim3(256), 0, s2, ao, 8000);
+            if (aggr == 1) hipLaunchKernelGGL(aggressor<1>, dim3(AB / 4), dim3(256), 0, s2, ao, 4000);
+        }
         hipDeviceSynchronize();
         hipMemcpy(got.data(), vo, VB * 256 * 4, hipMemcpyDeviceToHost);
     };
