@@ -63,6 +63,7 @@ _SIGS = {
     "c2m_occlusion_splat_workspace_bytes": (c_long, [c_long, c_int, c_int]),
     "c2m_occlusion_splat": (c_int, [c_void_p, c_long, c_long, c_long] + [c_int] * 4 + [c_void_p] * 4),
     "c2m_l1_mean_fwd": (c_int, [c_void_p] * 4 + [c_long, c_int, c_long, c_void_p, c_int, c_void_p]),
+    "c2m_relu_tap_bwd": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
     "c2m_l1_mean_bwd": (c_int, [c_void_p] * 6 + [c_long, c_int, c_long, c_int, c_void_p]),
     "c2m_ssim_fwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p, c_void_p]),
     "c2m_ssim_bwd": (c_int, [c_void_p] * 5 + [c_long, c_int, c_int, c_void_p]),

@@ -82,6 +82,53 @@ C2M_API int c2m_l1_mean_bwd(const void* a, const void* b, const float* mask, con
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------- VGG tap backward
+// A perceptual-loss tap (losses.py:60-65 on vgg.py:92-137's relu{1..5}_1 outputs): y = relu(conv(x)) feeds the next VGG conv
+// AND mean|y - t|.  Autograd ran three element-wise passes over the tap tensor for that -- the L1 gradient, the sum with the
+// next conv's data gradient, the ReLU mask -- 9 tensor passes; this is the same arithmetic in one (4 passes):
+//   out = (gy + gl/total * sign(y - t)) * (y > 0)        gy: gradient from the next conv (or NULL), gl: device scalar
+// bit-identical to the three-kernel chain in fp32 (same products, one commutative add, a 0/1 mask).
+template <class T>
+__global__ void relu_tap_bwd_kernel(const T* __restrict__ y, const T* __restrict__ t, const T* __restrict__ gy,
+                                    const float* __restrict__ gl, T* __restrict__ out, long total4, long total) {
+    const float g = gl[0] / (float)total;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const float4 a = c2m_ld4(y + 4 * i), b = c2m_ld4(t + 4 * i);
+        const float4 u = gy ? c2m_ld4(gy + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o;
+#define C2M_TAP(f) { const float d = a.f - b.f; const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); \
+                     const float v = g * sgn; o.f = a.f > 0.f ? u.f + v : 0.f; }
+        C2M_TAP(x) C2M_TAP(y) C2M_TAP(z) C2M_TAP(w)
+#undef C2M_TAP
+        c2m_st4(out + 4 * i, o);
+    }
+}
+
+template <class T>
+__global__ void relu_tap_bwd_tail_kernel(const T* __restrict__ y, const T* __restrict__ t, const T* __restrict__ gy,
+                                         const float* __restrict__ gl, T* __restrict__ out, long beg, long total) {
+    const float g = gl[0] / (float)total;
+    for (long i = beg + blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float a = c2m_ld(y, i), d = a - c2m_ld(t, i);
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        c2m_st(out, i, a > 0.f ? (gy ? c2m_ld(gy, i) : 0.f) + g * sgn : 0.f);
+    }
+}
+
+C2M_API int c2m_relu_tap_bwd(const void* y, const void* t, const void* gy, const float* gl, void* out, long total, int dt,
+                             void* stream) {
+    C2M_ENTER();
+    if (total <= 0) return 0;
+    C2M_DISPATCH_DT(dt,
+        const bool vec = !(((uintptr_t)y | (uintptr_t)t | (uintptr_t)gy | (uintptr_t)out) & C2mVec4<T>::mask);
+        const long n4 = vec ? total / 4 : 0;
+        if (n4) hipLaunchKernelGGL(relu_tap_bwd_kernel<T>, dim3(c2m_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                                   (const T*)t, (const T*)gy, gl, (T*)out, n4, total);
+        if (4 * n4 < total) hipLaunchKernelGGL(relu_tap_bwd_tail_kernel<T>, dim3(c2m_grid(total - 4 * n4, 256)), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)y, (const T*)t, (const T*)gy, gl, (T*)out, 4 * n4, total););
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------- SSIM
 struct SsimWin { float mx, my, ex2, ey2, exy; };
 

@@ -40,11 +40,12 @@ class PerceptualLoss(nn.Module):
             # frame-major fold: rows [t*B:(t+1)*B] are frame t -> per-frame means are recovered from one VGG pass
             with torch.no_grad():
                 x_feats = self.vgg19(fold_time(gt))
-            y_feats = self.vgg19(fold_time(fake))
+            # the feature L1 of every tap comes out of the VGG pass itself (fused tap backward, ops.conv_relu_tap)
+            y_feats = self.vgg19(fold_time(fake), tap_targets={k: x_feats[k] for k in _TAPS})
             content = 0.0
             for k in _TAPS:
                 # sum_t mean_frame|x - y| = T * mean_all|x - y| because every frame contributes equally many elements
-                content = content + ops.l1_mean(y_feats[k], x_feats[k]) * T
+                content = content + y_feats["l1"][k] * T
             out["perceptual"] = content / T
         return out
 

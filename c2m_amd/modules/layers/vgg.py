@@ -53,9 +53,13 @@ class Vgg19(torch.nn.Module):
             for param in self.parameters():
                 param.requires_grad = False
 
-    def forward(self, x):
+    def forward(self, x, tap_targets=None):
+        """tap_targets (optional): {slice name: target feature map without gradient}; those slices also return mean|y - target|
+        (the perceptual loss's feature L1, losses/losses.py:60-65) under out["l1"][name], with the L1 gradient, the sum with the
+        next conv's data gradient and the ReLU mask fused into one backward pass (ops.conv_relu_tap)."""
         x = (x - self.mean) / self.std
         out = {}
+        l1 = {}
         for name, steps in self._plan:
             seq = getattr(self, name)
             for kind, i in steps:
@@ -63,8 +67,13 @@ class Vgg19(torch.nn.Module):
                     x = ops.maxpool2x2(x)
                 else:
                     c = seq._modules[str(i)]
-                    x = ops.conv(x, c.weight, c.bias, stride=1, padding=1, padding_mode="zeros", act="relu")
+                    if tap_targets is not None and name in tap_targets:
+                        x, l1[name] = ops.conv_relu_tap(x, c.weight, c.bias, tap_targets[name])
+                    else:
+                        x = ops.conv(x, c.weight, c.bias, stride=1, padding=1, padding_mode="zeros", act="relu")
             out[name] = x
             if name == self.stop_after:
                 break
+        if tap_targets is not None:
+            out["l1"] = l1
         return out

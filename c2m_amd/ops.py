@@ -1019,6 +1019,51 @@ def conv(x, w, b=None, stride=1, padding=0, padding_mode="zeros", act=None, dgra
     return _ConvFn.apply(x, w, b, stride3, pad3, reflect, act, dgrad_channels, slope)
 
 
+class _ConvReluTapFn(torch.autograd.Function):
+    """y = relu(conv3x3(x; frozen w, b)) together with the L1 tap mean|y - t| it feeds (a perceptual-loss tap of the frozen
+    VGG-19, losses.py:60-65): backward folds the L1 gradient, its sum with the next conv's data gradient and the ReLU mask
+    into ONE element-wise pass (c2m_relu_tap_bwd) in front of the data gradient -- autograd ran three (9 tensor passes instead
+    of 4 over the largest tensors of the step).  Same fp32 arithmetic, so values and gradients are bit-identical to
+    conv(act='relu') + l1_mean."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, t, pad3):
+        y = _ConvFn.apply(x, w, b, (1, 1, 1), pad3, False, "relu", None, LRELU_SLOPE)       # (grad mode is off in here)
+        t = _as(t, y.dtype)
+        l = _L1MeanFn.apply(y, t, None)
+        ctx.pl = _plan(_f(x), _f(w), (1, 1, 1), pad3, False, None)
+        ctx.x_dtype = x.dtype
+        ctx.save_for_backward(w, y, t)
+        ctx.set_materialize_grads(False)
+        return y, l
+
+    @staticmethod
+    def backward(ctx, gy, gl):
+        if gy is None and gl is None:
+            return None, None, None, None, None
+        w, y, t = ctx.saved_tensors
+        if gl is None:
+            gl = torch.zeros((), device=y.device, dtype=torch.float32)
+        gl = _f(gl.reshape(1).float())
+        gy = None if gy is None else _as(gy, y.dtype)
+        g = torch.empty_like(y)
+        _lib.check(_lib.lib().c2m_relu_tap_bwd(_p(y), _p(t), _p(gy), _p(gl), _p(g), y.numel(), _dt(y), _stream()), "relu_tap_bwd")
+        return _conv_dgrad(ctx.pl, w, g, True, ctx.x_dtype), None, None, None, None
+
+
+def conv_relu_tap(x, w, b, target, padding=1):
+    """(y, mean|y - target|) for y = relu(conv(x, w, b)) with a FROZEN w / b (the VGG-19 of the perceptual loss) and a target
+    without gradient: conv(act='relu') + l1_mean with a fused backward (see _ConvReluTapFn).  Falls back to the two ops where
+    the fused form does not apply (weights that need gradients, batches that run as 2 GiB chunks)."""
+    nd = x.dim() - 2
+    pad3 = _pad3(padding, nd)
+    if w.requires_grad or (b is not None and b.requires_grad) or target.requires_grad or not x.requires_grad or \
+            not torch.is_grad_enabled() or _chunks_for_2gib(x.shape, w.shape, (1, 1, 1), pad3) > 1:
+        y = conv(x, w, b, stride=1, padding=padding, padding_mode="zeros", act="relu")
+        return y, l1_mean(y, target)
+    return _ConvReluTapFn.apply(x, w, b, target, pad3)
+
+
 def conv_transpose2d(x, w, b=None, stride=2, padding=1, act=None, slope=LRELU_SLOPE):
     """nn.ConvTranspose2d(x; w [Cin, Cout, kh, kw], stride, padding) (+ bias, activation) for frozen, no-grad use (FlowNet2's
     `deconv` / `upsampled_flow` layers, flownet2/networks/submodules.py:75-80): a transposed convolution IS the data gradient

@@ -198,6 +198,11 @@ int c2m_l1_mean_fwd(const void* a, const void* b, const float* mask, float* out,
                     void* workspace /* 8 KiB */, int dt /* a, b */, void* stream);
 int c2m_l1_mean_bwd(const void* a, const void* b, const float* mask, const float* gscale, void* ga, void* gb,
                     long total, int C, long inner, int dt /* a, b, ga, gb */, void* stream);
+/* Backward of a perceptual-loss tap y = relu(conv(x)) that feeds the next VGG conv and mean|y - t| (losses.py:60-65 on the
+ * relu{1..5}_1 slices of layers/vgg.py:92-137): out = (gy + gl[0]/total * sign(y - t)) * (y > 0) in one pass; gy may be NULL
+ * (last tap), gl is a device scalar (the gradient of the L1 mean).  out is what the conv's data gradient consumes.       */
+int c2m_relu_tap_bwd(const void* y, const void* t, const void* gy, const float* gl, void* out, long total,
+                     int dt /* y, t, gy, out */, void* stream);
 int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int W, void* workspace /* 8 KiB */,
                  void* stream);
 int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,

@@ -719,3 +719,38 @@ def test_conv_dgrad_channels_skips_the_gradient_free_tail(shape, cout, k, pad, m
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
     rel_close(res[1][1][:, :keep], res[0][1][:, :keep], 1e-6, "leading channels of the data gradient")
     assert float(res[1][1][:, keep:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,cout,has_next", [((3, 8, 16, 32), 16, True), ((2, 3, 18, 20), 64, True), ((2, 32, 8, 16), 48, False),
+                                                 ((1, 5, 7, 9), 6, True)])
+def test_conv_relu_tap_matches_the_unfused_chain_bit_for_bit(shape, cout, has_next):
+    """ops.conv_relu_tap (perceptual-loss tap of the frozen VGG: relu(conv) feeding the next conv AND an L1 mean) against
+    conv(act='relu') + l1_mean + autograd's own gradient sum: same fp32 arithmetic -> identical bits in y, the L1 value and dX.
+    has_next = False is the last tap (relu5_1): no gradient arrives through y itself."""
+    seed = zlib.crc32(str((shape, cout)).encode()) % 10000
+    x0 = rnd(seed, *shape)
+    w = g(rnd(seed + 1, cout, shape[1], 3, 3, scale=(1.0 / (shape[1] * 9)) ** 0.5))
+    b = g(rnd(seed + 2, cout, scale=0.1))
+    w2 = g(rnd(seed + 3, 8, cout, 3, 3, scale=(1.0 / (cout * 9)) ** 0.5))
+    res = []
+    for fused in (False, True):
+        x = g(x0).requires_grad_(True)
+        if fused:
+            y, l = ops.conv_relu_tap(x, w, b, None if False else _tap_target(seed, w, b, x0))
+        else:
+            y = ops.conv(x, w, b, stride=1, padding=1, padding_mode="zeros", act="relu")
+            l = ops.l1_mean(y, _tap_target(seed, w, b, x0))
+        total = l * 3.0
+        if has_next:
+            total = total + ops.conv(y, w2, None, stride=1, padding=1, padding_mode="zeros").square().mean()
+        total.backward()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), l.detach().clone(), x.grad.clone()))
+    for a, c, what in zip(res[0], res[1], ("y", "l1", "dX")):
+        assert torch.equal(a, c), f"{what}: fused tap differs from the unfused chain"
+    assert float(res[1][2].abs().max()) > 0
+
+
+def _tap_target(seed, w, b, x0):
+    with torch.no_grad():
+        return ops.conv(g(x0) * 0.9 + 0.05, w, b, stride=1, padding=1, padding_mode="zeros", act="relu")
