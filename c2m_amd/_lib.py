@@ -59,6 +59,7 @@ _SIGS = {
     "c2m_roi_align_bwd": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_float, c_void_p]),
     "c2m_maxpool2x2_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_maxpool2x2_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_int, c_void_p]),
+    "c2m_maxpool2x2_relu_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_sparse_raster": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "c2m_occlusion_splat_workspace_bytes": (c_long, [c_long, c_int, c_int]),
     "c2m_occlusion_splat": (c_int, [c_void_p, c_long, c_long, c_long] + [c_int] * 4 + [c_void_p] * 4),

@@ -678,7 +678,7 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ in, T* __restrict__ ou
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
 template <typename I, class T = float>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restrict__ gout,
-                                    T* __restrict__ gin, long NC, int Hi, int Wi) {
+                                    T* __restrict__ gin, long NC, int Hi, int Wi, int relu) {
     const int Ho = Hi / 2, Wo = Wi / 2;
     const I total = (I)(NC * Hi * Wi);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
@@ -692,7 +692,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restric
             int arg = 0; float m = v[0];
 #pragma unroll
             for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
-            if (arg == (y & 1) * 2 + (x & 1)) g = c2m_ld(gout, (long)nc * Ho * Wo + oy * Wo + ox);
+            if (arg == (y & 1) * 2 + (x & 1) && !(relu && !(m > 0.f))) g = c2m_ld(gout, (long)nc * Ho * Wo + oy * Wo + ox);
         }
         c2m_st(gin, (long)i, g);
     }
@@ -717,7 +717,7 @@ C2M_API int c2m_maxpool2x2_fwd(const void* in_, void* out_, long NC, int Hi, int
 // each window four times), two 8-byte loads + one gradient, two 8-byte stores
 template <typename I, class T = float>
 __global__ void maxpool2_bwd_win_kernel(const T* __restrict__ in, const T* __restrict__ gout,
-                                        T* __restrict__ gin, long NC, int Hi, int Wi) {
+                                        T* __restrict__ gin, long NC, int Hi, int Wi, int relu) {
     const int Ho = Hi / 2, Wo = Wi / 2;
     const I total = (I)(NC * Ho * Wo);
     for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
@@ -729,34 +729,48 @@ __global__ void maxpool2_bwd_win_kernel(const T* __restrict__ in, const T* __res
         int arg = 0; float m = v[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
-        const float g = c2m_ld(gout, (long)i);
+        const float g = (relu && !(m > 0.f)) ? 0.f : c2m_ld(gout, (long)i);     // relu: `in` is a ReLU output, gin its pre-activation's
         c2m_st2(gin + base, make_float2(arg == 0 ? g : 0.f, arg == 1 ? g : 0.f));
         c2m_st2(gin + base + Wi, make_float2(arg == 2 ? g : 0.f, arg == 3 ? g : 0.f));
     }
 }
 
-C2M_API int c2m_maxpool2x2_bwd(const void* in_, const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream) {
-    C2M_ENTER();
+static int maxpool2x2_bwd_impl(const void* in_, const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream,
+                               int relu) {
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     if (dt == C2M_BF16) {
         if ((Hi & 1) == 0 && (Wi & 1) == 0 && ((((uintptr_t)in_) | ((uintptr_t)gin_)) & 3) == 0 && total < (1L << 31)) {
             hipLaunchKernelGGL((maxpool2_bwd_win_kernel<unsigned, bf16_t>), dim3(c2m_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                               (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+                               (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi, relu);
             return (int)hipGetLastError();
         }
         const dim3 grid(c2m_grid(total, 256));
-        if (total < (1L << 31)) hipLaunchKernelGGL((maxpool2_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
-        else hipLaunchKernelGGL((maxpool2_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi);
+        if (total < (1L << 31)) hipLaunchKernelGGL((maxpool2_bwd_kernel<unsigned, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi, relu);
+        else hipLaunchKernelGGL((maxpool2_bwd_kernel<long, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_, (const bf16_t*)gout_, (bf16_t*)gin_, NC, Hi, Wi, relu);
         return (int)hipGetLastError();
     }
     const float* in = (const float*)in_; const float* gout = (const float*)gout_; float* gin = (float*)gin_;
     if ((Hi & 1) == 0 && (Wi & 1) == 0 && ((((uintptr_t)in) | ((uintptr_t)gin)) & 7) == 0) {
-        C2M_IDX_DISPATCH(total, maxpool2_bwd_win_kernel, dim3(c2m_grid(total / 4, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
+        C2M_IDX_DISPATCH(total, maxpool2_bwd_win_kernel, dim3(c2m_grid(total / 4, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi, relu);
         return (int)hipGetLastError();
     }
-    C2M_IDX_DISPATCH(total, maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi);
+    C2M_IDX_DISPATCH(total, maxpool2_bwd_kernel, dim3(c2m_grid(total, 256)), (hipStream_t)stream, in, gout, gin, NC, Hi, Wi, relu);
     return (int)hipGetLastError();
+}
+
+C2M_API int c2m_maxpool2x2_bwd(const void* in_, const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream) {
+    C2M_ENTER();
+    return maxpool2x2_bwd_impl(in_, gout_, gin_, NC, Hi, Wi, dt, stream, 0);
+}
+
+// `in` is the OUTPUT of a ReLU (layers/vgg.py: conv -> ReLU -> MaxPool2d): gin is the gradient of the ReLU's INPUT, i.e. the pool
+// backward times (in > 0) -- the window maximum of a ReLU output is 0 only where the whole window is, so the mask is one
+// compare on the value the kernel already holds, and the separate activation-backward pass over the full-resolution tensor
+// (read, read, write) goes away.
+C2M_API int c2m_maxpool2x2_relu_bwd(const void* in_, const void* gout_, void* gin_, long NC, int Hi, int Wi, int dt, void* stream) {
+    C2M_ENTER();
+    return maxpool2x2_bwd_impl(in_, gout_, gin_, NC, Hi, Wi, dt, stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------- RoIAlign

@@ -60,20 +60,33 @@ class Vgg19(torch.nn.Module):
         x = (x - self.mean) / self.std
         out = {}
         l1 = {}
+        flat = []                              # [(kind, features index, slice the op closes or None)]
         for name, steps in self._plan:
-            seq = getattr(self, name)
-            for kind, i in steps:
-                if kind == "pool":
-                    x = ops.maxpool2x2(x)
-                else:
-                    c = seq._modules[str(i)]
-                    if tap_targets is not None and name in tap_targets:
-                        x, l1[name] = ops.conv_relu_tap(x, c.weight, c.bias, tap_targets[name])
-                    else:
-                        x = ops.conv(x, c.weight, c.bias, stride=1, padding=1, padding_mode="zeros", act="relu")
-            out[name] = x
+            for k, (kind, i) in enumerate(steps):
+                flat.append((kind, i, name, k == len(steps) - 1))
             if name == self.stop_after:
                 break
+        j = 0
+        while j < len(flat):
+            kind, i, name, closes = flat[j]
+            if kind == "pool":
+                x = ops.maxpool2x2(x)
+            else:
+                c = getattr(self, name)._modules[str(i)]
+                fuse_pool = tap_targets is not None and name not in tap_targets and j + 1 < len(flat) and flat[j + 1][0] == "pool"
+                if tap_targets is not None and name in tap_targets:
+                    x, l1[name] = ops.conv_relu_tap(x, c.weight, c.bias, tap_targets[name])
+                elif fuse_pool:
+                    # conv -> ReLU -> MaxPool2d with nobody else reading the ReLU output (training path: only the taps are
+                    # consumed): one node, ReLU backward inside the pool backward.  out[name] is not produced then.
+                    x = ops.conv_relu_pool(x, c.weight, c.bias)
+                    j += 1
+                    closes = False
+                else:
+                    x = ops.conv(x, c.weight, c.bias, stride=1, padding=1, padding_mode="zeros", act="relu")
+            if closes:
+                out[name] = x
+            j += 1
         if tap_targets is not None:
             out["l1"] = l1
         return out

@@ -1064,6 +1064,42 @@ def conv_relu_tap(x, w, b, target, padding=1):
     return _ConvReluTapFn.apply(x, w, b, target, pad3)
 
 
+class _ConvReluPoolFn(torch.autograd.Function):
+    """maxpool2x2(relu(conv3x3(x; frozen w, b))) as one node (layers/vgg.py: the conv -> ReLU -> MaxPool2d runs of the frozen
+    VGG-19 whose ReLU output nobody else reads): the pool backward applies the ReLU mask on the value it already holds
+    (c2m_maxpool2x2_relu_bwd), so the activation-backward pass over the full-resolution tensor disappears.  Same arithmetic ->
+    bit-identical to conv(act='relu') + maxpool2x2."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, pad3):
+        y = _ConvFn.apply(x, w, b, (1, 1, 1), pad3, False, "relu", None, LRELU_SLOPE)
+        p = _MaxPool2Fn.apply(y)
+        ctx.pl = _plan(_f(x), _f(w), (1, 1, 1), pad3, False, None)
+        ctx.x_dtype = x.dtype
+        ctx.save_for_backward(w, y)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        w, y = ctx.saved_tensors
+        N, C, H, W = y.shape
+        g = torch.empty_like(y)
+        _lib.check(_lib.lib().c2m_maxpool2x2_relu_bwd(_p(y), _p(_as(gp, y.dtype)), _p(g), N * C, H, W, _dt(y), _stream()),
+                   "maxpool_relu_bwd")
+        return _conv_dgrad(ctx.pl, w, g, True, ctx.x_dtype), None, None, None
+
+
+def conv_relu_pool(x, w, b, padding=1):
+    """maxpool2x2(relu(conv(x, w, b))) for a FROZEN w / b, with the ReLU backward folded into the pool backward; the unfused
+    ops where that does not apply (trainable weights, no gradient wanted, 2 GiB batch chunks, odd extents)."""
+    nd = x.dim() - 2
+    pad3 = _pad3(padding, nd)
+    if nd != 2 or w.requires_grad or (b is not None and b.requires_grad) or not x.requires_grad or not torch.is_grad_enabled() or \
+            _chunks_for_2gib(x.shape, w.shape, (1, 1, 1), pad3) > 1:
+        return maxpool2x2(conv(x, w, b, stride=1, padding=padding, padding_mode="zeros", act="relu"))
+    return _ConvReluPoolFn.apply(x, w, b, pad3)
+
+
 def conv_transpose2d(x, w, b=None, stride=2, padding=1, act=None, slope=LRELU_SLOPE):
     """nn.ConvTranspose2d(x; w [Cin, Cout, kh, kw], stride, padding) (+ bias, activation) for frozen, no-grad use (FlowNet2's
     `deconv` / `upsampled_flow` layers, flownet2/networks/submodules.py:75-80): a transposed convolution IS the data gradient

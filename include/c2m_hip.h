@@ -168,6 +168,9 @@ int c2m_roi_align_bwd(const float* boxes, const float* gout, float* gfeat, int N
 /* VGG-19 max pools (layers/vgg.py, torchvision features 4/9/18/27).                                           */
 int c2m_maxpool2x2_fwd(const void* in, void* out, long NC, int Hi, int Wi, int dt, void* stream);
 int c2m_maxpool2x2_bwd(const void* in, const void* gout, void* gin, long NC, int Hi, int Wi, int dt, void* stream);
+/* The same for a window input that is the output of a ReLU (vgg.py: conv -> ReLU -> MaxPool2d): gin is the gradient of the
+ * ReLU's INPUT (pool backward x (in > 0)), which spares the activation-backward pass over the full-resolution tensor. */
+int c2m_maxpool2x2_relu_bwd(const void* in, const void* gout, void* gin, long NC, int Hi, int Wi, int dt, void* stream);
 
 /* ---- FlowNet2 operators of the online target-flow path (flownet_ops.hip) -----------------------------
  * Replace the reference's CUDA extensions, forward only (the flow net runs frozen under no_grad, flow_net.py:32,66-67):

@@ -754,3 +754,24 @@ def test_conv_relu_tap_matches_the_unfused_chain_bit_for_bit(shape, cout, has_ne
 def _tap_target(seed, w, b, x0):
     with torch.no_grad():
         return ops.conv(g(x0) * 0.9 + 0.05, w, b, stride=1, padding=1, padding_mode="zeros", act="relu")
+
+
+@pytest.mark.parametrize("shape,cout", [((3, 8, 16, 32), 16), ((2, 3, 18, 20), 64), ((1, 64, 8, 16), 48)])
+def test_conv_relu_pool_matches_the_unfused_chain_bit_for_bit(shape, cout):
+    """ops.conv_relu_pool (conv -> ReLU -> MaxPool2d of the frozen VGG with the ReLU backward inside the pool backward) against
+    conv(act='relu') + maxpool2x2: identical bits in the output and in dX, incl. all-zero windows (dead ReLU regions)."""
+    seed = zlib.crc32(str(("crp", shape, cout)).encode()) % 10000
+    x0 = rnd(seed, *shape)
+    w = g(rnd(seed + 1, cout, shape[1], 3, 3, scale=(1.0 / (shape[1] * 9)) ** 0.5))
+    b = g(rnd(seed + 2, cout, scale=0.1) - 0.3)                    # many dead outputs -> windows whose maximum is 0
+    res = []
+    for fused in (False, True):
+        x = g(x0).requires_grad_(True)
+        p = ops.conv_relu_pool(x, w, b) if fused else \
+            ops.maxpool2x2(ops.conv(x, w, b, stride=1, padding=1, padding_mode="zeros", act="relu"))
+        go = g(rnd(seed + 3, *p.shape))
+        (p * go).sum().backward()
+        torch.cuda.synchronize()
+        res.append((p.detach().clone(), x.grad.clone()))
+    assert float((res[0][0] == 0).float().mean()) > 0.05, "the case should contain all-zero pooling windows"
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
