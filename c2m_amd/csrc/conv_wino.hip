@@ -1182,6 +1182,69 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ usum, const f
     }
 }
 
+// Stages 1 + 2 in one launch for S <= 64 splits (the >= 128-channel layers; round 3): a workgroup owns 64 output channels of one
+// input channel; thread (el, xi) sums ALL splits of frequency xi for the four output channels of float4 `el` in split order
+// (four loads in flight), the 16 frequencies of an output meet through LDS, then one thread per output applies G^T (.) G and
+// writes the nine taps.  The summed slab never goes to memory and the second launch (46 per step) disappears.  Layers with
+// hundreds of splits (<= 64 channels) keep the two-stage form: a thread walking 768 splits is a chain of dependent loads.
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const f32x4* __restrict__ slab, const float* __restrict__ dbslab,
+                                                                float* __restrict__ dW, float* __restrict__ db, int M, int K, int S) {
+    __shared__ f32x4 us[16][17];
+    const int el = threadIdx.x & 15, xi = threadIdx.x >> 4;
+    const int m4 = M >> 2;                                   // float4 per (xi, ci) row; M % 4 == 0
+    const int cblocks = (m4 + 15) / 16;
+    const long n4 = 4L * M * K;                              // float4 per slab = 16 * M * K / 4
+    const int item = blockIdx.x;
+    const int ci = item / cblocks, c4 = (item - ci * cblocks) * 16 + el;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < m4) {
+        const f32x4* __restrict__ q = slab + ((long)xi * K + ci) * m4 + c4;
+        int sp = 0;
+        for (; sp + 3 < S; sp += 4) {
+            const f32x4 a = q[(long)sp * n4], b = q[(long)(sp + 1) * n4], c = q[(long)(sp + 2) * n4], d = q[(long)(sp + 3) * n4];
+            acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
+        }
+        for (; sp < S; ++sp) acc = acc + q[(long)sp * n4];
+    }
+    us[xi][el] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int e = threadIdx.x >> 2, sub = threadIdx.x & 3;
+        const int co = ((item - ci * cblocks) * 16 + e) * 4 + sub;
+        if (co < M) {
+            float u[4][4];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] = us[k][e][sub];
+            float t[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+                t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+                t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+            }
+            float* __restrict__ o = dW + ((long)co * K + ci) * 9;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+                o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+                o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+            }
+        }
+    }
+    // bias gradient: the workgroups of input channel 0 sum dbslab for their 64 output channels (16 lanes per channel, fixed order)
+    if (db && ci == 0) {
+        const int base = (item - ci * cblocks) * 64;
+        for (int r = 0; r < 4; ++r) {
+            const int m = base + r * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+            float a = 0.f;
+            if (m < M)
+                for (int sp = sl; sp < S; sp += 16) a += dbslab[(long)sp * M + m];
+            a += __shfl_xor(a, 8, 16); a += __shfl_xor(a, 4, 16); a += __shfl_xor(a, 2, 16); a += __shfl_xor(a, 1, 16);
+            if (sl == 0 && m < M) db[m] = a;
+        }
+    }
+}
+
 // Number of region splits the launch will use.  The caller provides slab = (S + 1)*16*M*K floats (S partial slabs + the
 // summed one) and dbslab = S*M floats.
 // Input-channel tile of the launch: 32 (NI = 1: 64 x 32 channels, 128 accumulators, two workgroups per CU).  The 64 x 64
@@ -1230,6 +1293,13 @@ static int wino_wgrad_launch(const float* dY, const float* X, float* slab, float
     if (rc) return rc;
     const long n = 16L * M * K;
     float* usum = slab + (long)S * n;
+    static const bool two_stage = getenv("C2M_WINO_WGRAD_TWO_STAGE") != nullptr;      // A/B knob
+    if (S <= 64 && (M & 3) == 0 && !two_stage) {
+        const int cblocks = ((M >> 2) + 15) / 16;
+        hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)(K * cblocks)), dim3(256), 0, s, (const f32x4*)slab, dbslab,
+                           dW, db, M, K, S);
+        return (int)hipGetLastError();
+    }
     if ((n & 3) == 0) {
         hipLaunchKernelGGL(wino_slab_sum_kernel, dim3(c2m_grid(n / 4, 16)), dim3(256), 0, s, (const f32x4*)slab,
                            (f32x4*)usum, n / 4, S);
