@@ -21,6 +21,9 @@ _SIGS = {
     "c2m_conv_wgrad": (c_int, [c_void_p] * 8),
     "c2m_reflect_fold": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 7 + [c_void_p]),
     "c2m_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "c2m_pack_job_bytes": (c_int, []),
+    "c2m_pack_job_fill": (c_long, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_uint]),
+    "c2m_pack_multi": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "c2m_pack_weights_bf16_patch_bytes": (c_long, [c_int, c_int]),
     "c2m_pack_weights_bf16_patch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "c2m_wino_upack_floats": (c_long, [c_int, c_int]),

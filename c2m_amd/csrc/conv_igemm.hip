@@ -23,6 +23,7 @@
 #include "common.h"
 #include "dtype.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2610,13 +2611,11 @@ struct PackP { int M, C, CK, NS, nch, ntg, At, Ay, Ax, st, sh, sw, KH, KW; long 
 // one workgroup row per packed row r = cls*M + m (blockIdx.y); the per-tap source offsets of the row's parity class are
 // computed once into LDS, CK / NS are powers of two: one integer division (by ntg) per element remains
 template <int CK>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                            const PackP q) {
+__device__ __forceinline__ void pack_weights_row(const float* __restrict__ w, float* __restrict__ out, const PackP& q, int* toff,
+                                                 const int r, const int bx, const int nbx) {
     constexpr int NS = 16 / CK, LCK = CK == 16 ? 4 : (CK == 8 ? 3 : 2), LNS = 4 - LCK;
-    __shared__ int toff[128];
     const int taps = q.At * q.Ay * q.Ax;
     const int lda = q.nch * q.ntg * 16;
-    const int r = blockIdx.y;
     const int m = r % q.M; int cls = r / q.M;
     const int rx = cls % q.sw; cls /= q.sw;
     const int ry = cls % q.sh; const int rt = cls / q.sh;
@@ -2627,7 +2626,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     __syncthreads();
     const float* __restrict__ wr = w + m * q.s_m;
     float* __restrict__ orow = out + (long)r * lda;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < lda; k += gridDim.x * 256) {
+    for (int k = bx * 256 + threadIdx.x; k < lda; k += nbx * 256) {
         const int ch = k & (CK - 1); int t = k >> LCK;
         const int slot = t & (NS - 1); t >>= LNS;
         const int chunk = t / q.ntg, tg = t - chunk * q.ntg;
@@ -2636,12 +2635,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+template <int CK>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                            const PackP q) {
+    __shared__ int toff[128];
+    pack_weights_row<CK>(w, out, q, toff, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
 // bf16 weights of the bf16 LDS-patch kernel: out[chunk][tap][row (padded to Mpad)][16 channels] in bf16, RNE; rows >= M
 // and channels >= C are zero.  3x3 taps only; forward (flip = 0): tap = ky*3+kx of w[m][c][ky][kx] addressed through
 // s_m / s_c as in c2m_pack_weights; data gradient (flip = 1): the tap index is reversed (rotated filter).
-__global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint4* __restrict__ out, int M, int C, int Mpad,
-                                               long s_m, long s_c, int flip, long units) {
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_weights_bf16_patch_body(const float* __restrict__ w, uint4* __restrict__ out, int M, int C,
+                                                             int Mpad, long s_m, long s_c, int flip, long units, long b0, long nb) {
+    for (long u = b0 * (long)blockDim.x + threadIdx.x; u < units; u += nb * blockDim.x) {
         const int half = (int)(u & 1); long r = u >> 1;
         const int m = (int)(r % Mpad); r /= Mpad;
         const int tap = (int)(r % 9); const int chunk = (int)(r / 9);
@@ -2654,6 +2660,11 @@ __global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint
         }
         out[u] = __builtin_bit_cast(uint4, q);
     }
+}
+
+__global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint4* __restrict__ out, int M, int C, int Mpad,
+                                               long s_m, long s_c, int flip, long units) {
+    pack_weights_bf16_patch_body(w, out, M, C, Mpad, s_m, s_c, flip, units, blockIdx.x, gridDim.x);
 }
 
 // out: ceil(C/16) * 9 * Mpad * 32 bytes with Mpad = ceil(M/128)*128.  g[]: 0 M, 1 C, 2 s_m, 3 s_c, 4 flip.
@@ -2675,25 +2686,99 @@ C2M_API int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t
 
 // g[]: 0 M, 1 C, 2 CK, 3 KT, 4 KH, 5 KW, 6 st, 7 sh, 8 sw, 9 s_m, 10 s_c;  out holds st*sh*sw * M rows of
 // ceil(C/CK) * ceil(taps/NS) * 16 floats (NS = 16/CK, taps = (KT/st)*(KH/sh)*(KW/sw)).
-C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void* stream) {
-    C2M_ENTER();
-    PackP q;
+static int pack_params(const int64_t* g, PackP& q, long& rows, int& lda) {
     q.M = (int)g[0]; q.C = (int)g[1]; q.CK = (int)g[2];
     const int KT = (int)g[3];
     q.KH = (int)g[4]; q.KW = (int)g[5]; q.st = (int)g[6]; q.sh = (int)g[7]; q.sw = (int)g[8];
     q.s_m = g[9]; q.s_c = g[10];
+    rows = 0; lda = 0;
     if (q.M <= 0 || q.C <= 0) return 0;
     if ((q.CK != 4 && q.CK != 8 && q.CK != 16) || q.st < 1 || q.sh < 1 || q.sw < 1 || KT % q.st || q.KH % q.sh ||
         q.KW % q.sw) return (int)hipErrorInvalidValue;
     q.NS = 16 / q.CK;
     q.At = KT / q.st; q.Ay = q.KH / q.sh; q.Ax = q.KW / q.sw;
     q.nch = c2m_cdiv(q.C, q.CK); q.ntg = c2m_cdiv(q.At * q.Ay * q.Ax, q.NS);
-    const long rows = (long)q.st * q.sh * q.sw * q.M;
-    const int lda = q.nch * q.ntg * 16;
+    rows = (long)q.st * q.sh * q.sw * q.M;
+    lda = q.nch * q.ntg * 16;
     if (q.At * q.Ay * q.Ax > 128 || rows > 65535) return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void* stream) {
+    C2M_ENTER();
+    PackP q; long rows; int lda;
+    const int rc = pack_params(g, q, rows, lda);
+    if (rc || rows == 0) return rc;
     dim3 grid(c2m_cdiv(lda, 1024) < 1 ? 1 : c2m_cdiv(lda, 1024), (unsigned)rows);
     if (q.CK == 16)     hipLaunchKernelGGL((pack_weights_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
     else if (q.CK == 8) hipLaunchKernelGGL((pack_weights_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
     else                hipLaunchKernelGGL((pack_weights_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, w, out, q);
+    return (int)hipGetLastError();
+}
+
+// ---- all packs of a model in ONE launch (round 3).  With an optimizer in the step every trainable weight is re-packed once per
+// step and layout -- ~195 launches of 5-7 us in a full G + D step (1.3 ms of GPU time, more host time than that in eager mode).
+// The host keeps one PackJob per (weight, layout) it has packed before (c2m_pack_job_fill), the table lives in device memory,
+// and after the optimizer step one launch refreshes every pack in place: workgroup b finds its job by bisection over the jobs'
+// first workgroup index.  type 0: c2m_pack_weights (g[11]); type 1: c2m_pack_weights_bf16_patch (g[5]).
+struct PackJob {
+    const float* w; void* out;
+    PackP q;                                                  // type 0
+    int M, C, Mpad, flip; long s_m, s_c, units;               // type 1
+    int type; unsigned first, xblocks, nblocks;
+};
+
+C2M_API int c2m_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+
+// fills *job (host memory, c2m_pack_job_bytes() bytes); returns the number of workgroups the job takes, < 0 on bad geometry
+C2M_API long c2m_pack_job_fill(void* job, int type, const void* w, void* out, const int64_t* g, unsigned first_block) {
+    PackJob j;
+    memset(&j, 0, sizeof(j));
+    j.w = (const float*)w; j.out = out; j.type = type; j.first = first_block;
+    if (type == 0) {
+        long rows; int lda;
+        if (pack_params(g, j.q, rows, lda) || rows == 0) return -1;
+        j.xblocks = (unsigned)(c2m_cdiv(lda, 1024) < 1 ? 1 : c2m_cdiv(lda, 1024));
+        j.nblocks = j.xblocks * (unsigned)rows;
+    } else if (type == 1) {
+        j.M = (int)g[0]; j.C = (int)g[1]; j.s_m = g[2]; j.s_c = g[3]; j.flip = (int)g[4];
+        if (j.M <= 0 || j.C <= 0 || (((uintptr_t)out) & 15) != 0) return -1;
+        j.Mpad = c2m_cdiv(j.M, 128) * 128;
+        j.units = (long)c2m_cdiv(j.C, 16) * 9 * j.Mpad * 2;
+        j.xblocks = 1;
+        j.nblocks = (unsigned)c2m_grid(j.units, 256);
+    } else {
+        return -1;
+    }
+    memcpy(job, &j, sizeof(j));
+    return (long)j.nblocks;
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, const int2* __restrict__ blocktab) {
+    __shared__ int toff[128];
+    // (job, workgroup within the job) of this workgroup from a host-built table: the first form bisected over the jobs' first
+    // workgroup index -- eight dependent global loads (~5 us) in front of ~1 us of copying, 185 us per launch on the G + D set
+    const int2 e = blocktab[blockIdx.x];
+    const PackJob& j = jobs[e.x];
+    const unsigned lb = (unsigned)e.y;
+    if (j.type == 0) {
+        const int r = (int)(lb / j.xblocks), bx = (int)(lb % j.xblocks);
+        const PackP q = j.q;
+        if (q.CK == 16)     pack_weights_row<16>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
+        else if (q.CK == 8) pack_weights_row<8>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
+        else                pack_weights_row<4>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
+    } else {
+        pack_weights_bf16_patch_body(j.w, (uint4*)j.out, j.M, j.C, j.Mpad, j.s_m, j.s_c, j.flip, j.units, lb, j.nblocks);
+    }
+}
+
+// jobs: device copy of njobs PackJob records; blocktab: device int32 pairs (job index, workgroup index within the job), one per
+// workgroup of the launch, in any order (total_blocks = the sum of the jobs' workgroup counts)
+C2M_API int c2m_pack_multi(const void* jobs, const void* blocktab, int njobs, long total_blocks, void* stream) {
+    C2M_ENTER();
+    if (njobs <= 0 || total_blocks <= 0) return 0;
+    if (total_blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                       (const int2*)blocktab);
     return (int)hipGetLastError();
 }

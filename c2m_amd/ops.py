@@ -283,6 +283,7 @@ def _pack_bf16_patch(w, M, C, s_m, s_c):
     out = torch.empty(L.c2m_pack_weights_bf16_patch_bytes(M, C), device=w.device, dtype=torch.uint8)
     g = np.array([M, C, s_m, s_c, 0], dtype=np.int64)
     _lib.check(L.c2m_pack_weights_bf16_patch(_p(w), _p(out), _gp(g), _stream()), "pack_weights_bf16_patch")
+    out._c2m_job = (1, g)                   # how to rebuild this pack in place (refresh_trainable_packs)
     return out
 
 
@@ -691,6 +692,7 @@ def _pack_native(w, M, C, ck, kdims, stride, s_m, s_c):
     out = torch.empty(st * sh * sw * M, _cdiv(C, ck) * _cdiv(taps, ns) * 16, device=w.device, dtype=torch.float32)
     g = np.array([M, C, ck, kt, kh, kw, st, sh, sw, s_m, s_c], dtype=np.int64)
     _lib.check(_lib.lib().c2m_pack_weights(_p(w), _p(out), _gp(g), _stream()), "pack_weights")
+    out._c2m_job = (0, g)                   # how to rebuild this pack in place (refresh_trainable_packs)
     return out
 
 
@@ -707,11 +709,17 @@ def _packed(w, frozen, kind, build):
     gradient layouts were rebuilt on every use (pack_weights 76 + wino_filter 94 launches per step in round 2).
     Under a HIP-graph capture trainable weights are re-packed INSIDE the graph and never cached: the graph is replayed after
     eager optimizer steps, and a pack tensor from the graph's private pool must not leak into eager code."""
-    if not frozen and w.is_cuda and torch.cuda.is_current_stream_capturing():
-        return build()
     key = (id(w), kind)
     hit = _frozen_pack_cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+    fresh = hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr()
+    if not frozen and w.is_cuda and torch.cuda.is_current_stream_capturing():
+        # a pack that is kept fresh from outside the graph (refresh_trainable_packs after every optimizer step: same buffer,
+        # new contents) is used as it is -- the graph then holds no pack kernels; pinned, because the graph keeps its address
+        if _PACK_REFRESH and fresh and key in _pack_jobs and _pack_jobs[key][3] is hit[3]:
+            _capture_pins.append(hit[3])
+            return hit[3]
+        return build()
+    if fresh:
         return hit[3]
     if len(_frozen_pack_cache) > _PACK_CACHE_LIMIT:
         for k in [k for k, v in _frozen_pack_cache.items() if v[0]() is None]:       # owners that died (e.g. the
@@ -720,7 +728,69 @@ def _packed(w, frozen, kind, build):
             _frozen_pack_cache.clear()
     A = build()
     _frozen_pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), A)
+    job = getattr(A, "_c2m_job", None)
+    # (leaf tensors only: a weight derived per forward -- spectral norm's w / sigma -- dies with its step, and registering it would
+    # throw the device tables away every step: +2-3 ms of host time per eager step when that was tried)
+    if not frozen and job is not None and w.is_leaf and A.data_ptr() != w.data_ptr():
+        _pack_jobs[key] = (weakref.ref(w), job[0], job[1], A)
+        _pack_tables.clear()          # device job tables are keyed on (key, pointers): a new tensor may reuse both with another geometry
     return A
+
+
+_PACK_REFRESH = os.environ.get("C2M_PACK_REFRESH", "1") != "0"      # A/B knob: 0 = packs rebuilt lazily, one launch each
+_pack_jobs = {}          # (id(w), kind) -> (weakref(w), job type, g, packed tensor): packs of trainable weights we know how to rebuild
+_pack_tables = {}        # signature of a stale set -> (device job table, njobs, total workgroups)
+_capture_pins = []       # packs whose address a captured graph holds
+
+
+def refresh_trainable_packs(params=None):
+    """Rebuild, in ONE launch (c2m_pack_multi), every cached pack of a trainable weight whose weight has changed since it was
+    packed -- called by c2m_amd.optim.Adam.step and before a HIP-graph replay.  The packs keep their buffers, so the ~195 pack
+    launches a full G + D step used to spend on its first use of every layer after the optimizer step (1.3 ms of GPU time, more
+    host time than that) become one, and a captured graph needs no pack kernels at all.  Returns the number of packs rebuilt."""
+    if not _PACK_REFRESH or not _pack_jobs:
+        return 0
+    stale = []
+    if params is None:
+        items = list(_pack_jobs.items())
+    else:                                   # the optimizer's own parameters only (host time: ~1.5 us per registered pack)
+        ids = {id(p) for p in params}
+        items = [(k, v) for k, v in _pack_jobs.items() if k[0] in ids]
+    for key, (wref, typ, g, A) in items:
+        w = wref()
+        hit = _frozen_pack_cache.get(key)
+        if w is None or hit is None or hit[3] is not A or hit[0]() is not w or hit[2] != w.data_ptr():
+            del _pack_jobs[key]
+            continue
+        if hit[1] != w._version:
+            stale.append((key, w, typ, g, A))
+    if not stale:
+        return 0
+    L = _lib.lib()
+    sig = tuple(id(A) for _, _, _, _, A in stale)         # packs stay alive while registered; tables die with any new registration
+    tab = _pack_tables.get(sig)
+    if tab is None:
+        nb = L.c2m_pack_job_bytes()
+        host = (ctypes.c_ubyte * (nb * len(stale)))()
+        first = 0
+        btab = []
+        for i, (_, w, typ, g, A) in enumerate(stale):
+            n = L.c2m_pack_job_fill(ctypes.addressof(host) + i * nb, typ, _p(w), _p(A), _gp(g), first)
+            if n <= 0:
+                raise RuntimeError("c2m_pack_job_fill: bad pack geometry")
+            first += n
+            btab.append(np.stack([np.full(n, i, dtype=np.int32), np.arange(n, dtype=np.int32)], 1))
+        device = stale[0][1].device
+        dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        bdev = torch.from_numpy(np.concatenate(btab, 0)).to(device)
+        if len(_pack_tables) > 16:
+            _pack_tables.clear()
+        tab = _pack_tables[sig] = (dev, len(stale), first, bdev)
+    _lib.check(L.c2m_pack_multi(_p(tab[0]), _p(tab[3]), tab[1], tab[2], _stream()), "pack_multi")
+    for key, w, _, _, A in stale:
+        hit = _frozen_pack_cache[key]
+        _frozen_pack_cache[key] = (hit[0], w._version, hit[2], A)
+    return len(stale)
 
 
 def _set_io(geom, x, ydt):

@@ -78,6 +78,10 @@ class Adam(torch.optim.Adam):
             # the kernel writes through raw pointers: tell autograd (saved-tensor checks) and every `_version`-keyed
             # cache (ops._packed: packed / Winograd-transformed copies of frozen weights) that the values changed
             torch.autograd.graph.increment_version(plist)
+        # every cached pack (K-order matrix, bf16 patch image) of the weights just updated: rebuilt in place by ONE launch instead of
+        # one launch per layer and layout at their next use
+        from . import ops
+        ops.refresh_trainable_packs([p for group in self.param_groups for p in group["params"]])
         return loss
 
     def _build_plan(self, plist, sig):

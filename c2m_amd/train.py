@@ -7,6 +7,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .ddp import GradientReducer
 
 
@@ -155,6 +156,7 @@ class TrainStep:
     def __call__(self, data):
         """One update; returns (generated dict, generator loss dict incl. total_gen, D loss dict)."""
         if getattr(self, "_graph", None) is not None and data is self._graph_data:
+            ops.refresh_trainable_packs()       # weights changed outside Adam.step (load_state_dict ...): the graph holds no pack kernels
             self._graph.replay()
             if self.reducer is not None:
                 self.reducer.reduce_all()

@@ -73,6 +73,15 @@ int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW, float*
  *      9 row stride, 10 channel stride of the source (elements).  Replaces the reshape/permute/copy chain that
  *      aten::convolution does internally on its weights (no reference line of its own).                          */
 int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stream);
+/* Every pack of a model in ONE launch (after an optimizer step each trainable weight needs each of its layouts rebuilt once:
+ * ~195 launches of 5-7 us in a full G + D step).  The host fills one job record per (weight, layout) -- type 0: the arguments of
+ * c2m_pack_weights, type 1: those of c2m_pack_weights_bf16_patch -- with the index of its first workgroup (ascending, dense),
+ * keeps the table (and one (job, workgroup) pair per workgroup of the launch) in device memory and refreshes all packs in place
+ * with c2m_pack_multi.  c2m_pack_job_fill returns the number of workgroups of the job (< 0: bad geometry).                                                           */
+int c2m_pack_job_bytes(void);
+long c2m_pack_job_fill(void* host_job, int type, const void* w, void* packed, const int64_t* g, unsigned first_block);
+int c2m_pack_multi(const void* device_jobs, const void* device_blocktab /* int32 (job, workgroup in job) per workgroup */,
+                   int njobs, long total_blocks, void* stream);
 /* bf16 weight image of the bf16 LDS-patch kernel (3x3 stride-1 layers in bf16 mode, BASELINE configs[2-4]):
  * out[chunk][tap][row padded to a multiple of 128][16 channels] bf16.  g[] = {M, C, s_m, s_c, flip}; flip = 1 for the
  * data gradient (rotated taps).  Pass the result as A to c2m_conv_igemm with geom[2] (lda) = the padded row count. */

@@ -121,6 +121,56 @@ def test_trainable_weight_packs_are_built_once_per_optimizer_step():
         assert (y.detach().cpu().double() - ref).abs().max() <= 2e-5 * ref.abs().max(), "stale pack after the optimizer step"
 
 
+def test_adam_step_refreshes_every_pack_in_one_launch_bit_identically():
+    """ops.refresh_trainable_packs (called by Adam.step): the cached packs of the updated weights -- K-order matrices of a strided
+    layer's forward and data gradient, bf16 patch images of a 3x3 layer -- are rebuilt IN PLACE by c2m_pack_multi and equal a
+    fresh c2m_pack_weights / c2m_pack_weights_bf16_patch of the new weights bit for bit; frozen weights have no job."""
+    from c2m_amd import ops
+    torch.manual_seed(5)
+    with ops.conv_precision("bf16"):
+        ws = [torch.nn.Parameter(torch.randn(24, 16, 4, 4, device=DEV) * 0.05), torch.nn.Parameter(torch.randn(40, 32, 3, 3, device=DEV) * 0.05),
+              torch.nn.Parameter(torch.randn(8, 5, 3, 4, 4, device=DEV) * 0.05)]
+        frozen = torch.randn(16, 16, 3, 3, device=DEV) * 0.05
+        xs = [torch.randn(2, 16, 32, 64, device=DEV, requires_grad=True), torch.randn(2, 32, 16, 32, device=DEV, requires_grad=True),
+              torch.randn(2, 5, 4, 16, 32, device=DEV, requires_grad=True)]
+        strides, pads = [2, 1, (1, 2, 2)], [1, 1, (1, 1, 1)]
+        opt = Adam(ws, lr=5e-2, betas=(0.5, 0.999), eps=1e-7)
+        ops._frozen_pack_cache.clear(); ops._pack_jobs.clear(); ops._pack_tables.clear()
+
+        def run():
+            loss = ops.conv(xs[1], frozen, None, 1, 1).float().square().mean()
+            for x, w, s_, p_ in zip(xs, ws, strides, pads):
+                loss = loss + ops.conv(x, w, None, s_, p_, padding_mode="reflect").float().square().mean()
+            loss.backward()
+
+        run()
+        jobs = dict(ops._pack_jobs)
+        assert len(jobs) >= 5, "forward + data-gradient packs of three trainable layers"
+        assert all(v[0]() is not frozen for v in jobs.values())
+        ptrs = {k: v[3].data_ptr() for k, v in jobs.items()}
+        before = {k: v[3].clone() for k, v in jobs.items()}
+        opt.step()                                                      # -> refresh_trainable_packs()
+        torch.cuda.synchronize()
+        assert {k: v[3].data_ptr() for k, v in ops._pack_jobs.items()} == ptrs, "packs must be refreshed in place"
+        changed = 0
+        for k, (wref, typ, g_, A) in ops._pack_jobs.items():
+            w = wref()
+            hit = ops._frozen_pack_cache[k]
+            assert hit[1] == w._version and hit[3] is A
+            fresh = torch.empty_like(A)
+            fn = ops._lib.lib().c2m_pack_weights if typ == 0 else ops._lib.lib().c2m_pack_weights_bf16_patch
+            ops._lib.check(fn(ops._p(w), ops._p(fresh), ops._gp(g_), ops._stream()), "pack")
+            torch.cuda.synchronize()
+            assert torch.equal(A.view(torch.uint8).flatten(), fresh.view(torch.uint8).flatten()), f"refreshed pack {k[1]} differs from a fresh one"
+            changed += int(not torch.equal(A, before[k]))
+        assert changed == len(jobs), "every pack must carry the updated weights"
+        n_cached = len(ops._frozen_pack_cache)
+        for w in ws:
+            w.grad = None
+        run()                                                           # served from the refreshed cache: nothing new is packed
+        assert len(ops._frozen_pack_cache) == n_cached and ops.refresh_trainable_packs() == 0
+
+
 def _tiny_cfg():
     cfg = normalize_config(default_config(num_input_frames=2, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
                                           out_channel=16, ndf=4, use_spade=True, use_image_discriminator=True,
