@@ -1546,7 +1546,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p) {
 // registers (v_alignbit_b32), the vacated element being 0 (zeros) or the mirrored pixel (reflect).  Rows / frames outside
 // the image are whole-group zeros or mirrored by address.  Eligibility (host): sw == 1, Wi == Wo, Wo % 8 == 0, |dx| <= 1.
 // Same row order, slab layout and reduction as conv_wgrad_kernel.
-template <int BM, int BN, int WGM, int WGN>
+// SW = 2 (round 3: the 4x4 stride-2 layers of the discriminators and down blocks, a third of the bf16 weight-gradient time on
+// the lane-per-pixel kernel): the 8 input pixels of a group are every second element of a 16-element run starting at
+// 2*ox + dx -- two 16-byte loads and four v_perm_b32 (even halves; the odd halves when the run would start at -1 and is loaded
+// from 0 instead).  dx = -1 .. 2 (4 taps, pad 1): only the first element of a left-end group (pixel -1) and the last of a
+// right-end group (pixel Wi) fall into the padding.  Eligibility: sw == 2, Wi == 2*Wo, Wo % 8 == 0, -1 <= dx <= 2.
+template <int BM, int BN, int WGM, int WGN, int SW = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_wide_bf16_kernel(const WgradP p, const int ns) {
     constexpr int BK = 64, LDH = BK + 8;
     constexpr int TM = BM / WGM, TN = BN / WGN, MI = TM / 32, NI = TN / 32;
@@ -1595,8 +1600,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_wide_bf16_kernel(const WgradP 
 
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    u32x4 ra[AP], rb[BP];
+    u32x4 ra[AP], rb[BP], rb2[SW == 2 ? BP : 1];
     int redge[BP];                                           // -1: the group starts one pixel left of the row, +1: ends one past it
+    bool rtail[SW == 2 ? BP : 1];                            // SW = 2: the 16th element of the run lies past the row end
     auto issue = [&](int pk) {
         const int pix = pk + 8 * grp;
         const bool live = pix < pend;
@@ -1610,26 +1616,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_wide_bf16_kernel(const WgradP 
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             int it = p.is3d ? ot * p.st + b_dt[i] : 0, iy = oy * p.sh + b_dy[i];
-            const int ix0 = ox + b_dx[i];
+            const int ix0 = ox * SW + b_dx[i];
             bool ok = live && b_on[i];
             if (p.reflect) {
                 if (p.is3d) { it = it < 0 ? -it : it; it = it >= p.Ti ? 2 * p.Ti - 2 - it : it; }
                 iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
             }
             ok = ok && (unsigned)iy < (unsigned)p.Hi && (!p.is3d || (unsigned)it < (unsigned)p.Ti);
-            const int e = ix0 < 0 ? -1 : (ix0 + 8 > p.Wi ? 1 : 0);
-            redge[i] = ok ? e : 0;
-            const unsigned vo = ximg + b_off[i] + (unsigned)(it * (int)p.in_st + iy * (int)p.in_sh + (ix0 - e)) * 2u;
-            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? vo : C2M_OOB, 0, 0));
+            if constexpr (SW == 1) {
+                const int e = ix0 < 0 ? -1 : (ix0 + 8 > p.Wi ? 1 : 0);
+                redge[i] = ok ? e : 0;
+                const unsigned vo = ximg + b_off[i] + (unsigned)(it * (int)p.in_st + iy * (int)p.in_sh + (ix0 - e)) * 2u;
+                rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? vo : C2M_OOB, 0, 0));
+            } else {
+                // 16 elements from ix0 (from 0 when ix0 == -1: the wanted pixels are then the ODD elements 1, 3, .. 13 behind a
+                // pad element).  A right-end run reaches up to two elements past its row: in-bounds memory (the next row) except
+                // at the very end of the tensor, where the range check returns zeros -- that element is replaced in stash().
+                const int e = ix0 < 0 ? -1 : (ix0 + 14 >= p.Wi ? 1 : 0);
+                redge[i] = ok ? e : 0;
+                // a run whose 16th element is past the row end (dx = 1, 2 in the last group of a row) loads its second half
+                // one element EARLIER (elements 7 .. 14, wanted ones in the odd halves): at the end of the tensor the dword
+                // (x[Wi-1], x[Wi]) straddles the buffer's range and would come back as zero, x[Wi-1] included
+                const bool tail = e >= 0 && ix0 + 15 >= p.Wi;
+                rtail[i] = tail;
+                const unsigned vo = ximg + b_off[i] + (unsigned)(it * (int)p.in_st + iy * (int)p.in_sh + (e < 0 ? 0 : ix0)) * 2u;
+                rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? vo : C2M_OOB, 0, 0));
+                rb2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? vo + (tail ? 14u : 16u) : C2M_OOB, 0, 0));
+            }
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < AP; ++i)
             *reinterpret_cast<u32x4*>(&hA[wave * AROWS + 8 * i + rsub][8 * grp]) = ra[i];
+        if constexpr (SW == 2) {
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const u32x4 lo = rb[i], hi = rb2[i];
+                // even elements (0, 2, .. 14) of the 16-element run / odd elements (1, 3, .. 15) for a left-end group
+                const unsigned hsel = rtail[i] ? 0x07060302u : 0x05040100u;      // shifted second half: the odd halves
+                const u32x4 ev = {__builtin_amdgcn_perm(lo.y, lo.x, 0x05040100u), __builtin_amdgcn_perm(lo.w, lo.z, 0x05040100u),
+                                  __builtin_amdgcn_perm(hi.y, hi.x, hsel), __builtin_amdgcn_perm(hi.w, hi.z, hsel)};
+                const u32x4 od = {__builtin_amdgcn_perm(lo.y, lo.x, 0x07060302u), __builtin_amdgcn_perm(lo.w, lo.z, 0x07060302u),
+                                  __builtin_amdgcn_perm(hi.y, hi.x, 0x07060302u), __builtin_amdgcn_perm(hi.w, hi.z, 0x07060302u)};
+                // left end: (pad, x1, x3, .. x13): pad = x1 (reflect) or 0
+                const unsigned padl = p.reflect ? od.x & 0xffffu : 0u;
+                const u32x4 L = {(od.x << 16) | padl, __builtin_amdgcn_alignbit(od.y, od.x, 16), __builtin_amdgcn_alignbit(od.z, od.y, 16),
+                                 __builtin_amdgcn_alignbit(od.w, od.z, 16)};
+                // right end: the last element (pixel Wi) -> x[Wi-2] = the element before it (reflect) or 0
+                const u32x4 R = {ev.x, ev.y, ev.z, (ev.w & 0xffffu) | (p.reflect ? ev.w << 16 : 0u)};
+                rb[i] = redge[i] < 0 ? L : (redge[i] > 0 ? R : ev);
+            }
+        }
         bool any_edge = false;
 #pragma unroll
-        for (int i = 0; i < BP; ++i) any_edge = any_edge || redge[i] != 0;
+        for (int i = 0; i < BP; ++i) any_edge = any_edge || (SW == 1 && redge[i] != 0);
         if (__any(any_edge)) {                               // wave-uniform: most K-steps of a wide map hold no row end
 #pragma unroll
             for (int i = 0; i < BP; ++i) {
@@ -2372,6 +2413,16 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
     if (bf16 != xh) return (int)hipErrorInvalidValue;  // the bf16 kernel gathers bf16 tensors, the fp32 kernel fp32 ones
     const dim3 grid1(grid.x * grid.y * grid.z);       // 1-D launch, decoded XCD-aware in the kernel (common.h)
     // g[92] = 1: the layer qualifies for the 16-byte-load form (host: unit x stride, Wi == Wo, Wo % 8 == 0, |tap dx| <= 1)
+    if (bf16 && g[92] == 2 && !getenv("C2M_WGRAD_NARROW")) {      // the stride-2 form (host: sw == 2, Wi == 2 Wo, Wo % 8 == 0, dx in -1 .. 2)
+        if (p.sw != 2 || p.Wi != 2 * p.Wo || (p.Wo & 7) || (p.dy_sc & 7) || (p.pix_per_split & 63)) return (int)hipErrorInvalidValue;
+        if (p.M <= 32)      hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<32, 128, 1, 4, 2>), grid1, dim3(256), 0, s, p, NS);
+        else if (p.M > 64)  hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<128, 128, 2, 2, 2>), grid1, dim3(256), 0, s, p, NS);
+        else                hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<64, C2M_WG64_BN, 2, 2, 2>), grid1, dim3(256), 0, s, p, NS);
+        int rcw = (int)hipGetLastError();
+        if (rcw) return rcw;
+        const long totalw = (long)p.M * (ngroups + 1) * 16;
+        return launch_wgrad_reduce(totalw, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Seff);
+    }
     if (bf16 && g[92] == 1 && !getenv("C2M_WGRAD_NARROW")) {
         if (p.sw != 1 || p.Wi != p.Wo || (p.Wo & 7) || p.Wi < 8 || (p.dy_sc & 7) || (p.pix_per_split & 63)) return (int)hipErrorInvalidValue;
         if (p.M <= 32)      hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<32, 128, 1, 4>), grid1, dim3(256), 0, s, p, NS);

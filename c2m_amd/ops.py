@@ -83,6 +83,7 @@ _conv_bf16 = False
 # 8x16 regions and still beats the gather kernel by 14-30 % (tools/run_conv.py A/B); the 10x18 domain (35 %) does not
 _WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
 _WINO_MIN_WGS = int(os.environ.get("C2M_WINO_MIN_WGS", "128"))   # smallest Winograd forward / dgrad grid: 160 workgroups of a 1536-deep layer still beat the gather kernel 1.5x
+_WGRAD_WIDE_S2 = os.environ.get("C2M_WGRAD_WIDE_S2", "1") != "0"      # bf16 stride-2 weight gradient on the 16-byte-load kernel (A/B knob)
 _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect data gradient over unpadded frames (A/B knob)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
@@ -542,6 +543,9 @@ class _ConvPlan:
         # groups stay inside an input row up to one pad pixel: unit x stride, same-width output, |tap dx| <= 1
         self.wg_geom[92] = int(bf16 and sw == 1 and Wi == Wo and Wo % 8 == 0 and Wi >= 8 and kw in (1, 3)
                                and pw == (kw - 1) // 2 and osp % 8 == 0)
+        # ... and its stride-2 form (4-wide taps, pad 1: dx = -1 .. 2; every second element of a 16-element run)
+        if bf16 and _WGRAD_WIDE_S2 and sw == 2 and Wi == 2 * Wo and Wo % 8 == 0 and kw == 4 and pw == 1 and osp % 8 == 0:
+            self.wg_geom[92] = 2
         self.wg_splits = L.c2m_conv_wgrad_splits(Cout, self.J, N * osp)
         # ---- dgrad: one launch per stride-parity class
         Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)

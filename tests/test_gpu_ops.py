@@ -61,6 +61,11 @@ CONV_CASES = [
     ((2, 6, 5, 6, 8), 4, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
     ((1, 34, 5, 16, 32), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "reflect"),
     ((1, 40, 24, 64), 200, (3, 3), 1, 1, "reflect"),    # bf16 LDS-patch kernel: 2 row blocks of 128, padded last chunk
+    # bf16 stride-2 weight gradient on the 16-byte-load kernel (every second element of a 16-element run; Wo % 8 == 0):
+    # several groups per row, one group per row (left AND right end), zeros and reflect, 64- / 128- / 32-row tiles, 3-D
+    ((2, 24, 16, 64), 72, (4, 4), 2, 1, "reflect"),
+    ((3, 8, 12, 16), 136, (4, 4), 2, 1, "zeros"),
+    ((2, 16, 3, 8, 32), 24, (3, 4, 4), (1, 2, 2), (1, 1, 1), "reflect"),
 ]
 
 
