@@ -114,7 +114,12 @@ class TrainStep:
             graph = torch.cuda.CUDAGraph()
             U.begin_deferred_nan()
             try:
-                with torch.cuda.graph(graph, stream=side):
+                # With a process group alive its watchdog THREAD polls the completion events of earlier collectives; in the default
+                # ("global") capture mode any such HIP call from another thread during the capture is an error that takes the
+                # process down ("operation not permitted when stream is capturing" -- seen once in ~6 runs of
+                # test_bench_graph_replay_with_the_reducer).  Thread-local mode restricts the check to the capturing thread.
+                mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+                with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
                     outputs = self._eager(data, in_capture=True)
             finally:
                 self._deferred_nan = U.end_deferred_nan()
