@@ -8,6 +8,26 @@ import torch.nn.functional as F
 from torch import nn
 
 
+_adj_cache = {}      # capturing? -> (weakref(edge_index), version, data_ptr, N, dtype, A)
+
+
+def _edge_multiplicity(edge_index, dst, src, N, dtype):
+    """A[i, j] = number of edges j -> i.  Every GATv2 layer of a step sees the same edge_index (10 calls per generator step), and
+    the accumulate-index_put_ that builds A is a chain of ~8 small kernels (bounds asserts, index arithmetic, sort): built once
+    per edge_index tensor (object, version and address; separately inside a HIP-graph capture, whose tensors live in the
+    graph's pool).  The accumulation adds exact 1.0s, so the result does not depend on the order."""
+    import weakref
+    cap = bool(edge_index.is_cuda and torch.cuda.is_current_stream_capturing())
+    hit = _adj_cache.get(cap)
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == edge_index.data_ptr() \
+            and hit[3] == N and hit[4] == dtype:
+        return hit[5]
+    A = torch.zeros(N, N, dtype=dtype, device=edge_index.device).index_put_((dst, src), torch.ones_like(dst, dtype=dtype),
+                                                                           accumulate=True)
+    _adj_cache[cap] = (weakref.ref(edge_index), edge_index._version, edge_index.data_ptr(), N, dtype, A)
+    return A
+
+
 class GATv2Conv(nn.Module):
     """GATv2 (Brody et al.) with PyG's parameterisation: lin_l / lin_r (bias), att [1,H,C], bias [C];
     heads averaged (concat=False), no self loops, softmax over the incoming edges of each target node."""
@@ -40,8 +60,7 @@ class GATv2Conv(nn.Module):
             # (whose float atomics are the one run-to-run nondeterminism torch would add to the step), and a formulation
             # independent of the edge-list restatement the oracle uses (oracle/thirdparty.py::gatv2_conv), so comparing the two
             # is a real check of both.
-            A = torch.zeros(N, N, dtype=x.dtype, device=x.device).index_put_((dst, src), torch.ones_like(dst, dtype=x.dtype),
-                                                                            accumulate=True)
+            A = _edge_multiplicity(edge_index, dst, src, N, x.dtype)
             e = F.leaky_relu(xl.unsqueeze(0) + xr.unsqueeze(1), self.negative_slope)          # [i, j, H, C]
             logit = (e * self.att).sum(-1)                                                     # [i, j, H]
             logit = logit.masked_fill(A.unsqueeze(-1) == 0, float("-inf"))
