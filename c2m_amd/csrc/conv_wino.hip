@@ -41,7 +41,7 @@ struct WinoP {
     // [lo, lo + ext) go straight to the unpadded gradient Y2, only the pad ring is written to Y (c2m_reflect_border_add
     // then folds the ring)
     float* Y2;
-    long y2_sn, y2_sc, y2_sh;
+    long y2_sn, y2_sc, y2_sh, y2_st;         // y2_st: frame stride of Y2 (3x3x3 layers; 0 for 2-D)
     int lo_y, lo_x, ext_y, ext_x;
     // 3x3x3 convolutions as a 2-D Winograd over "virtual" input channels (time tap, channel): image = (sample n, frame t),
     // virtual channel v = kt * cin + ci reads frame t + kt + toff of channel ci (reflected in time or absent -> zero records).
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
         const int yi = oy - p.lo_y, xi = ox - p.lo_x;
         if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y) {
             const bool in0 = (unsigned)xi < (unsigned)p.ext_x, in1 = (unsigned)(xi + 1) < (unsigned)p.ext_x;
-            yb1 = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
+            yb1 = p.Y2 + (long)smp * p.y2_sn + (long)frm * p.y2_st + (long)yi * p.y2_sh + xi;
             cs1 = p.y2_sc;
             mode = (in0 && in1) ? 1 : ((in0 || in1) ? 2 : 0);
         }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
         if (p.Y2 && (unsigned)yi < (unsigned)p.ext_y) {
             const bool in0 = (unsigned)xi < (unsigned)p.ext_x, in1 = (unsigned)(xi + 1) < (unsigned)p.ext_x,
                        in2 = (unsigned)(xi + 2) < (unsigned)p.ext_x, in3 = (unsigned)(xi + 3) < (unsigned)p.ext_x;
-            yb1 = p.Y2 + (long)img * p.y2_sn + (long)yi * p.y2_sh + xi;
+            yb1 = p.Y2 + (long)smp * p.y2_sn + (long)frm * p.y2_st + (long)yi * p.y2_sh + xi;
             cs1 = p.y2_sc;
             // the interior is shifted by the pad against the padded domain, so its 16-byte stores are only dword aligned
             // (fine for global_store_dwordx4); groups that straddle the interior's edge are stored per pixel
@@ -646,7 +646,7 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     C2M_ENTER();
     WinoP p;
     p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
-    p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
+    p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = p.y2_st = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
     if (Y_interior) {
         p.y2_sn = g[18]; p.y2_sc = g[19]; p.y2_sh = g[20];
         p.lo_y = (int)g[21]; p.lo_x = (int)g[22]; p.ext_y = (int)g[23]; p.ext_x = (int)g[24];
@@ -662,7 +662,8 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.Ti = (int)g[31]; p.treflect = (int)g[32];
     p.ptab = (const int*)(uintptr_t)g[33]; p.cpk = 0;
     if (p.nkt) {
-        if (Y_interior || p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
+        if (p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
+        if (Y_interior) p.y2_st = (long)p.ext_y * p.y2_sh;      // frames of the interior target are dense [ext_y][y2_sh] planes
         if (p.ptab) {
             if (p.cin % CKW) return (int)hipErrorInvalidValue;
             p.cpk = p.cin / CKW;

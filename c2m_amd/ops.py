@@ -494,6 +494,9 @@ class _ConvPlan:
                 if self.wino3d_pairs:
                     self.wino_pair_tab = torch.from_numpy(_time_pair_table(Ti).reshape(-1)).to(device)
                     self.wino_dgrad_geom[33] = self.wino_pair_tab.data_ptr()
+                    # every launched frame is a real one: the two-target epilogue of the 2-D layers applies per frame (interior
+                    # straight into dX, only the pad ring into the scratch tensor; then the border-only fold)
+                    self.wino_dgrad_geom[18:25] = (Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi)
             # weight gradient: the 2-D Winograd wgrad kernel over images (sample, frame) and virtual channels (kt, ci)
             wrows = 32 if Cout <= 32 else 64
             wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, wrows)
@@ -828,13 +831,18 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
         g3 = pl.wino_dgrad_geom
         npix = int(g3[2] * g3[5] * g3[6])
         tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+        two = pl.reflect and pl.wino3d_pairs
         _lib.check(_timed("wino", pl.dgrad_flops,
-                          lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), None, None, _gp(g3), 0, 0.0, _stream()), tag,
+                          lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if two else None, None, _gp(g3), 0, 0.0,
+                                                  _stream()), tag,
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad 3-D")
         if pl.reflect:
             Ti, Hi, Wi = pl.dims[3:6]
-            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0 if pl.wino3d_pairs else 1, 1, 1, 0,
-                                          _stream()), "reflect fold 3-D")
+            if two:
+                _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, 0, _stream()),
+                           "reflect border add 3-D")
+            else:
+                _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 1, 1, 1, 0, _stream()), "reflect fold 3-D")
         if dM < Cin:
             gx[:, dM:].zero_()
     elif pl.wino_dgrad:

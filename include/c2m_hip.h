@@ -104,7 +104,9 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
  *         33 temporal pair table (device pointer as an integer, or 0): the data gradient of a 3x3x3 layer with reflect
  *         padding in time, launched over the UNPADDED frames -- int32 ptab[To][11] = {npairs, (source frame of dY, U block
  *         = flipped time tap) x 5}: output frame t sums the pairs (to, kt) with reflect(to + kt - 1) == t (needs cin % 8
- *         == 0; toff / treflect are ignored).  geom[] always holds 34 entries.                                         */
+ *         == 0; toff / treflect are ignored).  With the pair table every launched frame is a real one, so Y_interior may be
+ *         given for a 3x3x3 layer too (frames of Y_interior are dense [ext_y][y2_sh] planes inside each channel).
+ *         geom[] always holds 34 entries.                                                                           */
 long c2m_wino_upack_floats(int M, int K);
 int c2m_wino_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
 /* Regions (workgroup tiles of <= 32 Winograd tiles) per image c2m_conv_wino uses for an Ho x Wo output domain: 8 x 16
