@@ -35,10 +35,18 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     const int cnt = (int)(end - beg);
     const bool vec = (S & 3) == 0 && ((uintptr_t)x & C2mVec4<T>::mask) == 0;      // chunk bounds are multiples of 4 then
     float s = 0.f;
+    // a chunk is at most 8 float4 per thread: they stay in registers for the second (centred) pass -- the first form read the
+    // chunk twice (the second time from L2); same arithmetic in the same order, so the statistics keep their bits
+    constexpr int NV = NORM_CHUNK / 1024;
+    float4 keep[NV];
     if (vec) {
-        for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            const float4 v = c2m_ld4(p + i);
-            s += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const long i = beg + threadIdx.x * 4 + (long)k * 1024;
+            if (i < end) {
+                keep[k] = c2m_ld4(p + i);
+                s += (keep[k].x + keep[k].y) + (keep[k].z + keep[k].w);
+            }
         }
     } else {
         for (long i = beg + threadIdx.x; i < end; i += 256) s += c2m_ld(p, i);
@@ -47,10 +55,13 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     const float mean = s / (float)cnt;
     float m2 = 0.f;
     if (vec) {
-        for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            const float4 v = c2m_ld4(p + i);
-            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-            m2 += (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const long i = beg + threadIdx.x * 4 + (long)k * 1024;
+            if (i < end) {
+                const float a = keep[k].x - mean, b = keep[k].y - mean, c = keep[k].z - mean, d = keep[k].w - mean;
+                m2 += (a * a + b * b) + (c * c + d * d);
+            }
         }
     } else {
         for (long i = beg + threadIdx.x; i < end; i += 256) { const float d = c2m_ld(p, i) - mean; m2 += d * d; }
