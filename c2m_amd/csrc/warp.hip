@@ -565,10 +565,23 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const T* __res
     const int y0 = ty * UB_TY, x0 = tx * UB_TX;
     const int gy0 = 2 * y0 - 1, gx0 = 2 * x0 - 1;
     const T* __restrict__ g = gout + (long)nc * Ho * Wo;
-    for (int e = threadIdx.x; e < UB_LR * UB_LC; e += 256) {
-        const int r = e / UB_LC, c = e - r * UB_LC;
-        const int gy = gy0 + r, gx = gx0 + c;
-        tile[r][c] = ((unsigned)gy < (unsigned)Ho && (unsigned)gx < (unsigned)Wo) ? c2m_ld(g, gy * Wo + gx) : 0.0f;
+    // tile column c is output column gx0 + c with gx0 = 2 x0 - 1 odd: columns 1 .. UB_LC - 2 are (even, odd) pairs -> one
+    // aligned 2-element load each (8 B of fp32 / 4 B of bf16; Wo is even, so a pair is inside the row or outside as a whole),
+    // columns 0 and UB_LC - 1 single elements.  (The first form fetched every element with its own 4-byte load.)
+    constexpr int UB_UNITS = UB_LC / 2 + 1;                   // per row: [col 0] [pairs (1,2) .. (UB_LC-3, UB_LC-2)] [col UB_LC-1]
+    for (int e = threadIdx.x; e < UB_LR * UB_UNITS; e += 256) {
+        const int r = e / UB_UNITS, u = e - r * UB_UNITS;
+        const int gy = gy0 + r;
+        const bool rok = (unsigned)gy < (unsigned)Ho;
+        if (u == 0 || u == UB_UNITS - 1) {
+            const int c = u == 0 ? 0 : UB_LC - 1, gx = gx0 + c;
+            tile[r][c] = (rok && (unsigned)gx < (unsigned)Wo) ? c2m_ld(g, gy * Wo + gx) : 0.0f;
+        } else {
+            const int c = 2 * u - 1, gx = gx0 + c;            // gx even
+            float2 v = make_float2(0.0f, 0.0f);
+            if (rok && (unsigned)gx < (unsigned)Wo) v = c2m_ld2(g + (long)gy * Wo + gx);
+            tile[r][c] = v.x; tile[r][c + 1] = v.y;
+        }
     }
     __syncthreads();
     const int ly = threadIdx.x >> 5, l = threadIdx.x & 31;
@@ -626,7 +639,7 @@ C2M_API int c2m_upsample2x_bwd(const void* gout_, void* gin_, long NC, int Hi, i
     const long total = NC * Hi * Wi;
     if (total <= 0) return 0;
     if (dt == C2M_BF16) {
-        if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31)) {            // LDS-tiled form (fp32 window in LDS)
+        if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31) && (((uintptr_t)gout_) & 3) == 0) {   // LDS-tiled form (fp32 window in LDS; 2-element loads)
             const int tx = Wi >= 64 ? 64 : 32;
             const long tiles = (long)c2m_cdiv(Wi, tx) * c2m_cdiv(Hi, UB_TY) * NC;
             if (tiles < (1L << 31)) {
@@ -641,7 +654,7 @@ C2M_API int c2m_upsample2x_bwd(const void* gout_, void* gin_, long NC, int Hi, i
         return (int)hipGetLastError();
     }
     const float* gout = (const float*)gout_; float* gin = (float*)gin_;
-    if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31)) {
+    if (Wi >= 32 && Hi >= 8 && total * 4 < (1L << 31) && (((uintptr_t)gout) & 7) == 0) {     // (2-element loads of the window)
         const int tx = Wi >= 64 ? 64 : 32;
         const long tiles = (long)c2m_cdiv(Wi, tx) * c2m_cdiv(Hi, UB_TY) * NC;
         if (tiles < (1L << 31)) {
