@@ -241,9 +241,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="the HIP events around every conv launch (roofline object) are recorded in every k-th step of the timed "
-                         "region: ~600 event records cost the step ~1 ms of GPU time (71.2 vs 72.2 ms); 1 = every step")
+                         "region: ~600 event records cost a step ~1 ms of GPU time (71.2 vs 72.2 ms with them in every step); 1 = every step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="conv operand precision: f32 = BASELINE configs[1] (the bench line); bf16 = configs[2-4] mode")
     ap.add_argument("--full-step", action="store_true", default=None,
