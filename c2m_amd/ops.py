@@ -407,6 +407,9 @@ class _ConvPlan:
         To, Ho, Wo = (Ti + 2 * pt - kt) // st + 1, (Hi + 2 * ph - kh) // sh + 1, (Wi + 2 * pw - kw) // sw + 1
         if min(To, Ho, Wo) <= 0:
             raise ValueError("empty convolution output")
+        if kt * kh * kw > 128:
+            raise NotImplementedError(f"conv kernels with more than 128 taps ({kt}x{kh}x{kw}) are not on the C2M path "
+                                      "(c2m_pack_weights / the gather tables hold 128 tap offsets)")
         if reflect and (pt >= Ti and pt > 0 or ph >= Hi and ph > 0 or pw >= Wi and pw > 0):
             raise ValueError("reflect padding must be smaller than the input extent")
         if 4 * N * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo) >= 2 ** 31:

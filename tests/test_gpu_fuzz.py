@@ -1,0 +1,27 @@
+"""Random-geometry conv parity sweep (tools/fuzz_conv.py) as a test: forward, data gradient, weight / bias gradient of ops.conv
+against torch's float64 CPU convolution on geometries the hand-written case lists do not enumerate, in both precision modes."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [["--seed", "11"], ["--seed", "12", "--bf16"]], ids=["fp32", "bf16"])
+def test_random_conv_geometries_vs_float64_reference(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_conv.py"), "--cases", "120"] + extra, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "0 failures" in out.stdout
+
+
+def test_more_than_128_taps_is_refused_loudly():
+    from c2m_amd import ops
+    x = torch.randn(1, 4, 3, 8, 8, device="cuda:0")
+    w = torch.randn(4, 4, 3, 7, 7, device="cuda:0")
+    with pytest.raises(NotImplementedError, match="128 taps"):
+        ops.conv(x, w, None, stride=1, padding=(1, 3, 3))
