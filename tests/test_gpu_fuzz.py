@@ -25,3 +25,12 @@ def test_more_than_128_taps_is_refused_loudly():
     w = torch.randn(4, 4, 3, 7, 7, device="cuda:0")
     with pytest.raises(NotImplementedError, match="128 taps"):
         ops.conv(x, w, None, stride=1, padding=(1, 3, 3))
+
+
+def test_random_norm_pool_resize_shapes_vs_float64_reference():
+    """tools/fuzz_ops.py: norm + activation (BN / IN / SPADE, fwd + every gradient), x2 up-sampling, 2x2 max-pool, bilinear resize
+    and masked L1 on odd extents around the kernels' chunk / vector / tile boundaries."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ops.py"), "--cases", "250", "--seed", "3"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "0 failures" in out.stdout
