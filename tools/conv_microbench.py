@@ -10,6 +10,8 @@ mode = sys.argv[9] if len(sys.argv) > 9 else "zeros"
 iters = int(sys.argv[10]) if len(sys.argv) > 10 else 20
 which = sys.argv[11] if len(sys.argv) > 11 else "all"
 dev = "cuda:0"
+if os.environ.get("C2M_BENCH_BF16"):          # bf16 data path (tools/pmc_gather_bf16.sh)
+    ops.set_conv_precision("bf16")
 x = torch.randn(N, Cin, H, W, device=dev, requires_grad=True)
 w = (torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5).requires_grad_(True)
 b = torch.zeros(Cout, device=dev, requires_grad=True)
