@@ -1,0 +1,431 @@
+// WORK IN PROGRESS -- NOT part of libc2m_hip.so (c2m_amd/build.py does not compile this file; nothing in c2m_amd/ refers to it).
+// Status at the end of round 3: the kernel computes correct results (forward of 2x5x9x11 -> 7 reflect: 1.2e-6 of scale;
+// 2x16x16x32 -> 32 and 1x16x16x32 -> 32 zeros: 3.0e-6 / 3.1e-6; all gates of tests/test_gpu_ops.py would hold), 240 VGPRs, no
+// scratch, but launches with >= 2 output images INTERMITTENTLY raise a GPU memory access fault or return NaNs in the last
+// image (same binary, same inputs: 1 run in 2 ... 5 in 7).  Not found by inspection of the ISA: every VMEM instruction's
+// descriptor, scalar offset and LDS target was traced (DMA soffset induction, zero-record select, U soffset, M0 values); the
+// fault does not depend on whether the DMA targets sit above or below 64 KB of LDS.  Open suspects: LDS-DMA with a 135 KB LDS
+// allocation / 8-wave workgroups (the shipped F(2x2,3x3) kernel issues the same instruction forms from 4-wave workgroups with
+// 52 KB), ds_read of the per-row source offset between two DMA instructions.  Host glue that was used (ops.py routing knob
+// C2M_WINO4, _lib signatures, a forced-mode parity test over every 2-D Winograd case) is in the round-3 session log / git
+// history of this file's first commit message; tools/wino43_error.py holds the fp32 error model, tools/dbg_wino4.py the
+// sentinel-gap harness.  Round-4 plan: DESIGN.md section 5.5.
+//
+// conv_wino4.hip -- Winograd F(4x4, 3x3) convolution for the deep 3x3 stride-1 2-D layers (the same call sites as conv_wino.hip:
+// layers/vgg.py:92-137, residual_block.py:13-31,42-71, spade_block.py:47-49 and their data gradients), fp32 on
+// v_mfma_f32_32x32x2_f32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 6x6 input tile, g: 3x3 filter, Y: 4x4 outputs     (Lavin & Gray, points 0, +-1, +-2, inf)
+// 36 multiplies per 16 outputs instead of 144: the contraction over input channels becomes 36 independent GEMMs with 4x fewer
+// MFMA FLOPs than the direct form (F(2x2,3x3): 2.25x).  The transforms are no longer exact scalings (1/6, 1/24 in G; 4, 5, 8 in B
+// and A): in fp32 the result differs from a float64 convolution by 3.5e-6 ... 7e-6 of the tensor's scale on the bench model's
+// layers (tools/wino43_error.py; F(2x2,3x3): 2e-7 ... 3e-7) -- inside the conv tests' 2e-5 / 5e-5 gates.
+//
+// One workgroup = 512 threads = 8 waves = ONE per CU (two waves per SIMD): 64 output channels x a 16x32 output region (4 x 8
+// tiles = the 32 MFMA columns) of one image.  Wave w: output-channel half wm = w & 1, frequency group fg = w >> 1 (frequencies
+// 9 fg .. 9 fg + 8): 9 x 16 = 144 accumulator registers.  Per 8-channel chunk:
+//   * the 8 x 18 x 34 input patch arrives by LDS-DMA two chunks ahead (three buffers; wave w fetches channel w, the per-lane
+//     source offsets -- reflect / bounds resolved once -- sit in a 640-entry LDS table);
+//   * thread (channel tk, tile tn, half h) transforms three rows of V = B^T d B of its 6x6 tile into V[xi][k][tile] in LDS
+//     (double buffered);
+//   * the U = G g G^T fragments come from L2 in a pre-packed order (c2m_wino4_filter_transform), 9 x 16 bytes per lane;
+//   * 36 MFMAs per wave.
+// The two waves of a SIMD run the interval's two phases in OPPOSITE order (waves 0-3: MFMAs, then transform of the next chunk;
+// waves 4-7: transform, then MFMAs), so one wave's LDS / VALU phase sits under the other's matrix phase without any
+// instruction-level interleaving.  The inverse transform goes through LDS in four passes of 16 output channels: raw accumulators
+// [xi][cout][tile] -> one thread per (cout, tile) computes A^T m A, adds the bias, applies the activation and stores four
+// 16-byte row segments (or per pixel into Y / Y_interior for the two-target data gradient of reflect-padded layers).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define W4_OOB 0x80000000u
+
+struct Wino4P {
+    const float* U;      // packed filter transform (wino4_filter_kernel)
+    const float* X;
+    float* Y;
+    const float* bias;
+    float* Y2;           // optional second target (see conv_wino.hip: interior of a padded-domain data gradient)
+    long y2_sn, y2_sc, y2_sh;
+    int lo_y, lo_x, ext_y, ext_x;
+    int M, K, nimg;
+    int Hi, Wi, Ho, Wo;
+    int iy0, ix0;
+    int reflect;
+    long in_sn, out_sn, out_sc, out_sh, out_off;
+    int in_sc, in_sh;
+    unsigned x_bytes;
+    int nchunks, mtiles;
+    int act;
+    float slope;
+};
+
+constexpr int W4_CK = 8;                              // channels per chunk
+constexpr int W4_TH = 4, W4_TW = 8;                   // tiles per region: 16 x 32 outputs
+constexpr int W4_OR = 4 * W4_TH, W4_OC = 4 * W4_TW;   // output region rows / cols
+constexpr int W4_PH = W4_OR + 2, W4_PW = W4_OC + 2;   // 18 x 34 input patch
+constexpr int W4_PPOS = W4_PH * W4_PW;                // 612 positions per channel
+constexpr int W4_ROWS = (W4_PPOS + 63) / 64;          // 10 DMA rows of 64 positions
+constexpr int W4_PCS = W4_ROWS * 64;                  // channel stride of the patch in LDS
+constexpr int W4_PBUF = W4_CK * W4_PCS;               // one patch buffer (floats)
+constexpr int W4_VBUF = 36 * W4_CK * 32;              // one V buffer (floats)
+
+// the 6-point transform B^T (same for rows and columns)
+#define W4_BT(o0, o1, o2, o3, o4, o5, x0, x1, x2, x3, x4, x5) \
+    do {                                                      \
+        const float a_ = (x4) - 4.f * (x2), b_ = (x3) - 4.f * (x1), c_ = (x4) - (x2), e_ = 2.f * ((x3) - (x1)); \
+        o0 = 4.f * (x0) - 5.f * (x2) + (x4);                  \
+        o1 = a_ + b_; o2 = a_ - b_; o3 = c_ + e_; o4 = c_ - e_; \
+        o5 = 4.f * (x1) - 5.f * (x3) + (x5);                  \
+    } while (0)
+
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
+    // ONE LDS block with the DMA targets first: the LDS address of a buffer_load ... lds travels in M0, and only destinations
+    // below 64 KB behaved (with the patches behind the 72 KB of V -- addresses 0x12000 ... 0x21000 -- results were intermittently
+    // wrong and a launch faulted)
+    __shared__ __attribute__((aligned(16))) float smem[3 * W4_PBUF + W4_PCS + 2 * W4_VBUF];
+#define sP (smem)                                              /* input patches [buf][k][18][34] (+pad): 60 KB, LDS-DMA two chunks ahead */
+#define sVo (reinterpret_cast<unsigned*>(smem + 3 * W4_PBUF))  /* per patch position: byte offset inside X or W4_OOB */
+#define sV (smem + 3 * W4_PBUF + W4_PCS)                       /* V[buf][xi][k][tile]; reused by the epilogue */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, fg = wave >> 1;
+    const bool t_first = (wave >> 2) & 1;             // waves w and w + 4 share a SIMD: opposite phase order
+    const int regions_x = (p.Wo + W4_OC - 1) / W4_OC, regions_y = (p.Ho + W4_OR - 1) / W4_OR;
+    // XCD-aware work order (conv_wino.hip): item w = region * mtiles + mt, XCD x owns a contiguous range of items
+    int rb, mt;
+    {
+        const unsigned L = blockIdx.x, total = gridDim.x;
+        const unsigned q = total >> 3, r = total & 7u, x = L & 7u, j = L >> 3;
+        const unsigned w = x * q + (x < r ? x : r) + j;
+        mt = (int)(w % (unsigned)p.mtiles); rb = (int)(w / (unsigned)p.mtiles);
+    }
+    const int rx = rb % regions_x; rb /= regions_x;
+    const int ry = rb % regions_y; const int img = rb / regions_y;
+    const int oy0 = ry * W4_OR, ox0 = rx * W4_OC;
+    const int nchunks = p.nchunks;
+
+    // ---- patch source offsets (fixed over the K loop)
+    {
+        const unsigned img_byte = (unsigned)(img * (int)p.in_sn) * 4u;
+        for (int pos = tid; pos < W4_PCS; pos += 512) {
+            const int r = pos / W4_PW, c = pos % W4_PW;
+            int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + c;
+            if (p.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+            }
+            const bool ok = pos < W4_PPOS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            sVo[pos] = ok ? img_byte + (unsigned)(iy * p.in_sh + ix) * 4u : W4_OOB;
+        }
+    }
+    __syncthreads();
+
+    const unsigned long xaddr = (unsigned long)p.X;
+    const u32x4 rs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const unsigned sp_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&smem[0];
+    // wave w fetches channel w of a chunk: ten DMA rows of 64 positions.  A channel past K gets a zero-record descriptor (the
+    // scalar offset is outside the hardware's range check); lanes past position 611 and positions outside the image carry an
+    // out-of-range voffset and write zeros into the channel's own padding / halo.
+    auto load_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const int ch = chunk * W4_CK + wave;
+        u32x4 rsk = rs;
+        rsk[2] = (chunk < nchunks && ch < p.K) ? p.x_bytes : 0u;
+        const int soff = ch * p.in_sc * 4;
+#pragma unroll
+        for (int dr = 0; dr < W4_ROWS; ++dr) {
+            const unsigned vo = sVo[dr * 64 + lane];
+            const unsigned dst = sp_lds + (unsigned)((buf * W4_PBUF + wave * W4_PCS + dr * 64) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(vo), "s"(rsk), "s"(soff) : "memory");
+        }
+    };
+    // ---- U fragments: Upack[chunk][mt][wave][f][lane][kk]: every load of a wave reads 1 KB contiguous
+    const unsigned long uaddr = (unsigned long)p.U;
+    const u32x4 urs = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+    const unsigned uvo = (unsigned)((((mt * 8 + wave) * 9) * 64 + lane) * 16);
+    const unsigned ustride_b = (unsigned)p.mtiles * 8u * 9u * 64u * 16u;       // bytes per chunk
+    f32x4 ua[9];
+    auto load_u = [&](int chunk) __attribute__((always_inline)) {
+        const int s0 = (int)((unsigned)(chunk < nchunks ? chunk : 0) * ustride_b), s1 = s0 + 4096, s2 = s0 + 8192;
+#pragma unroll
+        for (int f = 0; f < 9; ++f)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                         : "=&v"(ua[f]) : "v"(uvo), "s"(urs), "s"(f < 4 ? s0 : (f < 8 ? s1 : s2)), "n"((f & 3) * 1024) : "memory");
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ---- input transform role: channel tk, tile tn = (ty, tx), rows 3h .. 3h + 2 of V
+    const int item = tid & 255, th = __builtin_amdgcn_readfirstlane(tid >> 8);      // th is wave-uniform (waves 0-3 / 4-7)
+    const int tk = item >> 5, tn = item & 31;
+    const int pbase = tk * W4_PCS + (4 * (tn >> 3)) * W4_PW + 4 * (tn & 7);
+    auto transform = [&](int pb, int vb) __attribute__((always_inline)) {
+        const float* __restrict__ src = sP + pb * W4_PBUF + pbase;
+        float t[3][6];
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {                      // column pairs
+            f32x2 d[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(src + r * W4_PW + 2 * cp);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e];
+                const int c = 2 * cp + e;
+                if (th == 0) {
+                    const float a_ = d4 - 4.f * d2, b_ = d3 - 4.f * d1;
+                    t[0][c] = 4.f * d0 - 5.f * d2 + d4; t[1][c] = a_ + b_; t[2][c] = a_ - b_;
+                } else {
+                    const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+                    t[0][c] = c_ + e_; t[1][c] = c_ - e_; t[2][c] = 4.f * d1 - 5.f * d3 + d5;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // one column pair at a time: 12 raw values live, not 36
+        }
+        float* __restrict__ v = sV + vb * W4_VBUF + tk * 32 + tn;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float o0, o1, o2, o3, o4, o5;
+            W4_BT(o0, o1, o2, o3, o4, o5, t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5]);
+            const int xi0 = 6 * (3 * th + a);
+            v[(xi0 + 0) * W4_CK * 32] = o0; v[(xi0 + 1) * W4_CK * 32] = o1; v[(xi0 + 2) * W4_CK * 32] = o2;
+            v[(xi0 + 3) * W4_CK * 32] = o3; v[(xi0 + 4) * W4_CK * 32] = o4; v[(xi0 + 5) * W4_CK * 32] = o5;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto mma = [&](int cur) __attribute__((always_inline)) {
+        const float* __restrict__ vb = sV + cur * W4_VBUF + (9 * fg * W4_CK + (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float b[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) b[f] = vb[(f * W4_CK + 2 * kk) * 32];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) {
+                const f32x4 u = ua[f];
+                const float av = kk == 0 ? u.x : (kk == 1 ? u.y : (kk == 2 ? u.z : u.w));
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[f], acc[f], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: patches 0 and 1, U(0), V(0)
+    load_patch(0, 0);
+    load_patch(1, 1);
+    load_u(0);
+    asm volatile("s_waitcnt vmcnt(19)" ::: "memory");         // patch 0 has landed (patch 1 + U(0) may still be in flight)
+    __syncthreads();
+    transform(0, 0);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // patch 1 (this wave's part) complete before the first barrier
+    // Interval n: MFMAs of chunk n on V(n) / U(n); transform of chunk n + 1 (patch (n+1) % 3 -> V buffer (n+1) & 1); DMA of patch
+    // n + 2 issued first so that it has the whole interval to land.  VMEM order per wave: DMA(n+2) x 10, later U(n+1) x 9.
+    //   before the MFMAs:   vmcnt(10) -- U(n), issued in the previous interval, complete; the 10 DMA rows may be in flight
+    //   before the barrier: vmcnt(9)  -- DMA(n+2) complete; the 9 U loads may be in flight
+    int pn = 1;                                               // patch buffer of chunk n + 1
+    for (int n = 0; n < nchunks; ++n) {
+        __syncthreads();                                      // V(n) and patch(n+1) complete; V(n-1) and patch(n) are free
+        const int cur = n & 1;
+        const int dbuf = pn == 2 ? 0 : pn + 1;
+        load_patch(n + 2, dbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        // one definition point for the accumulators and the U registers (two copies of the interval under an if / else made the
+        // register allocator spill the U tuples at the join); only the transform is placed before or after the matrix phase
+        if (t_first) transform(pn, cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < 9; ++f) asm volatile("" : "+v"(ua[f]));
+        mma(cur);
+        load_u(n + 1);
+        if (!t_first) transform(pn, cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        pn = pn == 2 ? 0 : pn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of this workgroup may still write its LDS
+    __syncthreads();
+
+    // ---- inverse transform: four passes of 16 output channels through LDS
+    float* __restrict__ sR = sV;                              // [xi][16 cout][32 tiles]
+    const int etile = tid & 31, ecl = tid >> 5;               // epilogue role: one (cout, tile) per thread
+    const int ety = etile >> 3, etx = etile & 7;
+    const int oyb = oy0 + 4 * ety, oxb = ox0 + 4 * etx;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int pwm = pass >> 1, hf = pass & 1;
+        __syncthreads();
+        if (wm == pwm) {
+#pragma unroll
+            for (int f = 0; f < 9; ++f)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                    sR[((9 * fg + f) * 16 + rowl) * 32 + (lane & 31)] = hf ? acc[f][8 + rr] : acc[f][rr];
+                }
+        }
+        __syncthreads();
+        const int cout = mt * 64 + pwm * 32 + hf * 16 + ecl;
+        float y[4][4];
+        {
+            float s[6][4];                                     // m A  (columns 6 -> 4)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float* __restrict__ q = sR + ((6 * i) * 16 + ecl) * 32 + etile;
+                const float m0 = q[0], m1 = q[16 * 32], m2 = q[2 * 16 * 32], m3 = q[3 * 16 * 32], m4 = q[4 * 16 * 32], m5 = q[5 * 16 * 32];
+                const float pp = m1 + m2, nn = m1 - m2, PP = m3 + m4, NN = m3 - m4;
+                s[i][0] = m0 + pp + PP; s[i][1] = nn + 2.f * NN; s[i][2] = pp + 4.f * PP; s[i][3] = nn + 8.f * NN + m5;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                      // A^T (rows 6 -> 4)
+                const float pp = s[1][c] + s[2][c], nn = s[1][c] - s[2][c], PP = s[3][c] + s[4][c], NN = s[3][c] - s[4][c];
+                y[0][c] = s[0][c] + pp + PP; y[1][c] = nn + 2.f * NN; y[2][c] = pp + 4.f * PP; y[3][c] = nn + 8.f * NN + s[5][c];
+            }
+        }
+        if (cout < p.M) {
+            const float bb = p.bias ? p.bias[cout] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oyb + r;
+                if (oy >= p.Ho) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) y[r][c] = c2m_act(y[r][c] + bb, p.act, p.slope);
+                float* __restrict__ yb0 = p.Y + p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + oxb;
+                if (!p.Y2 && oxb + 3 < p.Wo) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    const f32x4u vv = {y[r][0], y[r][1], y[r][2], y[r][3]};
+                    *reinterpret_cast<f32x4u*>(yb0) = vv;
+                } else {
+                    const int yi = oy - p.lo_y;
+                    const bool row_in = p.Y2 && (unsigned)yi < (unsigned)p.ext_y;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (oxb + c >= p.Wo) continue;
+                        const int xi = oxb + c - p.lo_x;
+                        if (row_in && (unsigned)xi < (unsigned)p.ext_x)
+                            p.Y2[(long)img * p.y2_sn + (long)cout * p.y2_sc + (long)yi * p.y2_sh + xi] = y[r][c];
+                        else
+                            yb0[c] = y[r][c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+#undef sP
+#undef sVo
+#undef sV
+
+// Filter transform U = G g G^T (6x6), G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]],
+// written in the fragment order the kernel reads:
+//   Upack[chunk][mt][wave = (fg << 1) | wm][f][lane][kk] = U[xi = 9 fg + f][m = mt*64 + wm*32 + (lane & 31)][c = chunk*8 + 2kk + (lane >> 5)]
+// dgrad as in wino_filter_kernel (conv_wino.hip): m = input channel, c = output channel, g = w[c][m] rotated by 180 degrees.
+__global__ void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int K, int Cin_native,
+                                    int dgrad, int mtiles, long pairs) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i & 3); long r = i >> 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int wm = (int)(r & 1); r >>= 1;
+        const int mt = (int)(r % mtiles); const int chunk = (int)(r / mtiles);
+        const int m = mt * 64 + wm * 32 + (lane & 31), c = chunk * W4_CK + 2 * kk + (lane >> 5);
+        float u[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) u[a][b2] = 0.f;
+        if (m < M && c < K) {
+            const float* __restrict__ g = dgrad ? w + ((long)c * Cin_native + m) * 9 : w + ((long)m * Cin_native + c) * 9;
+            float gg[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) gg[a][b2] = dgrad ? g[(2 - a) * 3 + (2 - b2)] : g[a * 3 + b2];
+            float row[6][3];                                   // G g
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) {
+                const float g0 = gg[0][b2], g1 = gg[1][b2], g2 = gg[2][b2];
+                row[0][b2] = 0.25f * g0;
+                row[1][b2] = -(1.f / 6.f) * ((g0 + g2) + g1);
+                row[2][b2] = -(1.f / 6.f) * ((g0 + g2) - g1);
+                row[3][b2] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+                row[4][b2] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+                row[5][b2] = g2;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {                      // (G g) G^T
+                const float r0 = row[a][0], r1 = row[a][1], r2 = row[a][2];
+                u[a][0] = 0.25f * r0;
+                u[a][1] = -(1.f / 6.f) * ((r0 + r2) + r1);
+                u[a][2] = -(1.f / 6.f) * ((r0 + r2) - r1);
+                u[a][3] = (1.f / 24.f) * r0 + (1.f / 12.f) * r1 + (1.f / 6.f) * r2;
+                u[a][4] = (1.f / 24.f) * r0 - (1.f / 12.f) * r1 + (1.f / 6.f) * r2;
+                u[a][5] = r2;
+            }
+        }
+        const long base = ((long)chunk * mtiles + mt) * 8;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) {
+                const int xi = 6 * a + b2, fgi = xi / 9, f = xi % 9;
+                up[((((base + ((fgi << 1) | wm)) * 9 + f) * 64 + lane) << 2) + kk] = u[a][b2];
+            }
+    }
+}
+
+C2M_API long c2m_wino4_upack_floats(int M, int K) {
+    return 36L * (c2m_cdiv(M, 64) * 64L) * (c2m_cdiv(K, W4_CK) * (long)W4_CK);
+}
+
+// w: native [Cout][Cin][3][3].  dgrad = 0: M = Cout, K = Cin;  dgrad = 1: M = Cin, K = Cout.
+C2M_API int c2m_wino4_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream) {
+    C2M_ENTER();
+    const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+    if (M <= 0 || K <= 0) return 0;
+    const long total = c2m_wino4_upack_floats(M, K);
+    if (total * 4 >= 0xffffffffL) return (int)hipErrorInvalidValue;         // the kernel addresses U through a 4 GB buffer record
+    hipLaunchKernelGGL(wino4_filter_kernel, dim3(c2m_grid(total / 36, 256)), dim3(256), 0, (hipStream_t)stream, w, upack, M,
+                       K, Cin, dgrad, c2m_cdiv(M, 64), total / 36);
+    return (int)hipGetLastError();
+}
+
+// regions (16 x 32 outputs) per image
+C2M_API int c2m_wino4_regions(int Ho, int Wo) { return c2m_cdiv(Ho, W4_OR) * c2m_cdiv(Wo, W4_OC); }
+
+// geom[]: the 2-D entries of c2m_conv_wino (0 .. 24); 3x3x3 layers (geom[29] != 0) and the temporal pair table are refused.
+C2M_API int c2m_conv_wino4(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
+                           const int64_t* g, int act, float slope, void* stream) {
+    C2M_ENTER();
+    Wino4P p;
+    p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
+    p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
+    if (Y_interior) {
+        p.y2_sn = g[18]; p.y2_sc = g[19]; p.y2_sh = g[20];
+        p.lo_y = (int)g[21]; p.lo_x = (int)g[22]; p.ext_y = (int)g[23]; p.ext_x = (int)g[24];
+    }
+    p.M = (int)g[0]; p.K = (int)g[1]; p.nimg = (int)g[2];
+    p.Hi = (int)g[3]; p.Wi = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
+    p.iy0 = (int)g[7]; p.ix0 = (int)g[8]; p.reflect = (int)g[9];
+    p.in_sn = g[10]; p.in_sc = (int)g[11]; p.in_sh = (int)g[12];
+    p.out_sn = g[13]; p.out_sc = g[14]; p.out_sh = g[15]; p.out_off = g[16];
+    if (g[17] <= 0 || g[17] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[17];
+    if (g[29] != 0 || g[33] != 0) return (int)hipErrorInvalidValue;
+    p.act = act; p.slope = slope;
+    if (p.M <= 0 || p.K <= 0 || p.nimg <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
+    if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;
+    p.nchunks = c2m_cdiv(p.K, W4_CK);
+    p.mtiles = c2m_cdiv(p.M, 64);
+    if (c2m_wino4_upack_floats(p.M, p.K) * 4 >= 0xffffffffL) return (int)hipErrorInvalidValue;
+    const long regions = (long)p.nimg * c2m_wino4_regions(p.Ho, p.Wo);
+    if (regions * p.mtiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)(regions * p.mtiles)), dim3(512), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
