@@ -132,9 +132,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     // scalar offset is outside the hardware's range check); lanes past position 611 and positions outside the image carry an
     // out-of-range voffset and write zeros into the channel's own padding / halo.
     auto load_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+#ifdef W4_ZERO_RECORDS
         const int ch = chunk * W4_CK + wave;
         u32x4 rsk = rs;
         rsk[2] = (chunk < nchunks && ch < p.K) ? p.x_bytes : 0u;
+#else
+        // channels past K (last chunk, and the two chunks fetched past the end) re-read the LAST real channel: its values meet zero
+        // rows of U or a patch nobody transforms into a used V -- no descriptor is ever modified, every address is inside X
+        int ch = chunk * W4_CK + wave;
+        ch = ch < p.K ? ch : p.K - 1;
+        const u32x4 rsk = rs;
+#endif
         const int soff = ch * p.in_sc * 4;
 #pragma unroll
         for (int dr = 0; dr < W4_ROWS; ++dr) {
