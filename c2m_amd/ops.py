@@ -85,6 +85,7 @@ _WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
 _WINO_MIN_WGS = int(os.environ.get("C2M_WINO_MIN_WGS", "128"))   # smallest Winograd forward / dgrad grid: 160 workgroups of a 1536-deep layer still beat the gather kernel 1.5x
 _WGRAD_WIDE_S2 = os.environ.get("C2M_WGRAD_WIDE_S2", "1") != "0"      # bf16 stride-2 weight gradient on the 16-byte-load kernel (A/B knob)
 _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect data gradient over unpadded frames (A/B knob)
+_WINO4 = os.environ.get("C2M_WINO4", "auto")       # F(4x4,3x3) for the 2-D Winograd layers: "off" | "auto" (rule: _wino4_pays) | "force" (tests: every eligible 2-D Winograd launch)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
 # the direct kernel, "off", "force" (tests: every eligible shape).
@@ -362,6 +363,33 @@ def _geom(**kw):
     return g
 
 
+def _wino4_pays(L, M, K, nimg, Ho, Wo):
+    """F(4x4,3x3) (conv_wino4.hip: 64 rows x 16x32 outputs per 512-thread workgroup, ONE workgroup per CU) instead of F(2x2,3x3)
+    for a 2-D Winograd launch with M output rows, K input channels over nimg Ho x Wo output domains.  Measured per shape on one box
+    (tools/bench_wino4.py, round 3, first untuned kernel): 1.12-1.26x on grids of >= 4 workgroups per CU that fill their 16x32
+    regions, 0.8-0.95x on the 320-workgroup launches of the 16x32 / 32x64 maps (1.25 rounds of 256)."""
+    if _WINO4 == "force":
+        return True
+    if _WINO4 != "auto":
+        return False
+    regions = nimg * L.c2m_wino4_regions(Ho, Wo)
+    fill = nimg * Ho * Wo / float(regions * 512)
+    return K >= _WINO4_MIN_K and M >= 64 and M % 64 == 0 and fill >= 0.9 and regions * (M // 64) >= _WINO4_MIN_WGS
+
+
+_WINO4_MIN_K = int(os.environ.get("C2M_WINO4_MIN_K", "64"))
+_WINO4_MIN_WGS = int(os.environ.get("C2M_WINO4_MIN_WGS", "600"))      # 640 workgroups (256 -> 256 at 32x64, 40 images): 1.12x; 320: 0.8-0.95x
+
+
+def _wino4_filter(w, Cout, Cin, dgrad):
+    """c2m_wino4_filter_transform: native [Cout][Cin][3][3] -> packed 6x6 U = G g G^T fragments of conv_wino4_kernel."""
+    L = _lib.lib()
+    M, K = (Cin, Cout) if dgrad else (Cout, Cin)
+    U = torch.empty(L.c2m_wino4_upack_floats(M, K), device=w.device, dtype=torch.float32)
+    _lib.check(L.c2m_wino4_filter_transform(_p(w), _p(U), Cout, Cin, dgrad, _stream()), "wino4_filter_transform")
+    return U
+
+
 def _wino_geom(head, To=0, in_st=0, out_st=0, cin=0, nkt=0, toff=0, Ti=0, treflect=0):
     """geom[] of c2m_conv_wino (include/c2m_hip.h): 33 entries; the tail describes the time taps of a 3x3x3 layer."""
     g = np.zeros(34, dtype=np.int64)
@@ -427,6 +455,7 @@ class _ConvPlan:
         # ---- Winograd F(2x2,3x3) for the 3x3 stride-1 2-D layers (fp32 mode): forward, and the data gradient when the
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
         self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
+        self.wino4_fwd = self.wino4_dgrad = False         # F(4x4,3x3) instead of F(2x2,3x3) for that launch (2-D layers)
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
             wrows = 32 if Cout <= 32 else 64                      # workgroup tile: 64 (32 for Cout <= 32) output x 32 input channels
             wg_tiles = _cdiv(Cin, 32) * _cdiv(Cout, wrows)
@@ -449,6 +478,7 @@ class _ConvPlan:
                 self.wino_fwd = True
                 self.wino_fwd_geom = _wino_geom([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
                                                  Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc])
+                self.wino4_fwd = _wino4_pays(L, Cout, Cin, N, Ho, Wo)
             # data gradient: zero padding -> the unpadded domain; reflect padding -> the padded (H+2)x(W+2) domain with
             # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
@@ -461,6 +491,7 @@ class _ConvPlan:
                 self.wino_dgrad_geom = _wino_geom(
                     [Cin, Cout, N, Ho, Wo, Hd, Wd, o, o, 0, Cout * osp, osp, Wo, Cin * Hd * Wd, Hd * Wd, Wd, 0,
                      4 * N * Cout * osp, Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi])
+                self.wino4_dgrad = _wino4_pays(L, Cin, Cout, N, Hd, Wd)
         # ---- 3x3x3 stride-1 pad-1 layers (fuse_convs, the 3-D blocks): a 2-D Winograd over virtual input channels
         # (time tap, channel) with image = (sample, frame) -- the K loop is three times as deep as the 2-D layer's, the
         # temporal padding is a per-tap frame index (reflected, or a zero-record descriptor).  Data gradient: virtual
@@ -849,15 +880,18 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
         if dM < Cin:
             gx[:, dM:].zero_()
     elif pl.wino_dgrad:
-        U = _packed(w, frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
+        w4 = pl.wino4_dgrad
+        U = _packed(w, frozen_w, ("wino4-dgrad",), lambda: _wino4_filter(w, Cout, Cin, 1)) if w4 else \
+            _packed(w, frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
+        conv_wino = L.c2m_conv_wino4 if w4 else L.c2m_conv_wino
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
         npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
         tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
         # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
         tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
         _lib.check(_timed("wino", pl.fwd_flops,
-                          lambda: L.c2m_conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
-                                                  _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
+                          lambda: conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
+                                            _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad")
         if pl.reflect:
             Ti, Hi, Wi = pl.dims[3:6]
@@ -955,13 +989,16 @@ class _ConvFn(torch.autograd.Function):
             if pl.wino3d:      # virtual channels (kt, ci): [Cout][3*Cin][3][3]
                 U = _packed(w, ctx.frozen_w, ("wino-fwd3d",), lambda: _wino_filter(
                     w.permute(0, 2, 1, 3, 4).reshape(Cout, 3 * Cin, 3, 3).contiguous(), Cout, 3 * Cin, 0))
+            elif pl.wino4_fwd:
+                U = _packed(w, ctx.frozen_w, ("wino4-fwd",), lambda: _wino4_filter(w, Cout, Cin, 0))
             else:
                 U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
+            conv_wino = L.c2m_conv_wino4 if (pl.wino4_fwd and not pl.wino3d) else L.c2m_conv_wino
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
             _lib.check(_timed("wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                              lambda: L.c2m_conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
-                                                      slope, _stream()), tag,
+                              lambda: conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
+                                                slope, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)

@@ -115,6 +115,18 @@ int c2m_wino_regions(int Ho, int Wo);
 int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
                   const int64_t* geom, int act, float slope, void* stream);
 
+/* Winograd F(4x4, 3x3) form of the same 2-D launches (conv_wino4.hip: 36 multiplies per 16 outputs, 4x fewer MFMA FLOPs than
+ * the direct form; points 0, +-3/4, +-3/2, inf: fp32 error 2e-6 ... 4e-6 of the tensor scale): one workgroup = 64 rows x a
+ * 16 x 32 output region.  upack: c2m_wino4_upack_floats(M, K) floats written by c2m_wino4_filter_transform (same arguments as
+ * the F(2x2,3x3) transform); c2m_conv_wino4 takes c2m_conv_wino's geom[] and refuses its 3x3x3 entries (geom[29], geom[33] != 0).
+ * Replaces the same call sites as c2m_conv_wino (ATen conv2d forward / data gradient of the 3x3 stride-1 layers,
+ * layers/vgg.py:92-137, residual_block.py:13-31, spade_block.py:47-49).                                                 */
+long c2m_wino4_upack_floats(int M, int K);
+int c2m_wino4_filter_transform(const float* w, float* upack, int Cout, int Cin, int dgrad, void* stream);
+int c2m_wino4_regions(int Ho, int Wo);
+int c2m_conv_wino4(const float* upack, const float* X, float* Y, float* Y_interior, const float* bias,
+                   const int64_t* geom, int act, float slope, void* stream);
+
 /* Winograd weight gradient of the same layers: dg = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G (3x3, stride 1, pad 1,
  * H % 2 == 0, W % 8 == 0).  slab: c2m_wino_wgrad_splits(...) * 16 * M * K floats, dbslab: splits * M floats; dW in the
  * native [Cout][Cin][3][3] layout, db [Cout] (may be NULL).  Deterministic (fixed-order slab reduction).           */

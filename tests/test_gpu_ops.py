@@ -177,6 +177,54 @@ def test_conv_winograd_forced(case, monkeypatch):
         ops._geom_cache.clear()
 
 
+WINO4_CASES = [c for c in WINO_CASES if len(c[0]) == 4] + [
+    ((2, 256, 16, 32), 256, (3, 3), 1, 1, "reflect"),    # the 16 x 32 bottleneck blocks: one region per image, 32 chunks
+    ((1, 512, 16, 32), 128, (3, 3), 1, 1, "zeros"),      # VGG conv4-like depth: 64 chunks
+    ((1, 72, 40, 72), 80, (3, 3), 1, 1, "zeros"),        # partial regions on both axes (3 x 3 regions of 16 x 32), partial M tile
+    ((1, 17, 16, 32), 64, (3, 3), 1, 1, "reflect"),      # K not a multiple of 8: the last chunk re-reads the last channel against zero U rows
+    ((3, 8, 16, 32), 48, (3, 3), 1, 1, "zeros"),         # ONE chunk (prologue + one interval)
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_{c[5]}")
+def test_conv_winograd_f4x4_forced(case, monkeypatch):
+    """Winograd F(4x4,3x3) kernel (conv_wino4.hip) on every 2-D 3x3 stride-1 pad-1 shape of the suite: forward, zero-pad data
+    gradient, reflect data gradient over the padded domain (two-target stores), at the SAME gates as the other conv kernels
+    (measured on the GPU: 2e-6 ... 4e-6 of the tensor scale, tools/bench_wino4.py)."""
+    monkeypatch.setattr(ops, "_WINO", "force")
+    monkeypatch.setattr(ops, "_WINO4", "force")
+    ops._geom_cache.clear()
+    try:
+        xs, cout, k, stride, pad, mode = case
+        seed = zlib.crc32(("wino4" + str(case)).encode()) % 10000
+        x = rnd(seed, *xs)
+        w = rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * 9) ** 0.5))
+        b = rnd(seed + 2, cout, scale=0.1)
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        yr = _ref_conv(xr, wr, br, stride, pad, mode, None)
+        go = rnd(seed + 3, *yr.shape)
+        (yr * go).sum().backward()
+        xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+        y = ops.conv(xg, wg, bg, stride=stride, padding=pad, padding_mode=mode)
+        pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
+        assert pl.wino_fwd and pl.wino_dgrad and pl.wino4_fwd and pl.wino4_dgrad
+        (y * g(go)).sum().backward()
+        rel_close(y, yr, 2e-5, "F(4x4,3x3) fwd")
+        rel_close(xg.grad, xr.grad, 5e-5, "F(4x4,3x3) dgrad")
+        rel_close(wg.grad, wr.grad, 1e-4, "wgrad next to the F(4x4,3x3) launches")
+        # epilogue activation (applied after the bias, inside the inverse-transform pass); elements whose pre-activation is within
+        # rounding of 0 may take either slope
+        with torch.no_grad():
+            ya = ops.conv(g(x), g(w), g(b), stride=stride, padding=pad, padding_mode=mode, act="lrelu")
+        rel_close(ya, F.leaky_relu(yr.detach(), 0.2), 2e-5, "F(4x4,3x3) fwd + lrelu")
+        # twice the same launch: bit-identical (fixed summation order, no atomics)
+        with torch.no_grad():
+            yb = ops.conv(g(x), g(w), g(b), stride=stride, padding=pad, padding_mode=mode, act="lrelu")
+        assert torch.equal(ya, yb)
+    finally:
+        ops._geom_cache.clear()
+
+
 def _bf(t):
     return t.bfloat16().float()
 
