@@ -12,8 +12,8 @@
 // One workgroup = 512 threads = 8 waves = ONE per CU (two waves per SIMD): 64 output channels x a 16x32 output region (4 x 8
 // tiles = the 32 MFMA columns) of one image.  Wave w: output-channel half wm = w & 1, frequency group fg = w >> 1 (frequencies
 // 9 fg .. 9 fg + 8): 9 x 16 = 144 accumulator registers.  Per 8-channel chunk:
-//   * the 8 x 18 x 34 input patch arrives by LDS-DMA two chunks ahead (three buffers; wave w fetches channel w, the per-lane
-//     source offsets -- reflect / bounds resolved once -- sit in a 640-entry LDS table);
+//   * the 8 x 18 x 34 input patch (LDS row pitch 40: conflict-free transform reads) arrives by LDS-DMA two chunks ahead (three buffers; wave w fetches channel w, the per-lane
+//     source offsets -- reflect / bounds resolved once -- sit in a 768-entry LDS table, read once into registers);
 //   * thread (channel tk, tile tn, half h) transforms three rows of V = B^T d B of its 6x6 tile into V[xi][k][tile] in LDS
 //     (double buffered);
 //   * the U = G g G^T fragments come from L2 in a pre-packed order (c2m_wino4_filter_transform), 9 x 16 bytes per lane;
@@ -56,10 +56,16 @@ constexpr int W4_CK = 8;                              // channels per chunk
 constexpr int W4_TH = 4, W4_TW = 8;                   // tiles per region: 16 x 32 outputs
 constexpr int W4_OR = 4 * W4_TH, W4_OC = 4 * W4_TW;   // output region rows / cols
 constexpr int W4_PH = W4_OR + 2, W4_PW = W4_OC + 2;   // 18 x 34 input patch
-constexpr int W4_PPOS = W4_PH * W4_PW;                // 612 positions per channel
-constexpr int W4_ROWS = (W4_PPOS + 63) / 64;          // 10 DMA rows of 64 positions
-constexpr int W4_PCS = W4_ROWS * 64;                  // channel stride of the patch in LDS
-constexpr int W4_PBUF = W4_CK * W4_PCS;               // one patch buffer (floats)
+// LDS image of a channel's patch: row pitch 40, channel stride 722 floats.  A transform read (ds_read_b64, lane = (channel tk of 2,
+// tile (ty, tx))) hits bank pair (361 tk + 80 ty + 2 tx + const) mod 32: tx -> the 8 even pairs of a half, ty -> alternating halves,
+// tk -> odd pairs: two lanes per bank pair, the minimum for 64 x 8 bytes.  The dense 34-pitch / 640-stride image put EIGHT lanes on
+// a pair (32 cycles per read instead of 4-8): 18 reads x 8 waves kept the LDS busier than the matrix pipe (round 3: 280 -> see DESIGN).
+constexpr int W4_PITCH = 40;
+constexpr int W4_PPOS = W4_PH * W4_PITCH;             // 720 LDS positions per channel (34 of each 40 are patch columns)
+constexpr int W4_ROWS = (W4_PPOS + 63) / 64;          // 12 DMA rows of 64 positions (the last one: 16 live lanes)
+constexpr int W4_PCS = 722;                           // channel stride of the patch in LDS (half of it odd: see above)
+constexpr int W4_PBUF = W4_CK * W4_PCS + 48;          // one patch buffer (floats); + the dead lanes of the last channel's last row
+constexpr int W4_TAB = W4_ROWS * 64;                  // entries of the source-offset table
 constexpr int W4_VBUF = 36 * W4_CK * 32;              // one V buffer (floats)
 
 // Interpolation points 0, +-3/4, +-3/2, inf (tools/wino43_matrices.py): every coefficient of B^T and A^T is dyadic (exact in fp32), and
@@ -79,14 +85,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     // ONE LDS block with the DMA targets first: the LDS address of a buffer_load ... lds travels in M0, and only destinations
     // below 64 KB behaved (with the patches behind the 72 KB of V -- addresses 0x12000 ... 0x21000 -- results were intermittently
     // wrong and a launch faulted)
-    __shared__ __attribute__((aligned(16))) float smem[3 * W4_PBUF + W4_PCS + 2 * W4_VBUF];
+    __shared__ __attribute__((aligned(16))) float smem[3 * W4_PBUF + W4_TAB + 2 * W4_VBUF];
 #define sP (smem)                                              /* input patches [buf][k][18][34] (+pad): 60 KB, LDS-DMA two chunks ahead */
 #define sVo (reinterpret_cast<unsigned*>(smem + 3 * W4_PBUF))  /* per patch position: byte offset inside X or W4_OOB */
-#define sV (smem + 3 * W4_PBUF + W4_PCS)                       /* V[buf][xi][k][tile]; reused by the epilogue */
+#define sV (smem + 3 * W4_PBUF + W4_TAB)                       /* V[buf][xi][k][tile]; reused by the epilogue */
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, fg = wave >> 1;
-    const bool t_first = (wave >> 2) & 1;             // waves w and w + 4 share a SIMD: opposite phase order
+    // opposite phase order for the two waves of a SIMD, whichever way the hardware pairs them: (w, w + 4) or (w, w + 1)
+    const bool t_first = (wave ^ (wave >> 2)) & 1;
     const int regions_x = (p.Wo + W4_OC - 1) / W4_OC, regions_y = (p.Ho + W4_OR - 1) / W4_OR;
     // XCD-aware work order (conv_wino.hip): item w = region * mtiles + mt, XCD x owns a contiguous range of items
     int rb, mt;
@@ -104,14 +111,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     // ---- patch source offsets (fixed over the K loop)
     {
         const unsigned img_byte = (unsigned)(img * (int)p.in_sn) * 4u;
-        for (int pos = tid; pos < W4_PCS; pos += 512) {
-            const int r = pos / W4_PW, c = pos % W4_PW;
+        for (int pos = tid; pos < W4_TAB; pos += 512) {
+            const int r = pos / W4_PITCH, c = pos % W4_PITCH;
             int iy = oy0 + p.iy0 + r, ix = ox0 + p.ix0 + c;
             if (p.reflect) {
                 iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
                 ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
             }
-            const bool ok = pos < W4_PPOS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bool ok = pos < W4_PPOS && c < W4_PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             sVo[pos] = ok ? img_byte + (unsigned)(iy * p.in_sh + ix) * 4u : W4_OOB;
         }
     }
@@ -120,9 +127,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     const unsigned long xaddr = (unsigned long)p.X;
     const u32x4 rs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
     const unsigned sp_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)&smem[0];
-    // wave w fetches channel w of a chunk: ten DMA rows of 64 positions.  A channel past K gets a zero-record descriptor (the
+    // wave w fetches channel w of a chunk: twelve DMA rows of 64 positions.  A channel past K gets a zero-record descriptor (the
     // scalar offset is outside the hardware's range check); lanes past position 611 and positions outside the image carry an
     // out-of-range voffset and write zeros into the channel's own padding / halo.
+    // this lane's ten source offsets, read ONCE: fetched from the table in front of every DMA instruction they cost an LDS round
+    // trip each (ds_read -> wait -> DMA, ten times in a row at the start of every interval, in front of the matrix phase)
+    unsigned pvo[W4_ROWS];
+#pragma unroll
+    for (int dr = 0; dr < W4_ROWS; ++dr) pvo[dr] = sVo[dr * 64 + lane];
     auto load_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
 #ifdef W4_ZERO_RECORDS
         const int ch = chunk * W4_CK + wave;
@@ -138,10 +150,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         const int soff = ch * p.in_sc * 4;
 #pragma unroll
         for (int dr = 0; dr < W4_ROWS; ++dr) {
-            const unsigned vo = sVo[dr * 64 + lane];
+            const unsigned vo = pvo[dr];
             const unsigned dst = sp_lds + (unsigned)((buf * W4_PBUF + wave * W4_PCS + dr * 64) * 4);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(vo), "s"(rsk), "s"(soff) : "memory");
+            // the last row's lanes past position 719 would write zeros into the NEXT channel's first positions: switched off
+            if (dr * 64 + 64 <= W4_PPOS || dr * 64 + lane < W4_PPOS)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(vo), "s"(rsk), "s"(soff) : "memory");
         }
     };
     // ---- U fragments: Upack[chunk][mt][wave][f][lane][kk]: every load of a wave reads 1 KB contiguous
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     // ---- input transform role: channel tk, tile tn = (ty, tx), rows 3h .. 3h + 2 of V
     const int item = tid & 255, th = __builtin_amdgcn_readfirstlane(tid >> 8);      // th is wave-uniform (waves 0-3 / 4-7)
     const int tk = item >> 5, tn = item & 31;
-    const int pbase = tk * W4_PCS + (4 * (tn >> 3)) * W4_PW + 4 * (tn & 7);
+    const int pbase = tk * W4_PCS + (4 * (tn >> 3)) * W4_PITCH + 4 * (tn & 7);
     auto transform = [&](int pb, int vb) __attribute__((always_inline)) {
         const float* __restrict__ src = sP + pb * W4_PBUF + pbase;
         float t[3][6];
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         for (int cp = 0; cp < 3; ++cp) {                      // column pairs
             f32x2 d[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(src + r * W4_PW + 2 * cp);
+            for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(src + r * W4_PITCH + 2 * cp);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e];
@@ -188,7 +202,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
                     t[0][c] = c_ + e_; t[1][c] = c_ - e_; t[2][c] = 1.265625f * d1 - 2.8125f * d3 + d5;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);                 // one column pair at a time: 12 raw values live, not 36
         }
         float* __restrict__ v = sV + vb * W4_VBUF + tk * 32 + tn;
 #pragma unroll
@@ -201,34 +214,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto mma = [&](int cur) __attribute__((always_inline)) {
+    // Matrix phase of chunk n with the U fragments of chunk n + 1 re-loaded BEHIND their last use: three groups of three
+    // frequencies (three independent accumulator chains per group keep dependent MFMAs 3 x 64 cycles apart); a group's U registers
+    // are re-loaded as soon as its twelve MFMAs are issued, so the first loads have ~1 500 matrix cycles + the other phase to land
+    // instead of all nine being issued behind the whole phase (transform-first waves had only their transform to hide them).
+    auto mma = [&](int cur, int next_chunk) __attribute__((always_inline)) {
         const float* __restrict__ vb = sV + cur * W4_VBUF + (9 * fg * W4_CK + (lane >> 5)) * 32 + (lane & 31);
+        const int s0 = (int)((unsigned)(next_chunk < nchunks ? next_chunk : 0) * ustride_b), s1 = s0 + 4096, s2 = s0 + 8192;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float b[9];
+        for (int g3 = 0; g3 < 3; ++g3) {
+            float b[3][4];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) b[f] = vb[(f * W4_CK + 2 * kk) * 32];
+            for (int f = 0; f < 3; ++f)
 #pragma unroll
-            for (int f = 0; f < 9; ++f) {
-                const f32x4 u = ua[f];
-                const float av = kk == 0 ? u.x : (kk == 1 ? u.y : (kk == 2 ? u.z : u.w));
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[f], acc[f], 0, 0, 0);
-            }
+                for (int kk = 0; kk < 4; ++kk) b[f][kk] = vb[((3 * g3 + f) * W4_CK + 2 * kk) * 32];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const f32x4 u = ua[3 * g3 + f];
+                    const float av = kk == 0 ? u.x : (kk == 1 ? u.y : (kk == 2 ? u.z : u.w));
+                    acc[3 * g3 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[f][kk], acc[3 * g3 + f], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 3 * g3; f < 3 * g3 + 3; ++f)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                             : "=&v"(ua[f]) : "v"(uvo), "s"(urs), "s"(f < 4 ? s0 : (f < 8 ? s1 : s2)), "n"((f & 3) * 1024) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: patches 0 and 1, U(0), V(0)
     load_patch(0, 0);
     load_patch(1, 1);
     load_u(0);
-    asm volatile("s_waitcnt vmcnt(19)" ::: "memory");         // patch 0 has landed (patch 1 + U(0) may still be in flight)
+    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");         // patch 0 has landed (patch 1 + U(0) may still be in flight)
     __syncthreads();
     transform(0, 0);
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // patch 1 (this wave's part) complete before the first barrier
     // Interval n: MFMAs of chunk n on V(n) / U(n); transform of chunk n + 1 (patch (n+1) % 3 -> V buffer (n+1) & 1); DMA of patch
-    // n + 2 issued first so that it has the whole interval to land.  VMEM order per wave: DMA(n+2) x 10, later U(n+1) x 9.
-    //   before the MFMAs:   vmcnt(10) -- U(n), issued in the previous interval, complete; the 10 DMA rows may be in flight
+    // n + 2 issued first so that it has the whole interval to land.  VMEM order per wave: DMA(n+2) x 12, later U(n+1) x 9.
+    //   before the MFMAs:   vmcnt(12) -- U(n), issued in the previous interval, complete; the 12 DMA rows may be in flight
     //   before the barrier: vmcnt(9)  -- DMA(n+2) complete; the 9 U loads may be in flight
     int pn = 1;                                               // patch buffer of chunk n + 1
     for (int n = 0; n < nchunks; ++n) {
@@ -240,11 +267,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         // one definition point for the accumulators and the U registers (two copies of the interval under an if / else made the
         // register allocator spill the U tuples at the join); only the transform is placed before or after the matrix phase
         if (t_first) transform(pn, cur ^ 1);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
         for (int f = 0; f < 9; ++f) asm volatile("" : "+v"(ua[f]));
-        mma(cur);
-        load_u(n + 1);
+        mma(cur, n + 1);
         if (!t_first) transform(pn, cur ^ 1);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         pn = pn == 2 ? 0 : pn + 1;

@@ -12,7 +12,10 @@ L4.c2m_wino4_filter_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctyp
 L4.c2m_conv_wino4.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 p = lambda t: ctypes.c_void_p(t.data_ptr())
-SHAPES = [(40, 512, 16, 32, 512, 0), (40, 256, 32, 64, 256, 0), (40, 256, 16, 32, 256, 1), (40, 128, 64, 128, 128, 1),
+if os.environ.get("W4_SHAPES"):                # "N,Cin,H,W,Cout,reflect;..." instead of the bench-model list
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["W4_SHAPES"].split(";")]
+else:
+  SHAPES = [(40, 512, 16, 32, 512, 0), (40, 256, 32, 64, 256, 0), (40, 256, 16, 32, 256, 1), (40, 128, 64, 128, 128, 1),
           (40, 128, 64, 128, 128, 0), (40, 64, 128, 256, 64, 0), (40, 128, 32, 64, 128, 1), (40, 256, 32, 64, 128, 1)]
 print("N Cin H W Cout reflect | F(2x2) us  TF/s | F(4x4) us  TF/s | speed-up | max rel err F(4x4)")
 for (N, Cin, H, W, Cout, refl) in SHAPES:
