@@ -41,6 +41,7 @@ from c2m_amd.train import TrainStep, init_distributed  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD, 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
 WINOGRAD_REDUCTION = 2.25         # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
+WINOGRAD4_REDUCTION = 4.0         # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
 # SURVEY.md 8d, FlopCounterMode on the reference graph, per 7-frame clip at 128x256 (conv FLOPs scale with the pixels)
 ALGO_GFLOP_PER_CLIP = {False: 1068.6, True: 1159.8}          # [full_step]
 
@@ -408,6 +409,7 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
             fam = {
                 "winograd_fwd_dgrad (conv_wino_kernel)": _family(s, ["wino"], WINOGRAD_REDUCTION, PEAK_FP32_MFMA_TFLOPS, ev_s),
+                "winograd_f4x4_fwd_dgrad (conv_wino4_kernel)": _family(s, ["wino4"], WINOGRAD4_REDUCTION, PEAK_FP32_MFMA_TFLOPS, ev_s),
                 "direct_fwd_dgrad (conv_igemm_kernel, conv_patch3x3_kernel)": _family(s, ["igemm" + sfx], 1.0, peak, ev_s),
                 "wgrad (conv_wgrad_kernel)": _family(s, ["wgrad" + sfx], 1.0, peak, ev_s),
                 "winograd_wgrad (conv_wino_wgrad_kernel)": _family(s, ["wino_wgrad"], WINOGRAD_REDUCTION, PEAK_FP32_MFMA_TFLOPS, ev_s),
@@ -437,11 +439,11 @@ def main():
                                    f"runs {nl / sampled:.1f}; regenerate with tools/prof_round.sh")
             result["roofline"] = {
                 "bound": "mfma",
-                "kernel": "all conv MFMA launches: conv_wino_kernel + conv_igemm_kernel + conv_patch3x3_kernel (forward, "
-                          "data gradient) + conv_wgrad_kernel (weight gradient)",
+                "kernel": "all conv MFMA launches: conv_wino_kernel + conv_wino4_kernel + conv_igemm_kernel + conv_patch3x3_kernel "
+                          "(forward, data gradient) + conv_wgrad_kernel + conv_wino_wgrad_kernel (weight gradient)",
                 "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe / peak, 4),
                 "flops_counted": "EXECUTED MFMA FLOPs = algorithmic direct-convolution FLOPs (2*M*K*Npix on the unpadded "
-                                 "domain) with Winograd launches divided by 2.25",
+                                 "domain) with F(2x2,3x3) Winograd launches divided by 2.25 and F(4x4,3x3) launches by 4",
                 "algorithmic_tflops": round(alg, 2),
                 "families": fam,
                 "whole_step": {"algorithmic_tflop_per_step": round(tflop_per_step, 3),

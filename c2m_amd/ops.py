@@ -886,10 +886,10 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
         conv_wino = L.c2m_conv_wino4 if w4 else L.c2m_conv_wino
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
         npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
-        tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
+        tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
         # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
         tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
-        _lib.check(_timed("wino", pl.fwd_flops,
+        _lib.check(_timed("wino4" if w4 else "wino", pl.fwd_flops,
                           lambda: conv_wino(_p(U), _p(gy), _p(tgt), _p(gx) if pl.reflect else None, None,
                                             _gp(pl.wino_dgrad_geom), 0, 0.0, _stream()), tag,
                           4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad")
@@ -995,8 +995,9 @@ class _ConvFn(torch.autograd.Function):
                 U = _packed(w, ctx.frozen_w, ("wino-fwd",), lambda: _wino_filter(w, Cout, Cin, 0))
             conv_wino = L.c2m_conv_wino4 if (pl.wino4_fwd and not pl.wino3d) else L.c2m_conv_wino
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
-            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+            w4 = pl.wino4_fwd and not pl.wino3d           # F(4x4,3x3): its own roofline family (executed = algorithmic / 4)
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
+            _lib.check(_timed("wino4" if w4 else "wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
                               lambda: conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
                                                 slope, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")

@@ -1,6 +1,7 @@
-# SQ counter passes over tools/bench_wino4.py (work-in-progress F(4x4,3x3) kernel next to the shipped F(2x2,3x3) one)
+# SQ counter passes over tools/bench_wino4.py (the F(4x4,3x3) kernel next to the F(2x2,3x3) one)
 set -e
 export TMPDIR=/tmp
+export W4_SHAPES=${W4_SHAPES:-"40,128,64,128,128,0;40,256,32,64,256,0"}     # (the program after -- must be python itself: no env wrapper)
 R=$PWD
 for C in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do

@@ -61,7 +61,7 @@ with open(f"{O}/hbm_per_kernel.txt", "w") as f:
     for ms, name, n, t, rd, wr in rows[:60]:
         f.write(f"{ms * 1e3:7.3f}  {name:60s} {n:6.1f} {t * 1e6:8.1f} {rd / 1e6:9.2f} {wr / 1e6:9.2f} "
                 f"{(rd + wr) / t / 1e9:8.0f} {(2 * rd + wr) / t / 1e9:8.0f}\n")
-conv = [r for r in rows if any(s in r[1] for s in ("conv_wino_kernel", "conv_igemm_kernel", "conv_patch3x3", "conv_wgrad_kernel",
+conv = [r for r in rows if any(s in r[1] for s in ("conv_wino_kernel", "conv_wino4_kernel", "conv_igemm_kernel", "conv_patch3x3", "conv_wgrad_kernel",
                                                    "conv_wino_wgrad_kernel"))]
 nl = sum(r[2] for r in conv)
 rd = sum(r[4] * r[2] for r in conv) / nl
