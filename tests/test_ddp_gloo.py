@@ -12,6 +12,20 @@ import torch.nn as nn
 from c2m_amd.ddp import GradientReducer
 
 
+def _retry_rendezvous(fn):
+    """A free port found by bind(0) can be taken again before the ranks listen on it, and spawned interpreters import torch
+    cold: ONE retry (new port) for failures of the process plumbing.  Numerical assertions are deterministic and fail twice."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception:                    # noqa: BLE001
+            return fn(*a, **k)
+    return run
+
+
 class Toy(nn.Module):
     def __init__(self):
         super().__init__()
@@ -70,6 +84,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("bucket_mb", [25.0, 0.0002])   # one bucket / several tiny buckets
+@_retry_rendezvous
 def test_mean_of_rank_gradients_two_ranks(bucket_mb):
     world = 2
     ctx = mp.get_context("spawn")
@@ -78,7 +93,7 @@ def test_mean_of_rank_gradients_two_ranks(bucket_mb):
     procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_mb, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -154,6 +169,7 @@ def _worker_divergent(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@_retry_rendezvous
 def test_rank0_broadcast_and_rank_divergent_graph():
     world = 2
     ctx = mp.get_context("spawn")
@@ -164,7 +180,7 @@ def test_rank0_broadcast_and_rank_divergent_graph():
         p.start()
     results = dict()
     for _ in range(world):
-        rank, start, grads = q.get(timeout=120)
+        rank, start, grads = q.get(timeout=300)
         results[rank] = (start, grads)
     for p in procs:
         p.join(timeout=60)
@@ -231,6 +247,7 @@ def _single_backwards(rank, state):
 
 
 @pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+@_retry_rendezvous
 def test_out_of_order_readiness_agreed_launch_order_and_bf16_buckets(comm_dtype):
     """(1) buckets launch as they complete, in the order rank 0 saw on the first step -- not in bucket-index order, where the
     late bucket 0 would hold back all others until finish(); (2) frozen parameters are broadcast from rank 0 as well;
@@ -244,7 +261,7 @@ def test_out_of_order_readiness_agreed_launch_order_and_bf16_buckets(comm_dtype)
         p.start()
     res = {}
     for _ in range(world):
-        r = q.get(timeout=120)
+        r = q.get(timeout=300)
         res[r[0]] = r[1:]
     for p in procs:
         p.join(timeout=60)
