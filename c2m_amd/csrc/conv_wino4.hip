@@ -18,9 +18,8 @@
 //     (double buffered);
 //   * the U = G g G^T fragments come from L2 in a pre-packed order (c2m_wino4_filter_transform), 9 x 16 bytes per lane;
 //   * 36 MFMAs per wave.
-// The two waves of a SIMD run the interval's two phases in OPPOSITE order (waves 0-3: MFMAs, then transform of the next chunk;
-// waves 4-7: transform, then MFMAs), so one wave's LDS / VALU phase sits under the other's matrix phase without any
-// instruction-level interleaving.  The inverse transform goes through LDS in four passes of 16 output channels: raw accumulators
+// Every wave interleaves its share of the next chunk's transform (column pass of one column pair per group of 12 MFMAs, row pass
+// at the end) and of the patch DMA with its own MFMAs (sched_group_barrier: 1 MFMA : 2 VALU).  The inverse transform goes through LDS in four passes of 16 output channels: raw accumulators
 // [xi][cout][tile] -> one thread per (cout, tile) computes A^T m A, adds the bias, applies the activation and stores four
 // 16-byte row segments (or per pixel into Y / Y_interior for the two-target data gradient of reflect-padded layers).
 #include "common.h"
@@ -52,6 +51,13 @@ struct Wino4P {
     float slope;
 };
 
+// W4_FUSED (default): every wave interleaves the transform of chunk n + 1 and the patch DMA of chunk n + 2 with its OWN MFMAs of
+// chunk n.  -DW4_SKEW builds the first form (two phases, opposite order in the two waves of a SIMD), kept for A/B runs: next to
+// a partner wave that streams MFMAs a wave's VALU / LDS phase takes 3x as long (tools/trace_wino4.py), so the phases did not overlap.
+#if !defined(W4_SKEW) && !defined(W4_FUSED)
+#define W4_FUSED 1
+#endif
+
 constexpr int W4_CK = 8;                              // channels per chunk
 constexpr int W4_TH = 4, W4_TW = 8;                   // tiles per region: 16 x 32 outputs
 constexpr int W4_OR = 4 * W4_TH, W4_OC = 4 * W4_TW;   // output region rows / cols
@@ -81,11 +87,27 @@ constexpr int W4_VBUF = 36 * W4_CK * 32;              // one V buffer (floats)
         o5 = 1.265625f * (x1) - 2.8125f * (x3) + (x5);        \
     } while (0)
 
+// Phase timestamps of workgroup 0 (tuning builds only: python -m c2m_amd.build w4trace -DW4_TRACE; tools/trace_wino4.py): s_memtime at
+// four points of the first 16 intervals of every wave, kept in LDS (a global store would count in vmcnt) and copied out at the end.
+#ifdef W4_TRACE
+__device__ unsigned long long w4_trace_buf[8 * 16 * 4 + 8 * 2];
+#define W4_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && n < 16) sTr[(wave * 16 + n) * 4 + (i)] = clock64(); } while (0)
+C2M_API int c2m_wino4_trace_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(w4_trace_buf), sizeof(w4_trace_buf));
+}
+#else
+#define W4_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     // ONE LDS block with the DMA targets first: the LDS address of a buffer_load ... lds travels in M0, and only destinations
     // below 64 KB behaved (with the patches behind the 72 KB of V -- addresses 0x12000 ... 0x21000 -- results were intermittently
     // wrong and a launch faulted)
     __shared__ __attribute__((aligned(16))) float smem[3 * W4_PBUF + W4_TAB + 2 * W4_VBUF];
+#ifdef W4_TRACE
+    __shared__ unsigned long long sTr[8 * 16 * 4 + 8 * 2];
+    const unsigned long long t_begin = clock64();
+#endif
 #define sP (smem)                                              /* input patches [buf][k][18][34] (+pad): 60 KB, LDS-DMA two chunks ahead */
 #define sVo (reinterpret_cast<unsigned*>(smem + 3 * W4_PBUF))  /* per patch position: byte offset inside X or W4_OOB */
 #define sV (smem + 3 * W4_PBUF + W4_TAB)                       /* V[buf][xi][k][tile]; reused by the epilogue */
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     unsigned pvo[W4_ROWS];
 #pragma unroll
     for (int dr = 0; dr < W4_ROWS; ++dr) pvo[dr] = sVo[dr * 64 + lane];
-    auto load_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+    auto load_patch = [&](int chunk, int buf, const int dr0 = 0, const int dr1 = W4_ROWS) __attribute__((always_inline)) {
 #ifdef W4_ZERO_RECORDS
         const int ch = chunk * W4_CK + wave;
         u32x4 rsk = rs;
@@ -149,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
 #endif
         const int soff = ch * p.in_sc * 4;
 #pragma unroll
-        for (int dr = 0; dr < W4_ROWS; ++dr) {
+        for (int dr = dr0; dr < dr1; ++dr) {
             const unsigned vo = pvo[dr];
             const unsigned dst = sp_lds + (unsigned)((buf * W4_PBUF + wave * W4_PCS + dr * 64) * 4);
             // the last row's lanes past position 719 would write zeros into the NEXT channel's first positions: switched off
@@ -182,6 +204,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     const int item = tid & 255, th = __builtin_amdgcn_readfirstlane(tid >> 8);      // th is wave-uniform (waves 0-3 / 4-7)
     const int tk = item >> 5, tn = item & 31;
     const int pbase = tk * W4_PCS + (4 * (tn >> 3)) * W4_PITCH + 4 * (tn & 7);
+    // (tools/trace_wino4.py: next to a partner wave that streams MFMAs this transform takes 3 300-3 600 cycles instead of the 1 200 it
+    // takes next to an idle one -- s_setprio 3 around it changes nothing -- which is why W4_FUSED below interleaves each wave's
+    // transform with its OWN MFMAs instead of running the two phases of a SIMD's waves in opposite order.)
     auto transform = [&](int pb, int vb) __attribute__((always_inline)) {
         const float* __restrict__ src = sP + pb * W4_PBUF + pbase;
         float t[3][6];
@@ -245,6 +270,82 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         }
     };
 
+#ifdef W4_FUSED
+    // Matrix phase of chunk n with the transform of chunk n + 1 INSIDE it: three groups of 12 MFMAs, each interleaved with the
+    // column pass of one column pair of this thread's tile (5 raw rows: rows 1-4 feed the +- pair of output rows, row 0 / 5 the
+    // single one; th selects coefficients and operands, no branch -- sched_group_barrier only orders within a basic block) and
+    // followed by the re-load of its three U registers; the row pass + 18 V stores close the interval.
+    const float cA = th ? 0.5625f : 2.25f, cB3 = th ? 1.5f : 0.75f, cB1 = th ? 0.84375f : 1.6875f;
+    const int xrow = th ? 5 : 0, r_single = th ? 5 : 0, r_plus = th ? 3 : 1, r_minus = th ? 4 : 2;
+    auto fused = [&](int cur, int next_chunk, int pb, int dbuf) __attribute__((always_inline)) {
+        const float* __restrict__ vb = sV + cur * W4_VBUF + (9 * fg * W4_CK + (lane >> 5)) * 32 + (lane & 31);
+        const float* __restrict__ src = sP + pb * W4_PBUF + pbase;
+        const int s0 = (int)((unsigned)(next_chunk < nchunks ? next_chunk : 0) * ustride_b), s1 = s0 + 4096, s2 = s0 + 8192;
+        float ts[6], tp[6], tm[6];                               // single / plus / minus output rows of the column pass
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
+            // VMEM order of an interval: D0-5, U0-2, D6-11, U3-5, U6-8 (D = DMA rows of patch n + 2, U = fragments of chunk n + 1).
+            // This group's U registers were re-loaded in the PREVIOUS interval: 12 / 12 / 18 younger requests may be in flight
+            if (g3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (g3 == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+#pragma unroll
+            for (int f = 3 * g3; f < 3 * g3 + 3; ++f) asm volatile("" : "+v"(ua[f]));
+            float b[3][4];
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) b[f][kk] = vb[((3 * g3 + f) * W4_CK + 2 * kk) * 32];
+            f32x2 d1 = *reinterpret_cast<const f32x2*>(src + 1 * W4_PITCH + 2 * g3), d2 = *reinterpret_cast<const f32x2*>(src + 2 * W4_PITCH + 2 * g3);
+            f32x2 d3 = *reinterpret_cast<const f32x2*>(src + 3 * W4_PITCH + 2 * g3), d4 = *reinterpret_cast<const f32x2*>(src + 4 * W4_PITCH + 2 * g3);
+            f32x2 dx = *reinterpret_cast<const f32x2*>(src + xrow * W4_PITCH + 2 * g3);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const f32x4 u = ua[3 * g3 + f];
+                    const float av = kk == 0 ? u.x : (kk == 1 ? u.y : (kk == 2 ? u.z : u.w));
+                    acc[3 * g3 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[f][kk], acc[3 * g3 + f], 0, 0, 0);
+                }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = 2 * g3 + e;
+                const float q0 = th ? d1[e] : dx[e], q2 = th ? d3[e] : d2[e], q4 = th ? dx[e] : d4[e];
+                ts[c] = 1.265625f * q0 - 2.8125f * q2 + q4;
+                const float a_ = d4[e] - cA * d2[e], b_ = cB3 * d3[e] - cB1 * d1[e];
+                tp[c] = a_ + b_; tm[c] = a_ - b_;
+            }
+            // 12 MFMAs with the 17 LDS reads in front and ~2 VALU behind each
+            __builtin_amdgcn_sched_group_barrier(0x100, 17, 0);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // half of the patch DMA of chunk n + 2 behind the first / second group's MFMAs (in front of the whole phase the 96 DMA
+            // instructions of a workgroup kept the matrix pipes idle for 500-1 000 cycles per interval: tools/trace_wino4.py)
+            if (g3 < 2) load_patch(next_chunk + 1, dbuf, 6 * g3, 6 * g3 + 6);
+#pragma unroll
+            for (int f = 3 * g3; f < 3 * g3 + 3; ++f)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                             : "=&v"(ua[f]) : "v"(uvo), "s"(urs), "s"(f < 4 ? s0 : (f < 8 ? s1 : s2)), "n"((f & 3) * 1024) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* __restrict__ v = sV + (cur ^ 1) * W4_VBUF + tk * 32 + tn;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float* t = a == 0 ? ts : (a == 1 ? tp : tm);
+            const int row = a == 0 ? r_single : (a == 1 ? r_plus : r_minus);
+            float o0, o1, o2, o3, o4, o5;
+            W4_BT(o0, o1, o2, o3, o4, o5, t[0], t[1], t[2], t[3], t[4], t[5]);
+            float* __restrict__ vr = v + 6 * row * W4_CK * 32;
+            vr[0] = o0; vr[1 * W4_CK * 32] = o1; vr[2 * W4_CK * 32] = o2;
+            vr[3 * W4_CK * 32] = o3; vr[4 * W4_CK * 32] = o4; vr[5 * W4_CK * 32] = o5;
+        }
+    };
+#endif
+
     // ---- prologue: patches 0 and 1, U(0), V(0)
     load_patch(0, 0);
     load_patch(1, 1);
@@ -252,7 +353,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     asm volatile("s_waitcnt vmcnt(21)" ::: "memory");         // patch 0 has landed (patch 1 + U(0) may still be in flight)
     __syncthreads();
     transform(0, 0);
+#ifdef W4_FUSED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // patch 1 and U(0) complete: the loop's counted waits assume a steady state
+#else
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // patch 1 (this wave's part) complete before the first barrier
+#endif
     // Interval n: MFMAs of chunk n on V(n) / U(n); transform of chunk n + 1 (patch (n+1) % 3 -> V buffer (n+1) & 1); DMA of patch
     // n + 2 issued first so that it has the whole interval to land.  VMEM order per wave: DMA(n+2) x 12, later U(n+1) x 9.
     //   before the MFMAs:   vmcnt(12) -- U(n), issued in the previous interval, complete; the 12 DMA rows may be in flight
@@ -260,19 +365,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     int pn = 1;                                               // patch buffer of chunk n + 1
     for (int n = 0; n < nchunks; ++n) {
         __syncthreads();                                      // V(n) and patch(n+1) complete; V(n-1) and patch(n) are free
+        W4_STAMP(0);
         const int cur = n & 1;
         const int dbuf = pn == 2 ? 0 : pn + 1;
+#ifndef W4_FUSED
         load_patch(n + 2, dbuf);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // one definition point for the accumulators and the U registers (two copies of the interval under an if / else made the
         // register allocator spill the U tuples at the join); only the transform is placed before or after the matrix phase
+#ifdef W4_FUSED
+        W4_STAMP(1);
+        fused(cur, n + 1, pn, dbuf);
+        W4_STAMP(2);
+        W4_STAMP(3);
+#else
         if (t_first) transform(pn, cur ^ 1);
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
         for (int f = 0; f < 9; ++f) asm volatile("" : "+v"(ua[f]));
+        W4_STAMP(1);
         mma(cur, n + 1);
+        W4_STAMP(2);
         if (!t_first) transform(pn, cur ^ 1);
+        W4_STAMP(3);
+#endif
+#ifdef W4_FUSED
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // DMA(n+2) complete; U3-8 of chunk n + 1 may be in flight
+#else
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+#endif
         pn = pn == 2 ? 0 : pn + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of this workgroup may still write its LDS
@@ -351,6 +473,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
             }
         }
     }
+#ifdef W4_TRACE
+    if (blockIdx.x == 0 && lane == 0) { sTr[8 * 16 * 4 + wave * 2] = t_begin; sTr[8 * 16 * 4 + wave * 2 + 1] = clock64(); }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = tid; i < 8 * 16 * 4 + 8 * 2; i += 512) w4_trace_buf[i] = sTr[i];
+#endif
 }
 
 #undef sP

@@ -366,14 +366,16 @@ def _geom(**kw):
 def _wino4_pays(L, M, K, nimg, Ho, Wo):
     """F(4x4,3x3) (conv_wino4.hip: 64 rows x 16x32 outputs per 512-thread workgroup, ONE workgroup per CU) instead of F(2x2,3x3)
     for a 2-D Winograd launch with M output rows, K input channels over nimg Ho x Wo output domains.  Measured per shape on one box
-    (tools/bench_wino4.py, round 3, first untuned kernel): 1.12-1.26x on grids of >= 4 workgroups per CU that fill their 16x32
-    regions, 0.8-0.95x on the 320-workgroup launches of the 16x32 / 32x64 maps (1.25 rounds of 256)."""
+    (tools/bench_wino4.py, round 3): 1.25-1.42x on grids of >= 2.5 workgroups per CU that fill their 16x32 regions, 1.08-1.12x on
+    the deep 16x32 layers, 0.87-0.92x on the 320-workgroup launches of 128-row layers at 32x64."""
     if _WINO4 == "force":
         return True
     if _WINO4 != "auto":
         return False
     regions = nimg * L.c2m_wino4_regions(Ho, Wo)
     fill = nimg * Ho * Wo / float(regions * 512)
+    # (the deep 16x32 layers -- 512 -> 512 / 256 -> 256, 320 / 160 workgroups -- measure 1.08x / 1.12x alone but made the step
+    # slower when routed here: 67.7 -> 68.3 ms; they stay on F(2x2))
     return K >= _WINO4_MIN_K and M >= 64 and M % 64 == 0 and fill >= 0.9 and regions * (M // 64) >= _WINO4_MIN_WGS
 
 
