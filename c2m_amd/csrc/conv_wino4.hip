@@ -410,7 +410,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
     const int etile = tid & 31, ecl = tid >> 5;               // epilogue role: one (cout, tile) per thread
     const int ety = etile >> 3, etx = etile & 7;
     const int oyb = oy0 + 4 * ety, oxb = ox0 + 4 * etx;
-#pragma unroll 1
+    // the four passes' bias values up front: loaded inside a pass, the ~2 000-cycle round trip sat in front of its stores four times
+    float bias4[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int co = mt * 64 + (pass >> 1) * 32 + (pass & 1) * 16 + ecl;
+        bias4[pass] = (p.bias && co < p.M) ? p.bias[co] : 0.f;
+    }
+#pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int pwm = pass >> 1, hf = pass & 1;
         __syncthreads();
@@ -445,13 +452,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
             }
         }
         if (cout < p.M) {
-            const float bb = p.bias ? p.bias[cout] : 0.f;
+            const float bb = bias4[pass];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = oyb + r;
                 if (oy >= p.Ho) continue;
+                if (p.act == C2M_ACT_NONE) {                   // one uniform branch per row instead of a switch per element
 #pragma unroll
-                for (int c = 0; c < 4; ++c) y[r][c] = c2m_act(y[r][c] + bb, p.act, p.slope);
+                    for (int c = 0; c < 4; ++c) y[r][c] += bb;
+                } else if (p.act == C2M_ACT_LRELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float v = y[r][c] + bb; y[r][c] = v > 0.f ? v : p.slope * v; }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[r][c] = c2m_act(y[r][c] + bb, p.act, p.slope);
+                }
                 float* __restrict__ yb0 = p.Y + p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + oxb;
                 if (!p.Y2 && oxb + 3 < p.Wo) {
                     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
