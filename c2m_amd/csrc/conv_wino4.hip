@@ -468,13 +468,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
                     for (int c = 0; c < 4; ++c) y[r][c] = c2m_act(y[r][c] + bb, p.act, p.slope);
                 }
                 float* __restrict__ yb0 = p.Y + p.out_off + (long)img * p.out_sn + (long)cout * p.out_sc + (long)oy * p.out_sh + oxb;
-                if (!p.Y2 && oxb + 3 < p.Wo) {
-                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                    const f32x4u vv = {y[r][0], y[r][1], y[r][2], y[r][3]};
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                const f32x4u vv = {y[r][0], y[r][1], y[r][2], y[r][3]};
+                const int yi = oy - p.lo_y, xi0 = oxb - p.lo_x;
+                const bool row_in = p.Y2 && (unsigned)yi < (unsigned)p.ext_y;
+                // two-target launches: a 4-pixel group that lies entirely inside the interior goes to Y_interior with one 16-byte
+                // store, one entirely outside it to Y (the pad ring); only groups that straddle the interior's edge go per pixel
+                const bool all_in = row_in && xi0 >= 0 && xi0 + 3 < p.ext_x;
+                const bool all_out = !row_in || xi0 + 3 < 0 || xi0 >= p.ext_x;
+                if (oxb + 3 < p.Wo && (!p.Y2 || all_out)) {
                     *reinterpret_cast<f32x4u*>(yb0) = vv;
+                } else if (oxb + 3 < p.Wo && all_in) {
+                    *reinterpret_cast<f32x4u*>(p.Y2 + (long)img * p.y2_sn + (long)cout * p.y2_sc + (long)yi * p.y2_sh + xi0) = vv;
                 } else {
-                    const int yi = oy - p.lo_y;
-                    const bool row_in = p.Y2 && (unsigned)yi < (unsigned)p.ext_y;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (oxb + c >= p.Wo) continue;

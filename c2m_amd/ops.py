@@ -376,10 +376,13 @@ def _wino4_pays(L, M, K, nimg, Ho, Wo):
     fill = nimg * Ho * Wo / float(regions * 512)
     # (the deep 16x32 layers -- 512 -> 512 / 256 -> 256, 320 / 160 workgroups -- measure 1.08x / 1.12x alone but made the step
     # slower when routed here: 67.7 -> 68.3 ms; they stay on F(2x2))
-    return K >= _WINO4_MIN_K and M >= 64 and M % 64 == 0 and fill >= 0.9 and regions * (M // 64) >= _WINO4_MIN_WGS
+    # fill: full regions only.  The padded 66 x 130 domains of the reflect data gradients (0.67 of their 16x32 regions) measure
+    # 1.06-1.24x as isolated forward grids (tools/bench_wino4.py) but routing them here made the step slower (67.8 -> 68.1 ms)
+    return K >= _WINO4_MIN_K and M >= 64 and M % 64 == 0 and fill >= _WINO4_MIN_FILL and regions * (M // 64) >= _WINO4_MIN_WGS
 
 
 _WINO4_MIN_K = int(os.environ.get("C2M_WINO4_MIN_K", "64"))
+_WINO4_MIN_FILL = float(os.environ.get("C2M_WINO4_MIN_FILL", "0.9"))
 _WINO4_MIN_WGS = int(os.environ.get("C2M_WINO4_MIN_WGS", "600"))      # 640 workgroups (256 -> 256 at 32x64, 40 images): 1.12x; 320: 0.8-0.95x
 
 
