@@ -1195,7 +1195,7 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
     p.out_off_c[0] = p.out_off; p.po_c[0][0] = p.po_t; p.po_c[0][1] = p.po_y; p.po_c[0][2] = p.po_x;
     for (int c = 0; c < p.ncls && p.ncls > 1; ++c) {
         p.out_off_c[c] = g[64 + c];
-        for (int d = 0; d < 3; ++d) p.po_c[c][d] = (int)g[72 + 3 * c + d];
+        for (int d = 0; d < 3; ++d) p.po_c[c][d] = (int)g[96 + 3 * c + d];     // 96 .. 119 (geom[90..92] are the type / form flags)
     }
     if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;

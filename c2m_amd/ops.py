@@ -354,7 +354,7 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(96, dtype=np.int64)
+    g = np.zeros(120, dtype=np.int64)      # 96 .. 119: per-class (po_t, po_y, po_x) of a class-batched launch
     idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
                in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
                in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
@@ -693,7 +693,7 @@ class _ConvPlan:
                 g[61], g[62], g[63] = b - a, Cin * nk0 * 16, nk0 * (1 + 16 // ck0)
                 for i in range(a, b):
                     g[64 + i - a] = cl[i]["geom"][21]
-                    g[72 + 3 * (i - a):75 + 3 * (i - a)] = cl[i]["geom"][39:42]
+                    g[96 + 3 * (i - a):99 + 3 * (i - a)] = cl[i]["geom"][39:42]      # (not 72 + 3c: class 6 sat on geom[90..92], the element-type flags)
                 groups.append(dict(geom=g, tab=torch.cat([c["tab"] for c in cl[a:b]]), ncls=b - a, first=a,
                                    npix=cl[a]["npix"]))
             if len(groups) < ncls:

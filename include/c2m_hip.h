@@ -31,7 +31,7 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  * K order: (channel chunk, tap group, tap slot, channel in chunk); one 16-deep K-step = NS taps x CK channels.
  * ktab: nk groups of (1 + NS) int4: header {channel_offset, nvalid_channels (-2: ones row), 0, 0} then NS taps
  *       {dt, dy, dx, valid}; A is the weight matrix packed by the host into the same order ([M][nk*16]).
- * geom[] (int64; 64 entries, 96 when parity classes are batched):
+ * geom[] (int64; 93 entries -- 90 / 91 / 92 are read by every call --, 120 when parity classes are batched):
  *   0 M   1 nk (K-steps; for wgrad: J rows)   2 lda   3 Npix = N*To*Ho*Wo   4 To 5 Ho 6 Wo   7 Ti 8 Hi 9 Wi
  *   10 st 11 sh 12 sw (input coord = o*stride + tap offset)   13 in_sn 14 in_st 15 in_sh (elements; w stride 1)
  *   16 out_sn 17 out_sc 18 out_st 19 out_sh 20 out_sw 21 out_off   22 reflect (0 zeros / 1 reflect) 23 is3d
@@ -49,7 +49,8 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  *   52 LDS-patch kernel (3x3, stride 1, fp32): 1 = on; 53 iy0 54 ix0 input origin of an output tile relative to its
  *      first output; 55-57 / 58-60 patch row / column of tap row / column 0,1,2 ((0,1,2) forward, (2,1,0) dgrad)
  *   61 ncls: stride parity classes batched into this launch (blockIdx.z = class*splits + split); 62 floats per class
- *      weight matrix, 63 int4 entries per class tap table, 64+c out_off of class c, 72+3c.. its (po_t, po_y, po_x)
+ *      weight matrix, 63 int4 entries per class tap table, 64+c out_off of class c, 96+3c.. its (po_t, po_y, po_x)
+ *      (geom[] holds 120 entries; 90 / 91 / 92 are the element-type and weight-gradient-form flags)
  * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
  * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
 int c2m_conv_igemm_splits(int M, int nk, int Npix);

@@ -63,6 +63,10 @@ CONV_CASES = [
     ((1, 40, 24, 64), 200, (3, 3), 1, 1, "reflect"),    # bf16 LDS-patch kernel: 2 row blocks of 128, padded last chunk
     # bf16 stride-2 weight gradient on the 16-byte-load kernel (every second element of a 16-element run; Wo % 8 == 0):
     # several groups per row, one group per row (left AND right end), zeros and reflect, 64- / 128- / 32-row tiles, 3-D
+    # (4,4,4) stride (2,2,2) reflect with an EVEN frame count and a one-split data gradient: all eight parity classes have the same
+    # extents and run as ONE class-batched two-target launch.  Class 6's (po_t, po_y) used to sit on geom[90] / geom[91], which every
+    # call overwrites with the element-type flags: a quarter of the odd columns of dX was wrong (found by tools/fuzz_conv.py, seed 23)
+    ((3, 16, 2, 6, 96), 8, (4, 4, 4), (2, 2, 2), (1, 1, 1), "reflect"),
     ((2, 24, 16, 64), 72, (4, 4), 2, 1, "reflect"),
     ((3, 8, 12, 16), 136, (4, 4), 2, 1, "zeros"),
     ((2, 16, 3, 8, 32), 24, (3, 4, 4), (1, 2, 2), (1, 1, 1), "reflect"),
