@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [["--seed", "11"], ["--seed", "12", "--bf16"]], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("extra", [["--seed", "11"], ["--seed", "12", "--bf16"], ["--seed", "23"]], ids=["fp32", "bf16", "fp32-seed23"])
 def test_random_conv_geometries_vs_float64_reference(extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_conv.py"), "--cases", "120"] + extra, cwd=ROOT,
                          capture_output=True, text=True, timeout=900)
