@@ -282,23 +282,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         const float* __restrict__ src = sP + pb * W4_PBUF + pbase;
         const int s0 = (int)((unsigned)(next_chunk < nchunks ? next_chunk : 0) * ustride_b), s1 = s0 + 4096, s2 = s0 + 8192;
         float ts[6], tp[6], tm[6];                               // single / plus / minus output rows of the column pass
-#pragma unroll
-        for (int g3 = 0; g3 < 3; ++g3) {
-            // VMEM order of an interval: D0-5, U0-2, D6-11, U3-5, U6-8 (D = DMA rows of patch n + 2, U = fragments of chunk n + 1).
-            // This group's U registers were re-loaded in the PREVIOUS interval: 12 / 12 / 18 younger requests may be in flight
-            if (g3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (g3 == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-#pragma unroll
-            for (int f = 3 * g3; f < 3 * g3 + 3; ++f) asm volatile("" : "+v"(ua[f]));
-            float b[3][4];
+        float b[3][4];
+        f32x2 d1, d2, d3, d4, dx;
+        // the 17 LDS reads of group g: 12 B fragments + 5 raw rows of column pair g
+        auto reads = [&](const int g3) __attribute__((always_inline)) {
 #pragma unroll
             for (int f = 0; f < 3; ++f)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) b[f][kk] = vb[((3 * g3 + f) * W4_CK + 2 * kk) * 32];
-            f32x2 d1 = *reinterpret_cast<const f32x2*>(src + 1 * W4_PITCH + 2 * g3), d2 = *reinterpret_cast<const f32x2*>(src + 2 * W4_PITCH + 2 * g3);
-            f32x2 d3 = *reinterpret_cast<const f32x2*>(src + 3 * W4_PITCH + 2 * g3), d4 = *reinterpret_cast<const f32x2*>(src + 4 * W4_PITCH + 2 * g3);
-            f32x2 dx = *reinterpret_cast<const f32x2*>(src + xrow * W4_PITCH + 2 * g3);
+            d1 = *reinterpret_cast<const f32x2*>(src + 1 * W4_PITCH + 2 * g3); d2 = *reinterpret_cast<const f32x2*>(src + 2 * W4_PITCH + 2 * g3);
+            d3 = *reinterpret_cast<const f32x2*>(src + 3 * W4_PITCH + 2 * g3); d4 = *reinterpret_cast<const f32x2*>(src + 4 * W4_PITCH + 2 * g3);
+            dx = *reinterpret_cast<const f32x2*>(src + xrow * W4_PITCH + 2 * g3);
+        };
+        // VMEM order of an interval: D0-5, U0-2, D6-11, U3-5, U6-8 (D = DMA rows of patch n + 2, U = fragments of chunk n + 1).
+        // A group's U registers were re-loaded in the PREVIOUS interval: 12 / 12 / 18 younger requests may be in flight
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < 3; ++f) asm volatile("" : "+v"(ua[f]));
+        reads(0);
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -315,21 +318,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
                 const float a_ = d4[e] - cA * d2[e], b_ = cB3 * d3[e] - cB1 * d1[e];
                 tp[c] = a_ + b_; tm[c] = a_ - b_;
             }
-            // 12 MFMAs with the 17 LDS reads in front and ~2 VALU behind each
-            __builtin_amdgcn_sched_group_barrier(0x100, 17, 0);
+            // 12 MFMAs, ~2 VALU behind each (group 0's LDS reads sit in front of them; the later groups' were issued before the
+            // VMEM block below, whose issue time covers their latency)
+            if (g3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 17, 0);
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // half of the patch DMA of chunk n + 2 behind the first / second group's MFMAs (in front of the whole phase the 96 DMA
-            // instructions of a workgroup kept the matrix pipes idle for 500-1 000 cycles per interval: tools/trace_wino4.py)
+            // next group's LDS reads first, then half of the patch DMA of chunk n + 2 and this group's U re-load (in front of the whole
+            // phase the 96 DMA instructions of a workgroup kept the matrix pipes idle for 500-1 000 cycles per interval)
+            if (g3 < 2) reads(g3 + 1);
             if (g3 < 2) load_patch(next_chunk + 1, dbuf, 6 * g3, 6 * g3 + 6);
 #pragma unroll
             for (int f = 3 * g3; f < 3 * g3 + 3; ++f)
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
                              : "=&v"(ua[f]) : "v"(uvo), "s"(urs), "s"(f < 4 ? s0 : (f < 8 ? s1 : s2)), "n"((f & 3) * 1024) : "memory");
+            if (g3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (g3 == 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            if (g3 < 2) {
+#pragma unroll
+                for (int f = 3 * g3 + 3; f < 3 * g3 + 6; ++f) asm volatile("" : "+v"(ua[f]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         float* __restrict__ v = sV + (cur ^ 1) * W4_VBUF + tk * 32 + tn;
