@@ -378,10 +378,14 @@ def _wino4_pays(L, M, K, nimg, Ho, Wo):
     # slower when routed here: 67.7 -> 68.3 ms; they stay on F(2x2))
     # fill: full regions only.  The padded 66 x 130 domains of the reflect data gradients (0.67 of their 16x32 regions) measure
     # 1.06-1.24x as isolated forward grids (tools/bench_wino4.py) but routing them here made the step slower (67.8 -> 68.1 ms)
-    return K >= _WINO4_MIN_K and M >= 64 and M % 64 == 0 and fill >= _WINO4_MIN_FILL and regions * (M // 64) >= _WINO4_MIN_WGS
+    wgs = regions * (M // 64) if M % 64 == 0 else 0
+    if K < _WINO4_MIN_K or M < 64 or fill < _WINO4_MIN_FILL:
+        return False
+    return wgs >= _WINO4_MIN_WGS or (K >= 256 and M >= 256 and wgs >= _WINO4_DEEP_WGS)
 
 
 _WINO4_MIN_K = int(os.environ.get("C2M_WINO4_MIN_K", "64"))
+_WINO4_DEEP_WGS = int(os.environ.get("C2M_WINO4_DEEP_WGS", "1000000"))      # deep (K, M >= 256) layers on small maps: A/B knob, off by default
 _WINO4_MIN_FILL = float(os.environ.get("C2M_WINO4_MIN_FILL", "0.9"))
 _WINO4_MIN_WGS = int(os.environ.get("C2M_WINO4_MIN_WGS", "600"))      # 640 workgroups (256 -> 256 at 32x64, 40 images): 1.12x; 320: 0.8-0.95x
 
