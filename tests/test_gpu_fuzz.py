@@ -34,3 +34,12 @@ def test_random_norm_pool_resize_shapes_vs_float64_reference():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "0 failures" in out.stdout
+
+
+def test_random_shapes_through_the_forced_f4x4_winograd_kernel():
+    """tools/fuzz_wino4.py: odd / large 2-D 3x3 geometries through conv_wino4.hip whatever the routing rule would pick (forward, data
+    gradient incl. the two-target reflect form, lrelu epilogue, bit-repeatability) against float64 at the conv gates."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_wino4.py"), "--cases", "60", "--seed", "4"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "0 failures" in out.stdout
