@@ -455,6 +455,9 @@ def main():
                 "event_steps": f"{sampled} of the {args.steps} timed steps carried the HIP events (every {max(args.event_every, 1)}-th)",
                 "avg_launch_us": round(1000.0 * ms_all / max(nl, 1), 2),
                 "share_of_step_time": round(ms_all / (1000.0 * ev_s), 3),
+                # steps are issued asynchronously, so an event step has no wall time of its own: the shares divide by the MEAN
+                # step time x event steps; an event step is ~1 ms (1.5 %) longer than a plain one, shares are biased up by that
+                "share_basis": "mean wall time per step x event steps (event steps run ~1 ms longer; shares biased up by <= 1.5 %)",
             }
         if prof is not None and args.conv_table:
             with open(args.conv_table, "w") as f:

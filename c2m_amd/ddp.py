@@ -104,8 +104,13 @@ class GradientReducer:
         if self.world > 1:            # identical starting point on every rank, whatever the callers seeded
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
             with torch.no_grad():
-                for t in everything + [b for b in buffers if torch.is_tensor(b)]:
+                synced = everything + [b for b in buffers if torch.is_tensor(b)]
+                for t in synced:
                     dist.broadcast(t.data, src=src, group=self.group)
+                # writing through .data does not bump ._version, which c2m_amd.ops keys its packed-weight caches on (Winograd U
+                # fragments, K-order rows, also of the FROZEN VGG / flow net): a forward that ran before this constructor would
+                # leave ranks != 0 convolving with packs of their pre-broadcast weights
+                torch.autograd.graph.increment_version(synced)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in uniq]
         self.zero_grad()
 

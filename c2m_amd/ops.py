@@ -766,11 +766,19 @@ def _packed(w, frozen, kind, build):
         # a pack that is kept fresh from outside the graph (refresh_trainable_packs after every optimizer step: same buffer,
         # new contents) is used as it is -- the graph then holds no pack kernels; pinned, because the graph keeps its address
         if _PACK_REFRESH and fresh and key in _pack_jobs and _pack_jobs[key][3] is hit[3]:
-            _capture_pins.append(hit[3])
+            _capture_pins[id(hit[3])] = hit[3]
             return hit[3]
         return build()
     if fresh:
         return hit[3]
+    # A registered pack of this very tensor that has gone stale outside the optimizer (load_state_dict, .copy_, a torch
+    # optimizer): rebuild it IN PLACE.  A captured graph may hold the buffer's address (_capture_pins); a fresh allocation here
+    # would leave that graph replaying the old weights for ever.
+    job = _pack_jobs.get(key)
+    if _PACK_REFRESH and job is not None and hit is not None and job[0]() is w and hit[0]() is w and job[3] is hit[3] and \
+            hit[2] == w.data_ptr():
+        refresh_trainable_packs([w])
+        return job[3]
     if len(_frozen_pack_cache) > _PACK_CACHE_LIMIT:
         for k in [k for k, v in _frozen_pack_cache.items() if v[0]() is None]:       # owners that died (e.g. the
             del _frozen_pack_cache[k]                                                  # per-forward spectral-norm weight)
@@ -790,7 +798,7 @@ def _packed(w, frozen, kind, build):
 _PACK_REFRESH = os.environ.get("C2M_PACK_REFRESH", "1") != "0"      # A/B knob: 0 = packs rebuilt lazily, one launch each
 _pack_jobs = {}          # (id(w), kind) -> (weakref(w), job type, g, packed tensor): packs of trainable weights we know how to rebuild
 _pack_tables = {}        # signature of a stale set -> (device job table, njobs, total workgroups)
-_capture_pins = []       # packs whose address a captured graph holds
+_capture_pins = {}       # id -> pack whose address a captured graph holds (one entry per pack, however many captures)
 
 
 def refresh_trainable_packs(params=None):
@@ -1391,7 +1399,7 @@ def resample2d(img, flow):
     """FlowNet2 Resample2d (kernel_size 1, bilinear): img [N,C,H,W] sampled at (x + flow[:,0], y + flow[:,1]), taps clamped to
     the border (third_party/resample2d/src/resample2d_kernel.cu:16-75).  Forward only."""
     _dev(img, flow)
-    img, flow = _f(img.detach()), _f(flow.detach())
+    img, flow = _as(img.detach(), torch.float32), _as(flow.detach(), torch.float32)     # fp32-only kernel (bf16 conv outputs are cast)
     N, C, H, W = img.shape
     assert flow.shape == (N, 2, H, W)
     out = torch.empty_like(img)
@@ -1402,7 +1410,7 @@ def resample2d(img, flow):
 def channelnorm(x):
     """FlowNet2 ChannelNorm: sqrt(sum_c x^2) -> [N,1,H,W] (third_party/channelnorm/src/channelnorm_kernel.cu:19-62)."""
     _dev(x)
-    x = _f(x.detach())
+    x = _as(x.detach(), torch.float32)                   # fp32-only kernel
     N, C, H, W = x.shape
     out = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().c2m_channelnorm_fwd(_p(x), _p(out), N, C, H, W, _stream()), "channelnorm")
@@ -1413,7 +1421,7 @@ def correlation(a, b, pad_size=20, kernel_size=1, max_displacement=20, stride1=1
     """FlowNetC cost volume (third_party/correlation/src/correlation_cuda_kernel.cu:47-147; defaults = flownet_c.py:44-46):
     [N,C,H,W] x [N,C,H,W] -> [N, (2*(max_displacement//stride2)+1)^2, oH, oW]."""
     _dev(a, b)
-    a, b = _f(a.detach()), _f(b.detach())
+    a, b = _as(a.detach(), torch.float32), _as(b.detach(), torch.float32)      # fp32-only kernel: a bf16 pointer would be read as floats
     assert a.shape == b.shape
     N, C, H, W = a.shape
     L = _lib.lib()

@@ -8,24 +8,58 @@ import torch.nn.functional as F
 from torch import nn
 
 
-_adj_cache = {}      # capturing? -> (weakref(edge_index), version, data_ptr, N, dtype, A)
+_adj_cache = {}      # "dense" / "csr" -> (weakref(edge_index), version, data_ptr, N, dtype, payload): eager entries only
+_capture_local = {}  # the same keys for the capture in progress (tensors of that graph's private pool): dropped at its start / end
+
+
+def reset_capture_cache():
+    """Called by TrainStep.capture before and after a HIP-graph capture: an adjacency tensor built while capturing lives in THAT
+    graph's pool and must never be handed to another capture (the second graph would read memory it does not own)."""
+    _capture_local.clear()
+
+
+def _cached(kind, edge_index, N, dtype, build):
+    import weakref
+    cap = bool(edge_index.is_cuda and torch.cuda.is_current_stream_capturing())
+    store = _capture_local if cap else _adj_cache
+    hit = store.get(kind)
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == edge_index.data_ptr() \
+            and hit[3] == N and hit[4] == dtype:
+        return hit[5]
+    val = build(cap)
+    store[kind] = (weakref.ref(edge_index), edge_index._version, edge_index.data_ptr(), N, dtype, val)
+    return val
 
 
 def _edge_multiplicity(edge_index, dst, src, N, dtype):
     """A[i, j] = number of edges j -> i.  Every GATv2 layer of a step sees the same edge_index (10 calls per generator step), and
     the accumulate-index_put_ that builds A is a chain of ~8 small kernels (bounds asserts, index arithmetic, sort): built once
-    per edge_index tensor (object, version and address; separately inside a HIP-graph capture, whose tensors live in the
-    graph's pool).  The accumulation adds exact 1.0s, so the result does not depend on the order."""
-    import weakref
-    cap = bool(edge_index.is_cuda and torch.cuda.is_current_stream_capturing())
-    hit = _adj_cache.get(cap)
-    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == edge_index.data_ptr() \
-            and hit[3] == N and hit[4] == dtype:
-        return hit[5]
-    A = torch.zeros(N, N, dtype=dtype, device=edge_index.device).index_put_((dst, src), torch.ones_like(dst, dtype=dtype),
-                                                                           accumulate=True)
-    _adj_cache[cap] = (weakref.ref(edge_index), edge_index._version, edge_index.data_ptr(), N, dtype, A)
-    return A
+    per edge_index tensor (object, version and address) in eager mode and once per CAPTURE inside a HIP-graph capture (the
+    tensor then lives in that graph's pool).  The accumulation adds exact 1.0s, so the result does not depend on the order."""
+    return _cached("dense", edge_index, N, dtype, lambda cap: torch.zeros(N, N, dtype=dtype, device=edge_index.device).index_put_(
+        (dst, src), torch.ones_like(dst, dtype=dtype), accumulate=True))
+
+
+def _padded_csr(edge_index, dst, src, N):
+    """Edges grouped by target node into fixed-width rows: (order, slot, width) with edge order[k] sitting in row dst, column
+    rank-within-row -- slot = dst * width + rank, every slot distinct.  The width (largest in-degree) is read back to the host
+    once per edge_index; inside a capture the eager entry of the warm-up steps is used (its tensors are kept alive here)."""
+    def build(cap):
+        if cap:
+            hit = _adj_cache.get("csr")
+            if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == edge_index.data_ptr():
+                return hit[5]
+            raise RuntimeError("GATv2Conv (> 64 nodes): run one eager step with this edge_index before capturing a HIP graph "
+                               "(the padded edge layout needs the largest in-degree on the host)")
+        E = dst.numel()
+        order = torch.argsort(dst, stable=True)
+        counts = torch.bincount(dst, minlength=N)
+        width = max(int(counts.max()) if E else 0, 1)
+        start = torch.cumsum(counts, 0) - counts
+        ds = dst[order]
+        slot = ds * width + (torch.arange(E, device=dst.device) - start[ds])
+        return order, slot, width
+    return _cached("csr", edge_index, N, torch.int64, build)
 
 
 class GATv2Conv(nn.Module):
@@ -69,13 +103,19 @@ class GATv2Conv(nn.Module):
             ex = (logit - mx.unsqueeze(1).detach()).exp() * A.unsqueeze(-1)
             alpha = ex / (ex.sum(1, keepdim=True) + 1e-16)
             return torch.einsum("ijh,jhc->ihc", alpha, xl).mean(dim=1) + self.bias
-        e = F.leaky_relu(xl[src] + xr[dst], self.negative_slope)
-        logit = (e * self.att).sum(-1)
-        mx = torch.full((N, H), float("-inf"), dtype=x.dtype, device=x.device)
-        mx = mx.scatter_reduce(0, dst[:, None].expand(-1, H), logit, reduce="amax", include_self=True)
-        mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
-        ex = (logit - mx[dst].detach()).exp()
-        den = torch.zeros((N, H), dtype=x.dtype, device=x.device).index_add(0, dst, ex)
-        alpha = ex / (den[dst] + 1e-16)
-        out = torch.zeros((N, H, C), dtype=x.dtype, device=x.device).index_add(0, dst, xl[src] * alpha.unsqueeze(-1))
-        return out.mean(dim=1) + self.bias
+        # Many nodes (> 64: B >= 22 clips of three objects): edges grouped by target node into rows of `width` slots
+        # (_padded_csr), softmax and weighted sum as dense reductions along the row -- no scatter / index_add over edges, so no
+        # float atomics in the forward, and the gathers' backward is torch's sort-based accumulate (deterministic).  Empty
+        # slots carry -inf logits / zero messages.  tests/test_host_cpu.py holds this form to the dense one.
+        order, slot, width = _padded_csr(edge_index, dst, src, N)
+        so, do = src[order], dst[order]
+        e = F.leaky_relu(xl[so] + xr[do], self.negative_slope)                                 # [E, H, C] in row order
+        logit = (e * self.att).sum(-1)                                                         # [E, H]
+        pad = torch.full((N * width, H), float("-inf"), dtype=x.dtype, device=x.device).index_copy(0, slot, logit)
+        pad = pad.view(N, width, H)
+        mx = pad.max(dim=1).values
+        mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)                            # nodes without incoming edges
+        ex = (pad - mx.unsqueeze(1).detach()).exp()                                            # exp(-inf) = 0 in empty slots
+        alpha = ex / (ex.sum(1, keepdim=True) + 1e-16)                                         # [N, width, H]
+        msg = torch.zeros((N * width, H, C), dtype=x.dtype, device=x.device).index_copy(0, slot, xl[so]).view(N, width, H, C)
+        return (alpha.unsqueeze(-1) * msg).sum(1).mean(dim=1) + self.bias

@@ -113,6 +113,8 @@ class TrainStep:
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             U.begin_deferred_nan()
+            from . import thirdparty
+            thirdparty.reset_capture_cache()                  # tensors cached during an earlier capture belong to that graph's pool
             try:
                 # With a process group alive its watchdog THREAD polls the completion events of earlier collectives; in the default
                 # ("global") capture mode any such HIP call from another thread during the capture is an error that takes the
@@ -123,6 +125,7 @@ class TrainStep:
                     outputs = self._eager(data, in_capture=True)
             finally:
                 self._deferred_nan = U.end_deferred_nan()
+                thirdparty.reset_capture_cache()
         finally:
             self.run_optimizers = run_opt
         self._graph, self._graph_data, self._graph_out = graph, data, outputs

@@ -117,7 +117,35 @@ def test_compute_flow_vs_reference_trainer(flownet):
         check_compact(c.arr, "cf", k, out[k], 5e-3, k)
     out1 = compute_flow(net, {"video": video}, dict(num_input_frames=1, num_predicted_frames=5))
     assert out1["input_of"] is None and out1["input_occ"] is None and "target_fw_of" not in out1
-    assert torch.equal(out1["target_bw_of"][:, :, 1:], out1["target_bw_of"][:, :, 1:])
+    # t_in = 1 on the clip shifted by one frame asks for the same (frame 1 -> frame 2 + i) pairs as t_in = 2 on the whole clip
+    sh = compute_flow(net, {"video": video[:, :, 1:].contiguous()}, dict(num_input_frames=1, num_predicted_frames=5))
+    assert sh["input_of"] is None
+    torch.testing.assert_close(sh["target_bw_of"], out["target_bw_of"], rtol=1e-4, atol=1e-4)
+    assert float((sh["target_bw_occ"] - out["target_bw_occ"]).abs().mean()) < 1e-4
+    # ... and on the unshifted clip the targets are different pairs (frame 0 -> frame 1 + i)
+    assert not torch.allclose(out1["target_bw_of"], out["target_bw_of"], atol=1e-3)
+
+
+def test_flownet_is_fp32_inside_a_bf16_training_mode(flownet):
+    """under ops.set_conv_precision('bf16') (configs[2-4]) the flow net's convolutions returned bf16 tensors that
+    the fp32-only correlation / resample2d / channelnorm kernels then read as floats.  The net now pins fp32 for itself and
+    the three operators cast; targets are bit-identical in both modes."""
+    from c2m_amd import ops
+    c, net = flownet
+    video = synth_input(c.meta["video"]).to(DEV)
+    tp = dict(num_input_frames=2, num_predicted_frames=5)
+    ref = compute_flow(net, {"video": video}, tp)
+    with ops.conv_precision("bf16"):
+        got = compute_flow(net, {"video": video}, tp)
+        a = torch.randn(2, 16, 24, 32, device=DEV)
+        b = torch.randn(2, 16, 24, 32, device=DEV)
+        fl = torch.randn(2, 2, 24, 32, device=DEV)
+        ab, bb = a.bfloat16(), b.bfloat16()
+        assert torch.equal(ops.correlation(ab, bb), ops.correlation(ab.float(), bb.float()))
+        assert torch.equal(ops.channelnorm(ab), ops.channelnorm(ab.float()))
+        assert torch.equal(ops.resample2d(ab, fl), ops.resample2d(ab.float(), fl))
+    for k in ("input_of", "input_occ", "target_bw_of", "target_bw_occ"):
+        assert torch.equal(got[k], ref[k]), k
 
 
 def test_online_flow_feeds_the_training_step(flownet):

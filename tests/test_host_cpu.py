@@ -142,7 +142,9 @@ def test_gatv2_dense_product_form_vs_edge_list_oracle_form():
     """torch_geometric's GATv2Conv is an absent third-party dependency (parity unpinned).  The product
     computes it in DENSE form (all ordered pairs, edge-multiplicity mask), the oracle over the EDGE LIST (scatter /
     index_add) -- two independent restatements of the published layer that must agree, including duplicate edges, nodes
-    without incoming edges and gradients.  Above DENSE_MAX_NODES the product switches to the edge-list form."""
+    without incoming edges and gradients.  Above DENSE_MAX_NODES the product switches to padded rows of edges per target
+    node (dense reductions along the row: no float-atomic index_add) -- a third formulation, held to the oracle's
+    here and to the product's own dense form in test_gatv2_padded_rows_form_equals_the_dense_form."""
     import torch
     from c2m_amd.thirdparty import GATv2Conv
     from oracle import thirdparty as TP
@@ -160,6 +162,35 @@ def test_gatv2_dense_product_form_vs_edge_list_oracle_form():
         (y * go).sum().backward()
         (yr * go).sum().backward()
         torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_gatv2_padded_rows_form_equals_the_dense_form():
+    """The > 64-node branch of the product's GATv2Conv against its dense branch on the SAME graph (90 nodes, ragged in-degrees,
+    duplicate edges, isolated nodes): forward, input gradient and every parameter gradient; twice the same bits."""
+    import torch
+    from c2m_amd.thirdparty import GATv2Conv
+    torch.manual_seed(1)
+    n = 90
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, n - 5, (2, 400), generator=g)                # nodes 85 .. 89 isolated; duplicates certain
+    ei = torch.cat([ei, ei[:, :7]], 1)
+    x = torch.randn(n, 16, generator=g)
+    outs = []
+    for dense_max in (64, 1000, 64):
+        m = GATv2Conv(16, 8, heads=4, concat=False, add_self_loops=False)
+        m.load_state_dict(outs[0][3]) if outs else None
+        m.DENSE_MAX_NODES = dense_max
+        xa = x.clone().requires_grad_(True)
+        y = m(xa, ei)
+        (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+        outs.append((y.detach(), xa.grad, [p.grad.clone() for p in m.parameters()], m.state_dict()))
+    (y0, gx0, gp0, _), (y1, gx1, gp1, _), (y2, gx2, gp2, _) = outs
+    torch.testing.assert_close(y0, y1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gx0, gx1, rtol=1e-4, atol=1e-6)
+    for a, b in zip(gp0, gp1):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    assert torch.equal(y0[-1], m.bias.detach())
+    assert torch.equal(y0, y2) and torch.equal(gx0, gx2) and all(torch.equal(a, b) for a, b in zip(gp0, gp2))
 
 
 @pytest.mark.parametrize("T", [2, 3, 4, 5, 7])
