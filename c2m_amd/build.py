@@ -42,6 +42,9 @@ def build(force=False, verbose=False, variant=None, defines=()):
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(LIB_DIR, src.replace(".hip", suffix + ".o"))
+        slp = os.environ.get("C2M_BUILD_SLP", "")         # tuning / bisect builds only (tools/concurrency_stress.py): SLP vectoriser ON
+        if slp == "1" or src in slp.split(","):           # for every file ("1") or for the listed ones ("conv_igemm.hip,warp.hip")
+            extra = [f for f in extra if f != "-fno-slp-vectorize"]
         if force or variant or _stale(o, [s] + common):
             cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-c", s, "-o", o] + extra + \
                   [f"-D{d}" for d in defines]

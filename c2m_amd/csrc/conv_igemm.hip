@@ -626,6 +626,14 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
     load_patch(chunk_beg, 0);
     load_a(chunk_beg * 9);
     store_a(0);
+    // The patch DMA is inline asm the compiler's s_waitcnt insertion does not see.  It used to be covered only implicitly, by the
+    // wait for the A-tile load issued after it (loads return in order) -- but with BM = 32 the threads >= 128 load no A element,
+    // so waves 2 and 3 reached the barrier WITHOUT ever waiting for the channels they had fetched, and their part of the patch
+    // could still be in flight when the other waves read it.  Alone on the chip the DMA always won the race; next to ANY other
+    // kernel that keeps the memory system busy it did not (round 4, tools/concurrency_stress.py: wrong forward values and
+    // gradients next to torch.add on another stream).  Every barrier that publishes a freshly fetched patch buffer now has an
+    // explicit wait in front of it (free: the waves that load A were waiting there already).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0, pcur = 0;
     for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
@@ -668,6 +676,7 @@ __global__ __launch_bounds__(256) void conv_patch3x3_kernel(const ConvP p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) store_a(cur ^ 1);
+            if (tap == 8 && more_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next chunk's patch DMA (see the prologue)
             __syncthreads();
             cur ^= 1;
         }
@@ -2231,8 +2240,14 @@ __global__ __launch_bounds__(256) void conv_thin_wgrad_rows_kernel(const WgradP 
             for (int c = 0; c < CPB; ++c) {
 #pragma unroll
                 for (int e = 0; e < HL; ++e) {
+#ifdef C2M_THIN_DPP      // bisect build (tools/concurrency_stress.py): whole-wave DPP shifts instead of ds_bpermute_b32 through the LDS crossbar
+                    const int su = __builtin_bit_cast(int, v[i][c][4 + e]), sd = __builtin_bit_cast(int, v[i][c][HL + e]);
+                    const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(su, su, 0x138, 0xf, 0xf, false));   // wave_shr:1
+                    const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(sd, sd, 0x130, 0xf, 0xf, false));   // wave_shl:1
+#else
                     const float up = __shfl_up(v[i][c][4 + e], 1, 64);                 // left neighbour's pixel 4 - HL + e
                     const float dn = __shfl_down(v[i][c][HL + e], 1, 64);              // right neighbour's pixel e
+#endif
                     const float bl = p.reflect ? v[i][c][HL + HL - e] : 0.f;           // image border: own pixel HL - e
                     const float br = p.reflect ? v[i][c][HL + 2 - e] : 0.f;            //               own pixel 2 - e
                     v[i][c][e] = (fl & 8) ? v[i][c][e] : ((fl & 2) ? bl : up);

@@ -198,6 +198,10 @@ ZERO_GRAD_BIASES = {
     "motion_encoder.sparse_motion_estimator.encode_scene_features.3.bias"}
 
 
+UPSTREAM_OF_RASTER = ("motion_encoder.sparse_motion_estimator.", "appearance_encoder.roi_align_",
+                      "appearance_encoder.fuse_appearance_roi.")
+
+
 @pytest.mark.parametrize("name", names("e2e_"))
 def test_train_step_vs_golden(name):
     c = Case(name)
@@ -242,12 +246,15 @@ def test_train_step_vs_golden(name):
     numel = {k: max(p.numel(), 1) for k, p in model.named_parameters()}
     per_elem = sorted(ref_g[k][1].item() / numel[k] for k in ref_g)
     noise = 1e-3 * per_elem[len(per_elem) // 2]      # analytically-zero grads (bias in front of a norm) sit below this
-    gtol = 5e-3 if exact_masks else 0.3     # predicted-theta fixture: only a sanity band (see above)
+    # predicted-theta fixture: the GNN and the RoI branch of the appearance encoder get their gradient from the theta losses only
+    # (the raster's output is detached, dense_motion.py:143) -- nothing chaotic upstream of them, so they are held to the same
+    # 5e-3 as in the gt fixtures; everything else is downstream of the float-equality mask
+    gtol = 5e-3
     bad = []
     for k, ref in ref_g.items():
         s = summarize(got[k].cpu())
         assert np.all(np.isfinite(s)), f"non-finite gradient {k}"
-        if not exact_masks:
+        if not exact_masks and not k.startswith(UPSTREAM_OF_RASTER):
             continue   # gradients downstream of the chaotic float-equality mask: key set + finiteness only
         if k in ZERO_GRAD_BIASES:
             # analytically zero: the reference's own value is the rounding residue of a cancelling sum -- same order only
