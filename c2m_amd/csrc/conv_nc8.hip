@@ -1,0 +1,403 @@
+// bf16 convolutions over CHANNEL-BLOCKED activations (round 4; BASELINE configs[2-4]).
+//
+// On NCHW the 8 consecutive input channels one lane of v_mfma_f32_32x32x16_bf16 consumes sit 2*H*W bytes apart, so the bf16
+// kernels of rounds 2-3 (conv_igemm.hip) gather 2 bytes per lane per load and run the matrix pipe 0.09-0.18 busy.  Here the
+// conv INPUT is "NC8": [N][ceil(C/8)][H][W][8] bf16 -- the 8 channels of one pixel are one 16-byte unit -- produced by
+// c2m_nchw_to_nc8 (one pass; fused into the producing kernels where they exist) and consumed by
+//
+//   conv_patch_nc8_kernel<BM>: 3x3 stride-1 layers, forward and data gradient (residual_block.py:13-31,42-71,
+//   spade_block.py:47-49, vgg.py:92-137, up_block.py:9-13, same_block.py:14-23).  Per 16-channel chunk the (8+2) x 34 pixel
+//   patch ([half][pixel] 16-byte units) and the 9 x BM x 16 weight image ([tap][half][row]) go global -> LDS by 16-byte
+//   LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, 8 DMA instructions per wave and chunk instead of
+//   24 two-byte gathers + 8 packs + 12 ds_write_b128.  Every B fragment of every tap is one conflict-free ds_read_b128 of the
+//   patch at a pixel offset.  Two LDS buffers of 32 KB (DMA destinations must stay below 64 KB, conv_wino4.hip), two
+//   workgroups per CU, ONE barrier per chunk: wait for this chunk's DMA, barrier, issue the next chunk's DMA into the buffer
+//   everybody has just left, 36 MFMAs per wave (BM = 64).
+//   Output: NCHW bf16 / fp32 exactly as conv_patch3x3_bf16_kernel writes it (two-target reflect data gradient, split-K slabs,
+//   bias + activation), so nothing downstream changes.
+#include "common.h"
+#include "dtype.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define NC8_OOB 0x80000000u
+
+// ------------------------------------------------------------------------------------------------ NCHW -> NC8
+// out[n][cb][p][j] = in[n][cb*8 + j][p] (zeros for channels >= C).  A thread owns 8 consecutive pixels of one channel block:
+// eight 16-byte loads (one per channel: contiguous over the lanes), an 8x8 transpose of 16-bit elements in registers, eight
+// 16-byte stores = 128 contiguous bytes per thread.
+__global__ __launch_bounds__(256) void nchw_to_nc8_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int C, int CB,
+                                                          long HW8 /* HW / 8 */, long total /* N*CB*HW8 */) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i % HW8;
+        const long ncb = i / HW8;
+        const int cb = (int)(ncb % CB);
+        const long n = ncb / CB;
+        unsigned r[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb * 8 + j;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (c < C) v = in[(n * C + c) * HW8 + g];
+            r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
+        }
+        // r[j][q] = pixels (2q, 2q+1) of channel j  ->  o[px][q'] = channels (2q', 2q'+1) of pixel px
+        uint4* __restrict__ dst = out + ((n * CB + cb) * HW8 + g) * 8;
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+            const int q = px >> 1;
+            const unsigned sel = (px & 1) ? 0x07060302u : 0x05040100u;      // high / low halves of (src0 = odd channel, src1 = even channel)
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(r[1][q], r[0][q], sel);
+            o.y = __builtin_amdgcn_perm(r[3][q], r[2][q], sel);
+            o.z = __builtin_amdgcn_perm(r[5][q], r[4][q], sel);
+            o.w = __builtin_amdgcn_perm(r[7][q], r[6][q], sel);
+            dst[px] = o;
+        }
+    }
+}
+
+// Elements per image plane must be a multiple of 8 (every map of the path is); x and y are 16-byte aligned.
+C2M_API int c2m_nchw_to_nc8(const void* x, void* y, long N, int C, long HW, void* stream) {
+    C2M_ENTER();
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    if ((HW & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return (int)hipErrorInvalidValue;
+    const int CB = (C + 7) / 8;
+    const long total = N * CB * (HW / 8);
+    hipLaunchKernelGGL(nchw_to_nc8_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C, CB, HW / 8, total);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1 patch kernel
+struct Nc8P {
+    const void* A;       // c2m_pack_weights_bf16_patch image: [chunk][tap 9][Mpad rows][2 halves] 16-byte units
+    const void* X;       // NC8 activations
+    float* Y;            // output (NCHW, fp32 or bf16), or the slab base when splits > 1
+    float* Y2;           // optional interior target of the reflect data gradient (ConvP semantics, conv_igemm.hip)
+    const float* bias;
+    int M, Mpad, nchunks, CB;
+    int Nimg, Ho, Wo, Hi, Wi;
+    int iy0, ix0, pty[3], ptx[3];
+    int reflect, act, yh, chunks_per_split;
+    float slope;
+    long out_sn, out_sc, out_sh, out_off, slab_stride;
+    int ps_y, ps_x, po_y, po_x, lo_y, lo_x, ext_y, ext_x;
+    long y2_sn, y2_sc, y2_sh;
+    unsigned x_bytes, a_bytes;
+};
+
+template <int BM, int NBUF, int WGS, int TR>
+__global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) {
+    constexpr int PW = 34, NPIX = (TR + 2) * PW;                  // 340 patch pixels (8-row tile), 612 (16-row tile)
+    constexpr int PROWS = (NPIX + 63) / 64;                       // DMA rows of 64 units per half plane: 6 / 10
+    constexpr int PPL = PROWS * 64;
+    constexpr int PPW = PROWS / 2;                                // ... per wave (wave w: half w >> 1, rows PPW * (w & 1) ...)
+    static_assert(PROWS % 2 == 0, "patch DMA rows split evenly over the two waves of a half plane");
+    constexpr int MI = BM / 32, NI = TR / 4;
+    constexpr int A_UNITS = 9 * BM * 2;
+    constexpr int NAI = (A_UNITS + 255) / 256;                    // weight DMA rows per wave and chunk
+    constexpr int A_PAD = NAI * 256;
+    constexpr int BUF = A_PAD + 2 * PPL;                          // units per buffer: 2048 (32 KB) at BM = 64
+    constexpr int NDMA = NAI + PPW;
+    constexpr int CG = BM >= 64 ? 64 : 32;                        // channels per staging pass of the epilogue
+    constexpr int T_UNITS = 4 * CG * 64 / 4;                      // its tile: [wave][channel][64 pixels] fp32
+    // (LDS-DMA destinations above 64 KB are fine: tools/micro/lds_dma_high.hip)
+    static_assert(NBUF * BUF * 16 * WGS <= 160 * 1024, "LDS");
+    __shared__ uint4 smem[NBUF * BUF >= T_UNITS ? NBUF * BUF : T_UNITS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.Wo + 31) / 32, tiles_y = (p.Ho + TR - 1) / TR;
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Nimg * tiles_y * tiles_x), (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM;
+    int tb = blk.x;
+    const int tx = tb % tiles_x; tb /= tiles_x;
+    const int ty = tb % tiles_y; const int n_img = tb / tiles_y;
+    const int oy0 = ty * TR, ox0 = tx * 32;
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
+    // ---- weight DMA: destination unit d = (i * 4 + wave) * 64 + lane of [tap][half][row]; source [tap][m0 + row][half]
+    const unsigned long aaddr = (unsigned long)p.A;
+    const u32x4 ars = {(unsigned)aaddr, (unsigned)(aaddr >> 32) & 0xffffu, p.a_bytes, 0x00020000u};
+    unsigned avo[NAI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        const int d = (i * 4 + wave) * 64 + lane;
+        const int tap = d / (2 * BM), half = (d / BM) & 1, row = d % BM;
+        avo[i] = d < A_UNITS ? (unsigned)(((tap * p.Mpad + m0 + row) * 2 + half) * 16) : NC8_OOB;
+    }
+    const unsigned a_chunk_bytes = (unsigned)(9 * p.Mpad * 32);
+    // ---- patch DMA: wave w fetches rows j = 3 * (w & 1) .. + 2 of half plane w >> 1; unit u = j * 64 + lane -> patch pixel
+    const unsigned long xaddr = (unsigned long)p.X;
+    const u32x4 xrs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const int phalf = wave >> 1, pj0 = PPW * (wave & 1);
+    const unsigned plane_bytes = (unsigned)(p.Hi * p.Wi * 16);
+    unsigned pvo[PPW];
+#pragma unroll
+    for (int r = 0; r < PPW; ++r) {
+        const int u = (pj0 + r) * 64 + lane;
+        const int row = u / PW, col = u % PW;
+        int iy = oy0 + p.iy0 + row, ix = ox0 + p.ix0 + col;
+        if (p.reflect) {
+            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+        }
+        const bool ok = u < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        pvo[r] = ok ? (unsigned)n_img * (unsigned)p.CB * plane_bytes + (unsigned)(iy * p.Wi + ix) * 16u : NC8_OOB;
+    }
+    // Every iteration issues exactly NDMA instructions per wave, so the counted waits below are constants: a chunk past the
+    // split's end is "fetched" through zero-record descriptors (no memory traffic; zeros land in a buffer nobody reads again).
+    auto issue_dma = [&](int chunk, int buf, bool live) {
+        const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
+        const int asoff = live ? (int)((unsigned)chunk * a_chunk_bytes) : 0;
+        u32x4 ark = ars;
+        ark[2] = live ? p.a_bytes : 0u;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+            const unsigned dst = base + (unsigned)((i * 4 + wave) * 64 * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(avo[i]), "s"(ark), "s"(asoff) : "memory");
+        }
+        // a channel block past the tensor's last one (odd block count, last chunk): zero records instead of the next image
+        const int cb = chunk * 2 + phalf;
+        u32x4 rsk = xrs;
+        rsk[2] = (live && cb < p.CB) ? p.x_bytes : 0u;
+        const int psoff = live ? (int)((unsigned)cb * plane_bytes) : 0;
+#pragma unroll
+        for (int r = 0; r < PPW; ++r) {
+            const unsigned dst = base + (unsigned)((A_PAD + phalf * PPL + (pj0 + r) * 64) * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(pvo[r]), "s"(rsk), "s"(psoff) : "memory");
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int pbase[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pbase[j] = A_PAD + (lane >> 5) * PPL + (wave * NI + j) * PW + (lane & 31);
+    const int abase = (lane >> 5) * BM + (lane & 31);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = p.pty[t / 3] * PW + p.ptx[t % 3];
+
+    const int chunk_beg = blk.z * p.chunks_per_split;
+    int chunk_end = chunk_beg + p.chunks_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
+
+    struct Frag { bf16x8 a[MI], b[NI]; };
+    auto read_frag = [&](int buf, int tap, Frag& f) {
+        const uint4* __restrict__ s = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) f.a[i] = __builtin_bit_cast(bf16x8, s[tap * 2 * BM + i * 32 + abase]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) f.b[j] = __builtin_bit_cast(bf16x8, s[pbase[j] + toff[tap]]);
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) issue_dma(chunk_beg + d, d, chunk_beg + d < chunk_end);
+    int cur = 0;
+    for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+        // The DMAs of the NBUF - 2 chunks after this one may stay in flight (vmcnt retires in order); after the barrier this
+        // chunk's image is complete in EVERY wave's share, and everybody has left the buffer read during the previous chunk,
+        // which the DMA of chunk + NBUF - 1 may now overwrite.
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int nb = cur == 0 ? NBUF - 1 : cur - 1;
+            issue_dma(chunk + NBUF - 1, nb, chunk + NBUF - 1 < chunk_end);
+        }
+        // Fragments are read TWO taps ahead of their MFMAs (three register sets) and every read is pinned behind one MFMA of the
+        // running tap (sched_group_barrier): left to itself the scheduler sank the reads to just in front of their use and every
+        // tap's first MFMA waited out the full LDS latency (s_waitcnt lgkmcnt in front of it, visible in the ISA).
+        Frag f[3];
+        read_frag(cur, 0, f[0]);
+        read_frag(cur, 1, f[1]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) read_frag(cur, tap + 2, f[(tap + 2) % 3]);
+            mma(f[tap % 3]);
+            if (tap + 2 < 9) {
+#pragma unroll
+                for (int g_ = 0; g_ < (MI * NI < MI + NI ? MI * NI : MI + NI); ++g_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (MI * NI > MI + NI) __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - (MI + NI), 0);
+                if (MI + NI > MI * NI) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI - MI * NI, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-record DMAs of the tail still write LDS
+    __syncthreads();                                       // the epilogue reuses the buffers as its staging tile
+
+    // ---- epilogue (the mappings of conv_patch3x3_bf16_kernel)
+    const bool direct = blk.nz == 1;
+    const bool yh = p.yh && direct;
+    float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
+    float* __restrict__ T = reinterpret_cast<float*>(&smem[0]) + wave * (CG * 64);
+    const bool vec_ok = !p.Y2 && (p.Wo & 7) == 0 && (p.out_off & 7) == 0 && (p.out_sc & 7) == 0 && (p.out_sn & 7) == 0 &&
+                        (p.out_sh & 7) == 0 && (p.slab_stride & 7) == 0 && ((uintptr_t)p.Y & 15) == 0;
+    if (vec_ok) {
+#pragma unroll
+        for (int h = 0; h < BM / CG; ++h) {
+            float bv[CG / 32][16];
+#pragma unroll
+            for (int q = 0; q < CG / 32; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + h * CG + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    bv[q][r] = (direct && p.bias && row < p.M) ? p.bias[row] : 0.f;
+                }
+#pragma unroll
+            for (int jp = 0; jp < NI / 2; ++jp) {          // two pixel rows (64 pixels) of this wave per staging pass
+#pragma unroll
+                for (int q = 0; q < CG / 32; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int cl = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            float v = acc[h * (CG / 32) + q][jp * 2 + jj][r] + bv[q][r];
+                            if (direct) v = c2m_act(v, p.act, p.slope);
+                            T[cl * 64 + jj * 32 + (lane & 31)] = v;
+                        }
+                // (each wave reads back only what it wrote, and a wave's LDS operations execute in order: no barrier)
+#pragma unroll
+                for (int it = 0; it < CG / 8; ++it) {
+                    const int cl = it * 8 + (lane >> 3), px = (lane & 7) * 8;
+                    const float4 v0 = *reinterpret_cast<const float4*>(&T[cl * 64 + px]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&T[cl * 64 + px + 4]);
+                    const int row = m0 + h * CG + cl;
+                    const int oy = oy0 + wave * NI + jp * 2 + (px >> 5), ox = ox0 + (px & 31);
+                    if (row < p.M && oy < p.Ho && ox < p.Wo) {
+                        const long e = p.out_off + (long)n_img * p.out_sn + (long)row * p.out_sc + (long)oy * p.out_sh + ox;
+                        if (yh) {
+                            const bf16x8 o = {(bf16_t)v0.x, (bf16_t)v0.y, (bf16_t)v0.z, (bf16_t)v0.w,
+                                              (bf16_t)v1.x, (bf16_t)v1.y, (bf16_t)v1.z, (bf16_t)v1.w};
+                            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.Y) + e));
+                        } else {
+                            const f32x4 a = {v0.x, v0.y, v0.z, v0.w}, b = {v1.x, v1.y, v1.z, v1.w};
+                            __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(Yb + e));
+                            __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(Yb + e + 4));
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int oy = oy0 + wave * NI + j, ox = ox0 + (lane & 31);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        float* ybase = Yb;                                 // element type: float, or bf16_t when yh
+        long yidx = p.out_off + (long)n_img * p.out_sn + (long)oy * p.out_sh + ox;
+        long row_stride = p.out_sc;
+        if (p.Y2) {
+            const int yp = oy * p.ps_y + p.po_y - p.lo_y, xp = ox * p.ps_x + p.po_x - p.lo_x;
+            if ((unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+                ybase = p.Y2;
+                yidx = (long)n_img * p.y2_sn + (long)yp * p.y2_sh + xp;
+                row_stride = p.y2_sc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) {
+                    float v = acc[i][j][r];
+                    if (direct) {
+                        if (p.bias) v += p.bias[row];
+                        v = c2m_act(v, p.act, p.slope);
+                    }
+                    if (yh) reinterpret_cast<bf16_t*>(ybase)[yidx + (long)row * row_stride] = (bf16_t)v;
+                    else ybase[yidx + (long)row * row_stride] = v;
+                }
+            }
+    }
+}
+
+// geom[]: the indices of c2m_conv_igemm's LDS-patch path (include/c2m_hip.h) -- M, nk = 9 * chunks, lda = padded rows of the
+// weight image, Npix, Ho, Wo, Hi, Wi, output strides, reflect, splits, slab stride, cin, the two-target block [36..51], the patch
+// origin / tap order [53..60], yh [91].  X is the NC8 form of the [N][cin][Hi][Wi] bf16 tensor.  2-D layers only.
+C2M_API int c2m_conv_patch_nc8(const void* A, const void* X, void* Y, void* Y_interior, const float* bias, const int64_t* g,
+                               int act, float slope, void* stream) {
+    C2M_ENTER();
+    Nc8P p;
+    p.A = A; p.X = X; p.Y = (float*)Y; p.Y2 = (float*)Y_interior; p.bias = bias;
+    p.M = (int)g[0]; p.Mpad = (int)g[2];
+    p.Ho = (int)g[5]; p.Wo = (int)g[6]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
+    const int nk = (int)g[1], cin = (int)g[28], splits = (int)g[26];
+    if (p.M <= 0 || g[3] <= 0) return 0;
+    if (g[4] != 1 || g[7] != 1 || g[23] != 0 || g[10] != 1 || g[11] != 1 || g[12] != 1 || !g[52] || g[20] != 1)
+        return (int)hipErrorInvalidValue;                  // 2-D, stride 1, unit pixel stride of the output
+    p.nchunks = nk / 9;
+    p.CB = (cin + 7) / 8;
+    if (p.nchunks * 9 != nk || cin <= 0 || cin > p.nchunks * 16 || p.Mpad % 128 != 0 || p.Mpad < p.M || splits < 1 ||
+        (((uintptr_t)A | (uintptr_t)X) & 15))
+        return (int)hipErrorInvalidValue;
+    p.Nimg = (int)(g[3] / ((long)p.Ho * p.Wo));
+    if ((long)p.Nimg * p.Ho * p.Wo != g[3]) return (int)hipErrorInvalidValue;
+    const long xb = (long)p.Nimg * p.CB * p.Hi * p.Wi * 16, ab = (long)p.nchunks * 9 * p.Mpad * 32;
+    if (xb >= 0x80000000LL || ab >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
+    p.out_sn = g[16]; p.out_sc = g[17]; p.out_sh = g[19]; p.out_off = g[21];
+    p.reflect = (int)g[22]; p.slab_stride = g[27];
+    p.act = act; p.slope = slope; p.yh = (int)g[91];
+    if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;
+    p.ps_y = (int)g[37]; p.ps_x = (int)g[38]; p.po_y = (int)g[40]; p.po_x = (int)g[41]; p.lo_y = (int)g[43]; p.lo_x = (int)g[44];
+    p.ext_y = (int)g[46]; p.ext_x = (int)g[47]; p.y2_sn = g[48]; p.y2_sc = g[49]; p.y2_sh = g[51];
+    p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
+    for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
+    p.chunks_per_split = c2m_cdiv(p.nchunks, splits);
+    if (c2m_cdiv(p.nchunks, p.chunks_per_split) != splits) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    // geom[93]: tile / buffering variant (tuning): 0 = rule below; (output rows, LDS buffers, workgroups per CU, tile rows):
+    // 1 (64, 2, 2, 8)   2 (64, 2, 2, 16)   3 (128, 3, 1, 8)   4 (32, 3, 2, 8)   5 (32, 2, 2, 16)   6 (64, 3, 1, 16)
+    int v = (int)g[93];
+    if (v == 0) {
+        // 16-row tiles (half the weight traffic per MFMA, twice the work between barriers) where they still give two full rounds
+        // of workgroups (512 resident: 256 CUs x 2); measured per shape on one box (tools/ab_nc8.py): 938-986 vs 883-910 TF/s on
+        // 256 -> 256 at 64x128, 629-662 vs 596-632 on 128 -> 128, but 811 vs 902 on the 320-workgroup 512 -> 512 layer at 16x32
+        const int BMv = p.M <= 32 ? 32 : 64;
+        const long wg16 = (long)p.Nimg * ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * c2m_cdiv(p.M, BMv) * splits;
+        const bool big = p.Ho >= 16 && wg16 >= 1024;
+        v = p.M <= 32 ? (big ? 5 : 4) : (big ? 2 : 1);
+    }
+#define NC8_LAUNCH(BM, NB, WG, TRW) do {                                                                                 \
+        const long tiles = (long)p.Nimg * ((p.Ho + TRW - 1) / TRW) * ((p.Wo + 31) / 32);                                 \
+        dim3 grid((unsigned)(tiles * c2m_cdiv(p.M, BM) * splits));                                                       \
+        hipLaunchKernelGGL((conv_patch_nc8_kernel<BM, NB, WG, TRW>), grid, dim3(256), 0, s, p); } while (0)
+    switch (v) {
+        case 1: NC8_LAUNCH(64, 2, 2, 8); break;
+        case 2: NC8_LAUNCH(64, 2, 2, 16); break;
+        case 3: NC8_LAUNCH(128, 3, 1, 8); break;
+        case 4: NC8_LAUNCH(32, 3, 2, 8); break;
+        case 5: NC8_LAUNCH(32, 2, 2, 16); break;
+        case 6: NC8_LAUNCH(64, 3, 1, 16); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef NC8_LAUNCH
+    return (int)hipGetLastError();
+}

@@ -270,11 +270,15 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
     if tuple(stride) != (1, 1, 1) or M <= 4 or C < 12 or Wo < 32 or Ho < 8 or _ceil(C, 16) > 1.25 * C:
         return False
     fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
+    if _NC8:              # the channel-blocked kernel (conv_nc8.hip) has no 2-byte gathers to amortise: every layer whose tiles fit
+        return fill <= _PATCH_FILL[1]
     if C < 128:
         return (M <= 64 or _PATCH_SMALLC) and fill <= 1.2
     return fill <= _PATCH_FILL[0] or (fill <= _PATCH_FILL[1] and C >= 256)
 
 
+_NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+_NC8 = os.environ.get("C2M_NC8", "1") != "0"        # bf16 3x3 stride-1 layers on channel-blocked input (A/B knob)
 _PATCH_FILL = tuple(float(v) for v in os.environ.get("C2M_PATCH_FILL", "1.15,1.4").split(","))     # tuning knobs (A/B runs)
 _PATCH_SMALLC = os.environ.get("C2M_PATCH_SMALLC", "0") == "1"
 
@@ -306,6 +310,21 @@ def _patch_splits(L, M, C, npix, bf16=False):
     nch = _cdiv(C, 16)
     s0 = _splits(L, M, nch * 9, npix, bf16)
     return _cdiv(nch, _cdiv(nch, s0))
+
+
+def _to_nc8(x):
+    """c2m_nchw_to_nc8: contiguous bf16 [N, C, H, W] -> [N, ceil(C/8), H, W, 8] (the conv input form of conv_nc8.hip)."""
+    N, C, H, W = x.shape
+    y = torch.empty(N, _cdiv(C, 8), H, W, 8, device=x.device, dtype=BF16)
+    _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, H * W, _stream()), "nchw_to_nc8")
+    return y
+
+
+def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope):
+    """One 3x3 stride-1 launch on channel-blocked input: the layout pass + c2m_conv_patch_nc8 (timed together)."""
+    xn = _to_nc8(x)
+    geom[93] = _NC8_VARIANT
+    return L.c2m_conv_patch_nc8(_p(A), _p(xn), _p(dst), _p(y2), _p(b), _gp(geom), act, slope, _stream())
 
 
 def _set_patch(geom, iy0, ix0, pty, ptx):
@@ -552,6 +571,8 @@ class _ConvPlan:
         # ---- forward
         self.ck = ck = _choose_ck(Cin, taps)
         self.fwd_patch = False
+        # channel-blocked input (conv_nc8.hip): 2-D bf16 patch layers whose planes are whole 8-pixel groups
+        self.nc8 = bool(bf16 and _NC8 and nd == 2 and (Hi * Wi) % 8 == 0 and (Ho * Wo) % 8 == 0)
         if (kt, kh, kw) == (1, 3, 3) and (_patch_bf16_ok(Cin, stride, Ho, Wo, Cout) if bf16 else
                                           _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout)):
             self.fwd_patch, self.ck = True, 16
@@ -972,9 +993,12 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
             tag = ("dgrad", Cin, Cout * c["taps"], c["npix"], pl.dims[9:12], pl.stride, pl.reflect, S)
             gin = (gy_f if thin_of.get(id(c)) else gy_b) if pl.bf16 else gy
             _set_io(c["geom"], gin, torch.float32 if thin_of.get(id(c)) else kdt)
+            nc8 = c["patch"] and pl.bf16 and _NC8 and not pl.is3d and (pl.dims[7] * pl.dims[8]) % 8 == 0
             _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
-                              lambda: L.c2m_conv_igemm(_p(A), _p(gin), _p(dst), _p(gx) if two_target else None, None,
-                                                       _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream()), tag,
+                              (lambda: _nc8_launch(L, A, gin, dst, gx if two_target else None, None, c["geom"], 0, 0.0)) if nc8 else
+                              (lambda: L.c2m_conv_igemm(_p(A), _p(gin), _p(dst), _p(gx) if two_target else None, None,
+                                                        _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream())),
+                              tag + (("nc8",) if nc8 else ()),
                               4 * (gy.numel() + w.numel() + xnumel) // len(pl.classes)), "conv_igemm dgrad")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(tgt), None, tgt.numel(), S, 1, 1, 0, 0.0, _dt(tgt), _stream()),
@@ -1039,9 +1063,11 @@ class _ConvFn(torch.autograd.Function):
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _set_io(pl.fwd_geom, x, ydt)
+        nc8 = pl.fwd_patch and pl.bf16 and pl.nc8
         _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                          lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
-                                                   ACT[act], slope, _stream()), tag,
+                          (lambda: _nc8_launch(L, A, x, dst, None, b, pl.fwd_geom, ACT[act], slope)) if nc8 else
+                          (lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
+                                                    ACT[act], slope, _stream())), tag + (("nc8",) if nc8 else ()),
                           x.element_size() * x.numel() + 4 * w.numel() + y.element_size() * y.numel()), "conv_igemm fwd")
         if S > 1:
             _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],

@@ -89,6 +89,18 @@ int c2m_pack_multi(const void* device_jobs, const void* device_blocktab /* int32
 long c2m_pack_weights_bf16_patch_bytes(int M, int C);
 int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, void* stream);
 
+/* Channel-blocked ("NC8") bf16 convolutions (conv_nc8.hip, round 4; the same 3x3 stride-1 call sites -- vgg.py:92-137,
+ * residual_block.py:13-31,42-71, spade_block.py:47-49, up_block.py:9-13, same_block.py:14-23 -- in bf16 mode).
+ * c2m_nchw_to_nc8: [N][C][HW] bf16 -> [N][ceil(C/8)][HW][8] bf16 (zero channels past C; HW % 8 == 0): the 8 channels one
+ * MFMA lane consumes become ONE 16-byte unit.  c2m_conv_patch_nc8: D = act(W * patches(X) + bias) for a 2-D 3x3 stride-1
+ * layer with X in NC8, A = the c2m_pack_weights_bf16_patch image, operands fetched global -> LDS by 16-byte LDS-DMA;
+ * geom[] as for c2m_conv_igemm's LDS-patch path (0 M, 1 nk = 9 * chunks, 2 padded rows of A, 3 Npix, 5 Ho, 6 Wo, 8 Hi, 9 Wi,
+ * 16-21 output strides / offset, 22 reflect, 26 splits, 27 slab stride, 28 Cin, 36-51 two-target block, 52 = 1, 53-60 patch
+ * origin and tap order, 91 output type); Y / Y_interior are NCHW (bf16 or fp32), split-K slabs fp32.                        */
+int c2m_nchw_to_nc8(const void* x, void* y, long N, int C, long HW, void* stream);
+int c2m_conv_patch_nc8(const void* A, const void* X_nc8, void* Y, void* Y_interior, const float* bias, const int64_t* geom,
+                       int act, float slope, void* stream);
+
 /* Winograd F(2x2,3x3) form of the 3x3 stride-1 layers (conv_wino.hip; same reference call sites as above: vgg.py:92-137,
  * spade_block.py:47-49, residual_block.py:13-71, up_block.py:9-13): 2.25x fewer MFMA FLOPs, fp32, bias/activation fused.
  * c2m_wino_filter_transform packs U = G g G^T in the kernel's fragment order (dgrad = 1: transposed + rotated filter of

@@ -2,7 +2,7 @@
 set -e
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r02/pmc_ab
+O=$R/${PMC_OUT:-gpurun_out/r02/pmc_ab}
 rm -rf $O; mkdir -p $O
 export AB_SHAPES=${AB_SHAPES:-2}
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/p1 -- python3 ${PMC_CMD:-tools/ab_wino_wgrad.py 10} > $O/p1.log 2>&1 || tail -5 $O/p1.log
@@ -10,7 +10,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 ${PMC_CMD:-tools/ab_wino_wgrad.py 10} > $O/kt.log 2>&1 || tail -5 $O/kt.log
 python3 - <<'PY'
 import csv, glob, collections
-O = "gpurun_out/r02/pmc_ab"
+import os
+O = os.environ.get("PMC_OUT", "gpurun_out/r02/pmc_ab")
 def load(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in glob.glob(f"{O}/{d}/*/*counter_collection.csv"):
