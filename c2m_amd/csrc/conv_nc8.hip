@@ -401,3 +401,271 @@ C2M_API int c2m_conv_patch_nc8(const void* A, const void* X, void* Y, void* Y_in
 #undef NC8_LAUNCH
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient on NC8 operands
+// dW[m][c][ky][kx] = sum_{n,y,x} dY[n][m][y][x] * X[n][c][y + ky - 1][x + kx - 1]   (3x3, stride 1, pad 1 zeros / reflect)
+// as 9 GEMMs D_tap[m][c] over K = pixels on v_mfma_f32_32x32x16_bf16.  Both operands need 8 consecutive PIXELS of one channel
+// per lane; NC8 stores 8 channels of one pixel per 16-byte unit -- the transposed form -- so the LDS images are plain copies of
+// NC8 rows ([channel block][pixel], 16-byte LDS-DMA like the forward kernel) and the fragments come out of them with
+// ds_read_b64_tr_b16 (per 16 lanes: 4 pixels x 16 channels delivered channel-per-lane).  A tap shift moves along the PIXEL axis
+// (units), never inside a unit, so every transposed read stays 8-byte aligned for every tap -- on NCHW the +-1 pixel taps are what
+// broke that alignment, and the NCHW kernel (conv_wgrad_wide_bf16_kernel) spends 15.8 VALU per MFMA on
+// shifting pixel groups in registers.
+// Workgroup = 64 dY channels x 32 X channels x 9 taps over a range of 4 x 32-pixel chunks; wave (mh, kh) owns 32 dY channels and
+// the K-steps of two of the chunk's four rows for ALL taps (9 accumulator tiles).  The two kh waves write separate slabs (no
+// cross-wave sum inside the kernel), deterministic reduction afterwards (wgrad_nc8_reduce_kernel).  Plane strides 132 / 204 units
+// keep the four channel blocks of a transposed read on disjoint banks.
+struct WgNc8P {
+    const void* dY; const void* X;
+    float* slab;          // [S][9][Mp][Cp]
+    float* dbslab;        // [S][Mp]
+    int M, C, Mp, Cp, CBy, CBx;
+    int Nimg, H, W, reflect;
+    int chunks_y, chunks_x, nchunks, chunks_per_split;
+    unsigned dy_bytes, x_bytes;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 nc8_tr_frag(const unsigned lds_byte, const int off0) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(unsigned long)(lds_byte + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(unsigned long)(lds_byte + off0 + 64));      // + 4 pixels
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) {
+    constexpr int DPL = 132, XPL = 204;                           // plane strides (units)
+    constexpr int SD = 8 * DPL, SX = 4 * XPL + 16 + 64;           // dY image, X image (+ pad, + a dump row for the filler DMA)
+    constexpr int BUF = SD + SX;                                  // 1952 units = 31232 B
+    constexpr int NDMA = 8;
+    __shared__ uint4 smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = wave & 1, kh = wave >> 1;
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Cp / 32), (unsigned)(p.Mp / 64), 0);
+    const int m0 = blk.y * 64, c0 = blk.x * 32, split = blk.z;
+    const int cby0 = m0 >> 3, cbx0 = c0 >> 3;
+    const unsigned HW16 = (unsigned)(p.H * p.W) * 16u;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
+
+    const unsigned long ya = (unsigned long)p.dY, xa = (unsigned long)p.X;
+    const u32x4 yrs = {(unsigned)ya, (unsigned)(ya >> 32) & 0xffffu, p.dy_bytes, 0x00020000u};
+    const u32x4 xrs = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    // ---- dY DMA rows of this wave: I = wave * 4 + j -> channel block I >> 1, row pair I & 1; lane -> (row, column)
+    const int d_r = lane >> 5, d_col = lane & 31;
+    // ---- X DMA rows: I = wave + 4 * j (I = 12 only in wave 0; the other waves issue a zero-record filler)
+    int x_plane[4], x_prow[4], x_pcol[4];
+    bool x_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u = (wave + 4 * j) * 64 + lane;
+        const int pl = u / XPL, pos = u % XPL;
+        x_plane[j] = pl; x_prow[j] = pos / 34; x_pcol[j] = pos % 34;
+        x_ok[j] = u < 4 * XPL && cbx0 + pl < p.CBx;
+    }
+    auto issue_dma = [&](int chunk, int buf, bool live) {
+        int t = chunk;
+        const int cx = t % p.chunks_x; t /= p.chunks_x;
+        const int cy = t % p.chunks_y; const int n = t / p.chunks_y;
+        const int y0 = cy * 4, x0 = cx * 32;
+        const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
+        // dY: 4 rows of 64 units
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int I = wave * 4 + j, cb = I >> 1, r = (I & 1) * 2 + d_r;
+            const bool ok = y0 + r < p.H && x0 + d_col < p.W;
+            const unsigned vo = ok ? ((unsigned)(n * p.CBy + cby0 + cb) * HW16 + (unsigned)((y0 + r) * p.W + x0 + d_col) * 16u) : NC8_OOB;
+            u32x4 rs = yrs;
+            rs[2] = (live && cby0 + cb < p.CBy) ? p.dy_bytes : 0u;
+            const unsigned dst = base + (unsigned)((cb * DPL + (I & 1) * 64) * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(vo), "s"(rs) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int I = wave + 4 * j;
+            int iy = y0 - 1 + x_prow[j], ix = x0 - 1 + x_pcol[j];
+            if (p.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+            }
+            const bool ok = x_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned vo = ok ? ((unsigned)(n * p.CBx + cbx0 + x_plane[j]) * HW16 + (unsigned)(iy * p.W + ix) * 16u) : NC8_OOB;
+            u32x4 rs = xrs;
+            rs[2] = (live && I < 13) ? p.x_bytes : 0u;
+            const unsigned dst = base + (unsigned)((SD + (I < 13 ? I * 64 : 4 * XPL + 16)) * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(vo), "s"(rs) : "memory");
+        }
+    };
+
+    f32x16 acc[9], accb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bool want_bias = blk.x == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    // transposed-read lane addresses: 16-lane group g = lane >> 4 reads channels 16 * (g & 1) ... of pixels 8 * (g >> 1) + q; lane
+    // 4q + pp of the group supplies row (pixel) q, 8-byte half pp & 1 of channel block 2 * (g & 1) + (pp >> 1)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned a_lane = (unsigned)((((mh * 4 + 2 * (g & 1) + (pp >> 1)) * DPL + 8 * (g >> 1) + q + kh * 64) * 16) + 8 * (pp & 1));
+    const unsigned b_lane = (unsigned)(((SD + (2 * (g & 1) + (pp >> 1)) * XPL + 8 * (g >> 1) + q + kh * 2 * 34) * 16) + 8 * (pp & 1));
+
+    const int chunk_beg = split * p.chunks_per_split;
+    int chunk_end = chunk_beg + p.chunks_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
+    issue_dma(chunk_beg < p.nchunks ? chunk_beg : 0, 0, chunk_beg < chunk_end);
+    int cur = 0;
+    for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_dma(chunk + 1 < chunk_end ? chunk + 1 : chunk, cur ^ 1, chunk + 1 < chunk_end);
+        const unsigned ab = lds0 + (unsigned)(cur * BUF * 16) + a_lane, bb = lds0 + (unsigned)(cur * BUF * 16) + b_lane;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const int r = ss >> 1, cc = (ss & 1) * 16;
+            const bf16x8 A = nc8_tr_frag(ab, (r * 32 + cc) * 16);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf16x8 B = nc8_tr_frag(bb, ((r + t / 3) * 34 + cc + t % 3) * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[t], 0, 0, 0);
+            }
+            if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ones, accb, 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the two pixel halves (kh) of a row tile are summed inside the workgroup (fixed order: kh 0 + kh 1) through the now free
+    // LDS images, five and four taps at a time (a tap tile of one wave = 4 KB); halves the slab traffic of the launch
+    __syncthreads();
+    float* __restrict__ xch = reinterpret_cast<float*>(&smem[0]) + mh * (5 * 16 * 64);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const int t0 = ph * 5, nt = ph ? 4 : 5;
+        if (kh == 1) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 64 + lane] = acc[t0 + t][r];
+            if (ph == 0 && want_bias)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) reinterpret_cast<float*>(&smem[0])[2 * 5 * 16 * 64 + (mh * 16 + r) * 64 + lane] = accb[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (t < nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t0 + t][r] += xch[(t * 16 + r) * 64 + lane];
+            if (ph == 0 && want_bias)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accb[r] += reinterpret_cast<float*>(&smem[0])[2 * 5 * 16 * 64 + (mh * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (kh != 0) return;
+    // ---- slabs: [split][tap][m][c]; an accumulator register is 32 consecutive c of one row
+    float* __restrict__ sb = p.slab + (long)split * 9 * p.Mp * p.Cp;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sb[((long)t * p.Mp + row) * p.Cp + c0 + (lane & 31)] = acc[t][r];
+        }
+    if (want_bias && (lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            p.dbslab[(long)split * p.Mp + row] = accb[r];
+        }
+    }
+}
+
+// dW[m][c][tap] = sum over slabs; db[m] likewise.  Thread = (tap, m, c) with c fastest (coalesced slab reads); four interleaved
+// partial sums keep the loads in flight, combined in a fixed order -> bit-reproducible.
+__global__ void wgrad_nc8_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab, float* __restrict__ dW,
+                                        float* __restrict__ db, int M, int C, int Mp, int Cp, int nslab) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long MC = (long)M * C;
+    if (i < 9 * MC) {
+        const int t = (int)(i / MC);
+        const long mc = i % MC;
+        const int c = (int)(mc % C), m = (int)(mc / C);
+        const float* __restrict__ q = slab + ((long)t * Mp + m) * Cp + c;
+        const long st = 9L * Mp * Cp;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < nslab; k += 4) {
+            s0 += q[(long)k * st]; s1 += q[(long)(k + 1) * st]; s2 += q[(long)(k + 2) * st]; s3 += q[(long)(k + 3) * st];
+        }
+        for (; k < nslab; ++k) s0 += q[(long)k * st];
+        dW[mc * 9 + t] = (s0 + s1) + (s2 + s3);
+    }
+    if (db && i < M) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += dbslab[(long)k * Mp + i];
+        db[i] = s;
+    }
+}
+
+static void wgrad_nc8_shape(int M, int C, long N, int H, int W, int& Mp, int& Cp, long& nchunks, int& S) {
+    Mp = c2m_cdiv(M, 64) * 64; Cp = c2m_cdiv(C, 32) * 32;
+    nchunks = N * c2m_cdiv(H, 4) * c2m_cdiv(W, 32);
+    const long tiles = (long)(Mp / 64) * (Cp / 32);
+    long s = (768 + tiles - 1) / tiles;                           // ~1.5 resident rounds of 512 workgroups ...
+    // ... but >= 16 chunks (2048 pixels, ~10 us of MFMAs) per split: every workgroup writes a 73 KB slab that is read back
+    const long maxs = nchunks / 16 > 0 ? nchunks / 16 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    const long per = (nchunks + s - 1) / s;
+    S = (int)((nchunks + per - 1) / per);
+}
+
+// Floats the caller provides: slab = S * 9 * Mp * Cp, then dbslab = S * Mp (S = c2m_conv_wgrad_nc8_splits).
+C2M_API int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W) {
+    int Mp, Cp, S; long nch;
+    wgrad_nc8_shape(M, C, N, H, W, Mp, Cp, nch, S);
+    return S;
+}
+C2M_API long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W) {
+    int Mp, Cp, S; long nch;
+    wgrad_nc8_shape(M, C, N, H, W, Mp, Cp, nch, S);
+    return (long)S * (9L * Mp * Cp + Mp);
+}
+
+// dY_nc8: [N][ceil(M/8)][H][W][8], X_nc8: [N][ceil(C/8)][H][W][8] (bf16); dW: [M][C][3][3] fp32; db: [M] fp32 or NULL.
+C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N,
+                               int H, int W, int reflect, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || C <= 0 || N <= 0) return 0;
+    WgNc8P p;
+    long nch; int S;
+    wgrad_nc8_shape(M, C, N, H, W, p.Mp, p.Cp, nch, S);
+    p.dY = dY_nc8; p.X = X_nc8; p.M = M; p.C = C; p.CBy = (M + 7) / 8; p.CBx = (C + 7) / 8;
+    p.Nimg = (int)N; p.H = H; p.W = W; p.reflect = reflect;
+    p.chunks_y = c2m_cdiv(H, 4); p.chunks_x = c2m_cdiv(W, 32); p.nchunks = (int)nch;
+    p.chunks_per_split = c2m_cdiv(nch, S);
+    const long yb = N * p.CBy * (long)H * W * 16, xb = N * p.CBx * (long)H * W * 16;
+    if (yb >= 0x80000000LL || xb >= 0x80000000LL || nch >= 0x7fffffffLL || (((uintptr_t)dY_nc8 | (uintptr_t)X_nc8) & 15) ||
+        (reflect && (H < 2 || W < 2)))
+        return (int)hipErrorInvalidValue;
+    p.dy_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
+    p.slab = slab; p.dbslab = slab + (long)S * 9 * p.Mp * p.Cp;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((p.Mp / 64) * (p.Cp / 32) * S));
+    hipLaunchKernelGGL(conv_wgrad_nc8_kernel, grid, dim3(256), 0, s, p);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    const long n = 9L * M * C;
+    hipLaunchKernelGGL(wgrad_nc8_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.slab, p.dbslab, dW, db, M, C,
+                       p.Mp, p.Cp, S);
+    return (int)hipGetLastError();
+}

@@ -271,13 +271,15 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
         return False
     fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
     if _NC8:              # the channel-blocked kernel (conv_nc8.hip) has no 2-byte gathers to amortise: every layer whose tiles fit
-        return fill <= _PATCH_FILL[1]
+        return fill <= _NC8_FILL      # (the padded 34x66 domain of a reflect data gradient fills 58 % of its tiles: still 1.5x the gather kernel)
     if C < 128:
         return (M <= 64 or _PATCH_SMALLC) and fill <= 1.2
     return fill <= _PATCH_FILL[0] or (fill <= _PATCH_FILL[1] and C >= 256)
 
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+_NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "1.8"))
+_NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
 _NC8 = os.environ.get("C2M_NC8", "1") != "0"        # bf16 3x3 stride-1 layers on channel-blocked input (A/B knob)
 _PATCH_FILL = tuple(float(v) for v in os.environ.get("C2M_PATCH_FILL", "1.15,1.4").split(","))     # tuning knobs (A/B runs)
 _PATCH_SMALLC = os.environ.get("C2M_PATCH_SMALLC", "0") == "1"
@@ -312,17 +314,25 @@ def _patch_splits(L, M, C, npix, bf16=False):
     return _cdiv(nch, _cdiv(nch, s0))
 
 
-def _to_nc8(x):
-    """c2m_nchw_to_nc8: contiguous bf16 [N, C, H, W] -> [N, ceil(C/8), H, W, 8] (the conv input form of conv_nc8.hip)."""
+def _to_nc8(x, keep=None):
+    """c2m_nchw_to_nc8: contiguous bf16 [N, C, H, W] -> [N, ceil(C/8), H, W, 8] (the conv input form of conv_nc8.hip).
+    keep: a dict that remembers the result per source tensor (the data gradient and the weight gradient of one backward node
+    share the NC8 form of dY)."""
+    if keep is not None:
+        hit = keep.get(x.data_ptr())
+        if hit is not None and hit[0] is x:
+            return hit[1]
     N, C, H, W = x.shape
     y = torch.empty(N, _cdiv(C, 8), H, W, 8, device=x.device, dtype=BF16)
     _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, H * W, _stream()), "nchw_to_nc8")
+    if keep is not None:
+        keep[x.data_ptr()] = (x, y)
     return y
 
 
-def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope):
+def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope, keep=None):
     """One 3x3 stride-1 launch on channel-blocked input: the layout pass + c2m_conv_patch_nc8 (timed together)."""
-    xn = _to_nc8(x)
+    xn = _to_nc8(x, keep)
     geom[93] = _NC8_VARIANT
     return L.c2m_conv_patch_nc8(_p(A), _p(xn), _p(dst), _p(y2), _p(b), _gp(geom), act, slope, _stream())
 
@@ -573,6 +583,9 @@ class _ConvPlan:
         self.fwd_patch = False
         # channel-blocked input (conv_nc8.hip): 2-D bf16 patch layers whose planes are whole 8-pixel groups
         self.nc8 = bool(bf16 and _NC8 and nd == 2 and (Hi * Wi) % 8 == 0 and (Ho * Wo) % 8 == 0)
+        # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
+        self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
+                              (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)
         if (kt, kh, kw) == (1, 3, 3) and (_patch_bf16_ok(Cin, stride, Ho, Wo, Cout) if bf16 else
                                           _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout)):
             self.fwd_patch, self.ck = True, 16
@@ -880,7 +893,7 @@ def _set_io(geom, x, ydt):
     return geom
 
 
-def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
+def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
     """Data gradient of the convolution described by plan `pl` (= the transposed convolution of gy with w): shared by
     _ConvFn.backward and conv_transpose2d.  gy contiguous [N, Cout, (To,) Ho, Wo]; returns [N, Cin, (Ti,) Hi, Wi] in
     `out_dtype` (the dtype of the forward input: bf16 on the bf16 data path, fp32 for fp32 inputs)."""
@@ -995,7 +1008,7 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32):
             _set_io(c["geom"], gin, torch.float32 if thin_of.get(id(c)) else kdt)
             nc8 = c["patch"] and pl.bf16 and _NC8 and not pl.is3d and (pl.dims[7] * pl.dims[8]) % 8 == 0
             _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", pl.dgrad_flops * c["taps"] * c["npix"] / pl.dgrad_work,
-                              (lambda: _nc8_launch(L, A, gin, dst, gx if two_target else None, None, c["geom"], 0, 0.0)) if nc8 else
+                              (lambda: _nc8_launch(L, A, gin, dst, gx if two_target else None, None, c["geom"], 0, 0.0, keep)) if nc8 else
                               (lambda: L.c2m_conv_igemm(_p(A), _p(gin), _p(dst), _p(gx) if two_target else None, None,
                                                         _p(c["tab"]), _gp(c["geom"]), 0, 0.0, _stream())),
                               tag + (("nc8",) if nc8 else ()),
@@ -1024,6 +1037,7 @@ class _ConvFn(torch.autograd.Function):
         N, Cin, Cout = pl.dims[0:3]
         ctx.frozen_w = not ctx.needs_input_grad[1]
         ctx.x_dtype = x.dtype
+        ctx.nc8_keep = None
         if not pl.bf16:
             x = _as(x, torch.float32)            # the fp32 kernels are fp32 in, fp32 out
         if pl.wino_fwd:
@@ -1064,8 +1078,9 @@ class _ConvFn(torch.autograd.Function):
         tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _set_io(pl.fwd_geom, x, ydt)
         nc8 = pl.fwd_patch and pl.bf16 and pl.nc8
+        ctx.nc8_keep = {} if (nc8 and pl.wgrad_nc8 and ctx.needs_input_grad[1]) else None      # X in NC8 form, for the weight gradient
         _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
-                          (lambda: _nc8_launch(L, A, x, dst, None, b, pl.fwd_geom, ACT[act], slope)) if nc8 else
+                          (lambda: _nc8_launch(L, A, x, dst, None, b, pl.fwd_geom, ACT[act], slope, ctx.nc8_keep)) if nc8 else
                           (lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
                                                     ACT[act], slope, _stream())), tag + (("nc8",) if nc8 else ()),
                           x.element_size() * x.numel() + 4 * w.numel() + y.element_size() * y.numel()), "conv_igemm fwd")
@@ -1095,30 +1110,51 @@ class _ConvFn(torch.autograd.Function):
         # behind MFMA kernels.  Fork / join are events, so a HIP-graph capture records the same parallel branches.
         side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and pl.bf16 and torch.cuda.is_current_stream_capturing())
         side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
+        # NC8 form of dY: one layout pass shared by the data gradient and the weight gradient of this node (made on the main
+        # stream BEFORE a fork, so the side stream's launch is ordered behind it)
+        keep = {} if (pl.bf16 and pl.nc8) else None
+        if keep is not None and need_w and pl.wgrad_nc8:
+            gy = _as(gy, BF16)
+            _to_nc8(gy, keep)
         if side is not None:
             main = torch.cuda.current_stream(x.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy)
-            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype)
+                gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy, keep)
+            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype, keep)
             main.wait_stream(side)
             for t in (gw, gb):
                 if t is not None:
                     t.record_stream(main)       # allocated in the side stream's pool, consumed (and freed) on the main stream
             return gx, gw, gb, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
-            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype)
+            gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype, keep)
         if need_w:
-            gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy)
+            gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy, keep)
         return gx, gw, gb, None, None, None, None, None, None
 
     @staticmethod
-    def _wgrad(ctx, pl, x, w, gy):
+    def _wgrad(ctx, pl, x, w, gy, keep=None):
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
         gw = gb = None
         if not pl.bf16:
             gy = _as(gy, torch.float32)
+        want = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if want and pl.bf16 and pl.wgrad_nc8:
+            # both operands in NC8 form: X from the forward launch (ctx.nc8_keep) or converted now, dY shared with the data gradient
+            Hi, Wi = pl.dims[4:6]
+            gyn = _to_nc8(_as(gy, BF16), keep)
+            xn = next(iter(ctx.nc8_keep.values()))[1] if ctx.nc8_keep else _to_nc8(_as(x, BF16))
+            slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N, Hi, Wi), device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+                              lambda: L.c2m_conv_wgrad_nc8(_p(gyn), _p(xn), _p(slab), _p(gw), _p(gb_t), Cout, Cin, N, Hi, Wi,
+                                                           int(pl.reflect), _stream()), tag,
+                              2 * (gyn.numel() + xn.numel()) + 4 * w.numel()), "conv_wgrad_nc8")
+            return gw, (gb_t if ctx.has_bias else None)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:
             S = pl.wino_wg_splits
             Ti, Hi, Wi = pl.dims[3:6]

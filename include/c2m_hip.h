@@ -100,6 +100,13 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
 int c2m_nchw_to_nc8(const void* x, void* y, long N, int C, long HW, void* stream);
 int c2m_conv_patch_nc8(const void* A, const void* X_nc8, void* Y, void* Y_interior, const float* bias, const int64_t* geom,
                        int act, float slope, void* stream);
+/* Weight (+ bias) gradient of a 2-D 3x3 stride-1 pad-1 layer from NC8 operands: dW[m][c][ky][kx] = sum dY[n][m][y][x] *
+ * X[n][c][y+ky-1][x+kx-1] (zeros or reflect padding), fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds
+ * c2m_conv_wgrad_nc8_slab_floats(...) floats of scratch (per-split partial sums, reduced in a fixed order); db may be NULL.  */
+int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W);
+long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W);
+int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int H,
+                       int W, int reflect, void* stream);
 
 /* Winograd F(2x2,3x3) form of the 3x3 stride-1 layers (conv_wino.hip; same reference call sites as above: vgg.py:92-137,
  * spade_block.py:47-49, residual_block.py:13-71, up_block.py:9-13): 2.25x fewer MFMA FLOPs, fp32, bias/activation fused.

@@ -32,19 +32,21 @@ def run(mode_nc8, N, Cin, H, W, Cout, pad):
             x.grad = w.grad = None
             y = ops.conv(x, w, b, stride=1, padding=1, padding_mode=pad, act="lrelu")
             y.backward(go)
-    tab = {r[0][1]: (r[2] / r[1] * 1000, r[3], r[0][-1]) for r in prof.table() if r[0][0] == "igemm_bf16"}
-    return y.detach(), x.grad.clone(), tab
+    tab = {r[0][1]: (r[2] / r[1] * 1000, r[3], r[0][-1]) for r in prof.table() if r[0][0] in ("igemm_bf16", "wgrad_bf16")}
+    return y.detach(), x.grad.clone(), tab, w.grad.clone()
 
 
 VARIANTS = [int(v) for v in os.environ.get("AB_VARIANTS", "0").split(",")]
 for shp in SHAPES:
-    y0, g0, t0 = run(False, *shp)
-    msg = f"{str(shp):40s} old fwd {t0['fwd'][0]:6.1f} us {t0['fwd'][1]:4.0f} TF/s dgrad {t0['dgrad'][0]:6.1f} us {t0['dgrad'][1]:4.0f} TF/s"
+    y0, g0, t0, w0 = run(False, *shp)
+    msg = f"{str(shp):40s} old fwd {t0['fwd'][0]:6.1f} us {t0['fwd'][1]:4.0f} TF/s dgrad {t0['dgrad'][0]:6.1f} us {t0['dgrad'][1]:4.0f} wgrad {t0['wgrad'][0]:6.1f} us {t0['wgrad'][1]:4.0f}"
     for v in VARIANTS:
         ops._NC8_VARIANT = v if not (v in (4, 5) and shp[4] > 32) and not (shp[4] <= 32 and v in (1, 2, 3, 6)) else (5 if v in (2, 6) else 4)
-        y1, g1, t1 = run(True, *shp)
+        y1, g1, t1, w1 = run(True, *shp)
         same = torch.equal(y0, y1), torch.equal(g0, g1)
-        msg += f" | v{ops._NC8_VARIANT}: fwd {t1['fwd'][0]:6.1f} us {t1['fwd'][1]:4.0f} dgrad {t1['dgrad'][0]:6.1f} us {t1['dgrad'][1]:4.0f} {t1['dgrad'][2]} same={int(same[0])}{int(same[1])}"
+        werr = float((w1 - w0).abs().max() / w0.abs().max())
+        msg += (f" | v{ops._NC8_VARIANT}: fwd {t1['fwd'][0]:6.1f} us {t1['fwd'][1]:4.0f} dgrad {t1['dgrad'][0]:6.1f} us {t1['dgrad'][1]:4.0f} {t1['dgrad'][2]} "
+                f"wgrad {t1['wgrad'][0]:6.1f} us {t1['wgrad'][1]:4.0f} {t1['wgrad'][2]} same={int(same[0])}{int(same[1])} gw rel diff {werr:.1e}")
     print(msg, flush=True)
 # the layout pass alone
 for N, C, H, W in ((40, 128, 64, 128), (40, 64, 128, 256), (40, 256, 32, 64)):
