@@ -2716,8 +2716,17 @@ __device__ __forceinline__ void pack_weights_bf16_patch_body(const float* __rest
     for (long u = b0 * (long)blockDim.x + threadIdx.x; u < units; u += nb * blockDim.x) {
         const int half = (int)(u & 1); long r = u >> 1;
         const int m = (int)(r % Mpad); r /= Mpad;
-        const int tap = (int)(r % 9); const int chunk = (int)(r / 9);
-        const int st = flip ? 8 - tap : tap;
+        int tap, chunk, st;
+        if (flip == 2) {
+            // 4x4 stride-2 layers on the parity-plane kernel (conv_nc8.hip, S2): out[16-channel chunk][parity py*2+px][tap a*2+b]
+            // [row][16 channels] with original tap (ky, kx) = (2a + 1 - py, 2b + 1 - px)
+            const int t4 = (int)(r % 4); r /= 4;
+            const int par = (int)(r % 4); chunk = (int)(r / 4);
+            st = (2 * (t4 >> 1) + 1 - (par >> 1)) * 4 + 2 * (t4 & 1) + 1 - (par & 1);
+        } else {
+            tap = (int)(r % 9); chunk = (int)(r / 9);
+            st = flip ? 8 - tap : tap;
+        }
         bf16x8 q;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -2737,6 +2746,10 @@ __global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint
 C2M_API long c2m_pack_weights_bf16_patch_bytes(int M, int C) {
     return (long)c2m_cdiv(C, 16) * 9 * (c2m_cdiv(M, 128) * 128) * 32;
 }
+// (flip = 2: the 4x4 stride-2 parity form, 16 (parity, tap) slots per chunk instead of 9 taps)
+C2M_API long c2m_pack_weights_bf16_s2_bytes(int M, int C) {
+    return (long)c2m_cdiv(C, 16) * 16 * (c2m_cdiv(M, 128) * 128) * 32;
+}
 
 C2M_API int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, void* stream) {
     C2M_ENTER();
@@ -2744,7 +2757,7 @@ C2M_API int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t
     if (M <= 0 || C <= 0) return 0;
     if ((((uintptr_t)out) & 15) != 0) return (int)hipErrorInvalidValue;
     const int Mpad = c2m_cdiv(M, 128) * 128;
-    const long units = (long)c2m_cdiv(C, 16) * 9 * Mpad * 2;
+    const long units = (long)c2m_cdiv(C, 16) * (g[4] == 2 ? 16 : 9) * Mpad * 2;
     hipLaunchKernelGGL(pack_weights_bf16_patch_kernel, dim3(c2m_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (uint4*)out, M, C, Mpad, (long)g[2], (long)g[3], (int)g[4], units);
     return (int)hipGetLastError();
@@ -2810,7 +2823,7 @@ C2M_API long c2m_pack_job_fill(void* job, int type, const void* w, void* out, co
         j.M = (int)g[0]; j.C = (int)g[1]; j.s_m = g[2]; j.s_c = g[3]; j.flip = (int)g[4];
         if (j.M <= 0 || j.C <= 0 || (((uintptr_t)out) & 15) != 0) return -1;
         j.Mpad = c2m_cdiv(j.M, 128) * 128;
-        j.units = (long)c2m_cdiv(j.C, 16) * 9 * j.Mpad * 2;
+        j.units = (long)c2m_cdiv(j.C, 16) * (j.flip == 2 ? 16 : 9) * j.Mpad * 2;
         j.xblocks = 1;
         j.nblocks = (unsigned)c2m_grid(j.units, 256);
     } else {

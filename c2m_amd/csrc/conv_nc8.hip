@@ -17,6 +17,8 @@
 //   bias + activation), so nothing downstream changes.
 #include "common.h"
 #include "dtype.h"
+#include <string.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -90,15 +92,21 @@ struct Nc8P {
     unsigned x_bytes, a_bytes;
 };
 
-template <int BM, int NBUF, int WGS, int TR>
+// S2 = true: the 4x4 stride-2 pad-1 layers (down_block.py:14-23, the discriminators) as 2x2 stride-1 correlations over the four
+// PARITY planes of the input: a "chunk" is (16 channels, parity (py, px)); its patch holds plane rows y' = oy0 + prow - py, i.e.
+// input pixels (2 * (oy0 + prow) - py, 2 * (ox0 + pcol) - px) -- a stride-2 gather is free for an LDS-DMA, whose per-lane global
+// address is arbitrary --, and output (y, x) takes taps (a, b) in {0,1}^2 at patch (y - oy0 + a, x - ox0 + b), which are the
+// original taps ky = 2a + 1 - py, kx = 2b + 1 - px.  Four chunks per 16 channels, 4 taps each: no zero-stuffed MACs.
+template <int BM, int NBUF, int WGS, int TR, bool S2 = false>
 __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) {
-    constexpr int PW = 34, NPIX = (TR + 2) * PW;                  // 340 patch pixels (8-row tile), 612 (16-row tile)
-    constexpr int PROWS = (NPIX + 63) / 64;                       // DMA rows of 64 units per half plane: 6 / 10
+    constexpr int NTAPS = S2 ? 4 : 9;
+    constexpr int PW = S2 ? 33 : 34, NPIX = (TR + (S2 ? 1 : 2)) * PW;   // 340 patch pixels (8-row tile), 612 (16-row tile); 297 (S2)
+    constexpr int PROWS = ((NPIX + 63) / 64 + 1) / 2 * 2;         // DMA rows of 64 units per half plane: 6 / 10
     constexpr int PPL = PROWS * 64;
     constexpr int PPW = PROWS / 2;                                // ... per wave (wave w: half w >> 1, rows PPW * (w & 1) ...)
     static_assert(PROWS % 2 == 0, "patch DMA rows split evenly over the two waves of a half plane");
     constexpr int MI = BM / 32, NI = TR / 4;
-    constexpr int A_UNITS = 9 * BM * 2;
+    constexpr int A_UNITS = NTAPS * BM * 2;
     constexpr int NAI = (A_UNITS + 255) / 256;                    // weight DMA rows per wave and chunk
     constexpr int A_PAD = NAI * 256;
     constexpr int BUF = A_PAD + 2 * PPL;                          // units per buffer: 2048 (32 KB) at BM = 64
@@ -130,28 +138,32 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         const int tap = d / (2 * BM), half = (d / BM) & 1, row = d % BM;
         avo[i] = d < A_UNITS ? (unsigned)(((tap * p.Mpad + m0 + row) * 2 + half) * 16) : NC8_OOB;
     }
-    const unsigned a_chunk_bytes = (unsigned)(9 * p.Mpad * 32);
+    const unsigned a_chunk_bytes = (unsigned)(NTAPS * p.Mpad * 32);
     // ---- patch DMA: wave w fetches rows j = 3 * (w & 1) .. + 2 of half plane w >> 1; unit u = j * 64 + lane -> patch pixel
     const unsigned long xaddr = (unsigned long)p.X;
     const u32x4 xrs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
     const int phalf = wave >> 1, pj0 = PPW * (wave & 1);
     const unsigned plane_bytes = (unsigned)(p.Hi * p.Wi * 16);
-    unsigned pvo[PPW];
+    unsigned pvo[S2 ? 4 : 1][PPW];                              // [parity][row]
 #pragma unroll
-    for (int r = 0; r < PPW; ++r) {
-        const int u = (pj0 + r) * 64 + lane;
-        const int row = u / PW, col = u % PW;
-        int iy = oy0 + p.iy0 + row, ix = ox0 + p.ix0 + col;
-        if (p.reflect) {
-            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
-            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+    for (int par = 0; par < (S2 ? 4 : 1); ++par)
+#pragma unroll
+        for (int r = 0; r < PPW; ++r) {
+            const int u = (pj0 + r) * 64 + lane;
+            const int row = u / PW, col = u % PW;
+            int iy = S2 ? 2 * (oy0 + row) - (par >> 1) : oy0 + p.iy0 + row;
+            int ix = S2 ? 2 * (ox0 + col) - (par & 1) : ox0 + p.ix0 + col;
+            if (p.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+            }
+            const bool ok = u < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            pvo[par][r] = ok ? (unsigned)n_img * (unsigned)p.CB * plane_bytes + (unsigned)(iy * p.Wi + ix) * 16u : NC8_OOB;
         }
-        const bool ok = u < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        pvo[r] = ok ? (unsigned)n_img * (unsigned)p.CB * plane_bytes + (unsigned)(iy * p.Wi + ix) * 16u : NC8_OOB;
-    }
     // Every iteration issues exactly NDMA instructions per wave, so the counted waits below are constants: a chunk past the
     // split's end is "fetched" through zero-record descriptors (no memory traffic; zeros land in a buffer nobody reads again).
-    auto issue_dma = [&](int chunk, int buf, bool live) {
+    auto issue_dma = [&](int chunk, int buf, bool live, auto PARC) {
+        constexpr int parc = decltype(PARC)::value;        // S2: parity of `chunk` (compile time: the chunk loop is unrolled by 4)
         const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
         const int asoff = live ? (int)((unsigned)chunk * a_chunk_bytes) : 0;
         u32x4 ark = ars;
@@ -163,15 +175,16 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
                          :: "s"(dst), "v"(avo[i]), "s"(ark), "s"(asoff) : "memory");
         }
         // a channel block past the tensor's last one (odd block count, last chunk): zero records instead of the next image
-        const int cb = chunk * 2 + phalf;
+        const int cb = (S2 ? chunk >> 2 : chunk) * 2 + phalf;
         u32x4 rsk = xrs;
         rsk[2] = (live && cb < p.CB) ? p.x_bytes : 0u;
         const int psoff = live ? (int)((unsigned)cb * plane_bytes) : 0;
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const unsigned dst = base + (unsigned)((A_PAD + phalf * PPL + (pj0 + r) * 64) * 16);
+            const unsigned vo = pvo[S2 ? parc : 0][r];
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(pvo[r]), "s"(rsk), "s"(psoff) : "memory");
+                         :: "s"(dst), "v"(vo), "s"(rsk), "s"(psoff) : "memory");
         }
     };
 
@@ -187,9 +200,9 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
 #pragma unroll
     for (int j = 0; j < NI; ++j) pbase[j] = A_PAD + (lane >> 5) * PPL + (wave * NI + j) * PW + (lane & 31);
     const int abase = (lane >> 5) * BM + (lane & 31);
-    int toff[9];
+    int toff[NTAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) toff[t] = p.pty[t / 3] * PW + p.ptx[t % 3];
+    for (int t = 0; t < NTAPS; ++t) toff[t] = S2 ? (t >> 1) * PW + (t & 1) : p.pty[t / 3] * PW + p.ptx[t % 3];
 
     const int chunk_beg = blk.z * p.chunks_per_split;
     int chunk_end = chunk_beg + p.chunks_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
@@ -210,10 +223,16 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
     };
 
-#pragma unroll
-    for (int d = 0; d < NBUF - 1; ++d) issue_dma(chunk_beg + d, d, chunk_beg + d < chunk_end);
-    int cur = 0;
-    for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+    static_assert(!S2 || NBUF == 4, "S2: buffer = parity = chunk & 3");
+    {
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+        issue_dma(chunk_beg, 0, chunk_beg < chunk_end, I0{});
+        if (NBUF > 2) issue_dma(chunk_beg + 1, 1, chunk_beg + 1 < chunk_end, I1{});
+        if (NBUF > 3) issue_dma(chunk_beg + 2, 2, chunk_beg + 2 < chunk_end, I2{});
+    }
+    // one chunk from buffer `cur`; PAR = its parity (S2; then cur == PAR), fetching chunk + NBUF - 1 of parity (PAR + 3) & 3
+    auto chunk_body = [&](int chunk, int cur, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
         // The DMAs of the NBUF - 2 chunks after this one may stay in flight (vmcnt retires in order); after the barrier this
         // chunk's image is complete in EVERY wave's share, and everybody has left the buffer read during the previous chunk,
         // which the DMA of chunk + NBUF - 1 may now overwrite.
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         __builtin_amdgcn_s_barrier();
         {
             const int nb = cur == 0 ? NBUF - 1 : cur - 1;
-            issue_dma(chunk + NBUF - 1, nb, chunk + NBUF - 1 < chunk_end);
+            issue_dma(chunk + NBUF - 1, nb, chunk + NBUF - 1 < chunk_end, std::integral_constant<int, (par + 3) & 3>{});
         }
         // Fragments are read TWO taps ahead of their MFMAs (three register sets) and every read is pinned behind one MFMA of the
         // running tap (sched_group_barrier): left to itself the scheduler sank the reads to just in front of their use and every
@@ -230,10 +249,10 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         read_frag(cur, 0, f[0]);
         read_frag(cur, 1, f[1]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 2 < 9) read_frag(cur, tap + 2, f[(tap + 2) % 3]);
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            if (tap + 2 < NTAPS) read_frag(cur, tap + 2, f[(tap + 2) % 3]);
             mma(f[tap % 3]);
-            if (tap + 2 < 9) {
+            if (tap + 2 < NTAPS) {
 #pragma unroll
                 for (int g_ = 0; g_ < (MI * NI < MI + NI ? MI * NI : MI + NI); ++g_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -244,7 +263,20 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        cur = cur + 1 == NBUF ? 0 : cur + 1;
+    };
+    if (S2) {                                              // (chunk count and chunk_beg are multiples of 4: parity = unroll position)
+        for (int chunk = chunk_beg; chunk < chunk_end; chunk += 4) {
+            chunk_body(chunk, 0, std::integral_constant<int, 0>{});
+            chunk_body(chunk + 1, 1, std::integral_constant<int, 1>{});
+            chunk_body(chunk + 2, 2, std::integral_constant<int, 2>{});
+            chunk_body(chunk + 3, 3, std::integral_constant<int, 3>{});
+        }
+    } else {
+        int cur = 0;
+        for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+            chunk_body(chunk, cur, std::integral_constant<int, 0>{});
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-record DMAs of the tail still write LDS
     __syncthreads();                                       // the epilogue reuses the buffers as its staging tile
@@ -399,6 +431,39 @@ C2M_API int c2m_conv_patch_nc8(const void* A, const void* X, void* Y, void* Y_in
         default: return (int)hipErrorInvalidValue;
     }
 #undef NC8_LAUNCH
+    return (int)hipGetLastError();
+}
+
+// 4x4 stride-2 pad-1 2-D convolution (zeros / reflect) on the parity-plane form of the patch kernel: X NC8 of [N][C][Hi][Wi]
+// (Hi, Wi even), A = c2m_pack_weights_bf16_patch with g[4] = 2 (c2m_pack_weights_bf16_s2_bytes), Y contiguous NCHW [N][M][Hi/2][Wi/2]
+// bf16 (yh = 1) or fp32, bias + activation fused.
+C2M_API int c2m_conv_s2_nc8(const void* A, const void* X, void* Y, const float* bias, int M, int C, long N, int Hi, int Wi,
+                            int reflect, int yh, int act, float slope, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || C <= 0 || N <= 0) return 0;
+    if ((Hi & 1) || (Wi & 1) || Hi < 4 || Wi < 4 || (((uintptr_t)A | (uintptr_t)X | (uintptr_t)Y) & 15)) return (int)hipErrorInvalidValue;
+    Nc8P p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.X = X; p.Y = (float*)Y; p.Y2 = nullptr; p.bias = bias;
+    p.M = M; p.Mpad = c2m_cdiv(M, 128) * 128;
+    p.Hi = Hi; p.Wi = Wi; p.Ho = Hi / 2; p.Wo = Wi / 2; p.Nimg = (int)N;
+    p.CB = (C + 7) / 8;
+    p.nchunks = c2m_cdiv(C, 16) * 4;
+    const long xb = N * p.CB * (long)Hi * Wi * 16, ab = (long)p.nchunks * 4 * p.Mpad * 32;
+    if (xb >= 0x80000000LL || ab >= 0x80000000LL || N * (long)M * p.Ho * p.Wo * 4 >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
+    p.out_sn = (long)M * p.Ho * p.Wo; p.out_sc = (long)p.Ho * p.Wo; p.out_sh = p.Wo; p.out_off = 0;
+    p.reflect = reflect; p.slab_stride = 0; p.act = act; p.slope = slope; p.yh = yh;
+    p.chunks_per_split = p.nchunks;
+    hipStream_t s = (hipStream_t)stream;
+    const long tiles = N * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
+    if (M <= 32) {
+        dim3 grid((unsigned)(tiles * c2m_cdiv(M, 32)));
+        hipLaunchKernelGGL((conv_patch_nc8_kernel<32, 4, 2, 8, true>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid((unsigned)(tiles * c2m_cdiv(M, 64)));
+        hipLaunchKernelGGL((conv_patch_nc8_kernel<64, 4, 2, 8, true>), grid, dim3(256), 0, s, p);
+    }
     return (int)hipGetLastError();
 }
 

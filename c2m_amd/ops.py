@@ -278,6 +278,7 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
 
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+_NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
 _NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "1.8"))
 _NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
 _NC8 = os.environ.get("C2M_NC8", "1") != "0"        # bf16 3x3 stride-1 layers on channel-blocked input (A/B knob)
@@ -285,11 +286,13 @@ _PATCH_FILL = tuple(float(v) for v in os.environ.get("C2M_PATCH_FILL", "1.15,1.4
 _PATCH_SMALLC = os.environ.get("C2M_PATCH_SMALLC", "0") == "1"
 
 
-def _pack_bf16_patch(w, M, C, s_m, s_c):
-    """c2m_pack_weights_bf16_patch: contiguous native 3x3 weights -> bf16 [chunk][tap][Mpad][16]."""
+def _pack_bf16_patch(w, M, C, s_m, s_c, mode=0):
+    """c2m_pack_weights_bf16_patch: contiguous native 3x3 weights -> bf16 [chunk][tap][Mpad][16]; mode 2: native 4x4 weights of a
+    stride-2 layer -> [chunk][input parity][2x2 tap][Mpad][16] (conv_nc8.hip, S2)."""
     L = _lib.lib()
-    out = torch.empty(L.c2m_pack_weights_bf16_patch_bytes(M, C), device=w.device, dtype=torch.uint8)
-    g = np.array([M, C, s_m, s_c, 0], dtype=np.int64)
+    nbytes = L.c2m_pack_weights_bf16_s2_bytes(M, C) if mode == 2 else L.c2m_pack_weights_bf16_patch_bytes(M, C)
+    out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    g = np.array([M, C, s_m, s_c, mode], dtype=np.int64)
     _lib.check(L.c2m_pack_weights_bf16_patch(_p(w), _p(out), _gp(g), _stream()), "pack_weights_bf16_patch")
     out._c2m_job = (1, g)                   # how to rebuild this pack in place (refresh_trainable_packs)
     return out
@@ -583,6 +586,10 @@ class _ConvPlan:
         self.fwd_patch = False
         # channel-blocked input (conv_nc8.hip): 2-D bf16 patch layers whose planes are whole 8-pixel groups
         self.nc8 = bool(bf16 and _NC8 and nd == 2 and (Hi * Wi) % 8 == 0 and (Ho * Wo) % 8 == 0)
+        # ... the 4x4 stride-2 pad-1 layers on the parity-plane form of the patch kernel (forward)
+        self.s2_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and (ph, pw) == (1, 1)
+                           and Hi % 2 == 0 and Wi % 2 == 0 and Cout > 4 and Cin >= 12 and Wo >= 16 and Ho >= 4 and
+                           (_ceil(Wo, 32) * _ceil(Ho, 8)) <= _NC8_FILL * Wo * Ho)
         # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
         self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
                               (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)
@@ -1056,6 +1063,22 @@ class _ConvFn(torch.autograd.Function):
                               lambda: conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
                                                 slope, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
+            ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
+            ctx.save_for_backward(x, w, y if ACT[act] else None)
+            return y
+        if pl.bf16 and pl.s2_nc8:
+            x = _as(x, BF16)
+            A = _packed(w, ctx.frozen_w, ("fwd-bf16-s2",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 16, 2))
+            y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
+            Hi_, Wi_ = pl.dims[4:6]
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+
+            def run_s2():
+                xn = _to_nc8(x)
+                return L.c2m_conv_s2_nc8(_p(A), _p(xn), _p(y), _p(b), Cout, Cin, N, Hi_, Wi_, int(pl.reflect), 1, ACT[act], slope,
+                                         _stream())
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_s2, tag,
+                              2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_s2_nc8 fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
             return y

@@ -100,6 +100,12 @@ int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, voi
 int c2m_nchw_to_nc8(const void* x, void* y, long N, int C, long HW, void* stream);
 int c2m_conv_patch_nc8(const void* A, const void* X_nc8, void* Y, void* Y_interior, const float* bias, const int64_t* geom,
                        int act, float slope, void* stream);
+/* 4x4 stride-2 pad-1 2-D layers (down_block.py:14-23, discriminator.py:59-89) on the parity-plane form of the same kernel: four
+ * (16 channels, input parity) chunks with 2x2 taps each -- the stride-2 gather is the LDS-DMA's per-lane address.  A =
+ * c2m_pack_weights_bf16_patch(g[4] = 2) (c2m_pack_weights_bf16_s2_bytes bytes); Y contiguous [N][M][Hi/2][Wi/2], bf16 (yh) or fp32. */
+long c2m_pack_weights_bf16_s2_bytes(int M, int C);
+int c2m_conv_s2_nc8(const void* A, const void* X_nc8, void* Y, const float* bias, int M, int C, long N, int Hi, int Wi, int reflect,
+                    int yh, int act, float slope, void* stream);
 /* Weight (+ bias) gradient of a 2-D 3x3 stride-1 pad-1 layer from NC8 operands: dW[m][c][ky][kx] = sum dY[n][m][y][x] *
  * X[n][c][y+ky-1][x+kx-1] (zeros or reflect padding), fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds
  * c2m_conv_wgrad_nc8_slab_floats(...) floats of scratch (per-split partial sums, reduced in a fixed order); db may be NULL.  */

@@ -49,6 +49,29 @@ for shp in SHAPES:
                 f"wgrad {t1['wgrad'][0]:6.1f} us {t1['wgrad'][1]:4.0f} {t1['wgrad'][2]} same={int(same[0])}{int(same[1])} gw rel diff {werr:.1e}")
     print(msg, flush=True)
 # the layout pass alone
+# 4x4 stride-2 forward: gather kernel vs the parity-plane NC8 kernel (+ fp32 reference error)
+for N, Cin, H, W, Cout, pad in ((40, 64, 64, 128, 128, "reflect"), (40, 128, 32, 64, 256, "reflect"), (40, 32, 128, 256, 64, "reflect"),
+                                (40, 256, 16, 32, 512, "reflect"), (8, 64, 128, 256, 128, "zeros"), (40, 15, 128, 256, 64, "reflect")):
+    res = {}
+    for mode in (False, True):
+        ops._NC8_S2 = mode
+        ops._geom_cache.clear()
+        g = torch.Generator().manual_seed(Cin + H)
+        x = torch.randn(N, Cin, H, W, generator=g).to(DEV).bfloat16()
+        w = (torch.randn(Cout, Cin, 4, 4, generator=g) / (Cin * 16) ** 0.5).to(DEV)
+        b = torch.randn(Cout, generator=g).to(DEV)
+        with torch.no_grad():
+            y = ops.conv(x, w, b, stride=2, padding=1, padding_mode=pad, act="lrelu")
+            with ops.ConvProfiler() as prof:
+                for _ in range(iters):
+                    ops.conv(x, w, b, stride=2, padding=1, padding_mode=pad, act="lrelu")
+            r = [r for r in prof.table() if r[0][1] == "fwd"][0]
+        res[mode] = (y.float(), r[2] / r[1] * 1000, r[3], r[0][-1])
+    xp = torch.nn.functional.pad(x.float(), (1, 1, 1, 1), mode="reflect" if pad == "reflect" else "constant")
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xp, w.bfloat16().float(), b, stride=2), 0.2)
+    e0, e1 = (float((res[m][0] - ref).abs().max() / ref.abs().max()) for m in (False, True))
+    print(f"s2 {(N, Cin, H, W, Cout, pad)}: gather {res[False][1]:6.1f} us {res[False][2]:4.0f} TF/s -> nc8 {res[True][1]:6.1f} us {res[True][2]:4.0f} TF/s "
+          f"({res[True][3]}) | max err vs fp32 conv of the same bf16 operands: gather {e0:.1e} nc8 {e1:.1e}", flush=True)
 for N, C, H, W in ((40, 128, 64, 128), (40, 64, 128, 256), (40, 256, 32, 64)):
     x = torch.randn(N, C, H, W, device=DEV).bfloat16()
     ref = x.view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
