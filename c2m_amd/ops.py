@@ -279,7 +279,7 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
-_NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "1.8"))
+_NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "2.6"))      # (18x34 padded domains of the 16x32 reflect data gradients: 2.5; still 1.5x+ the gather kernel)
 _NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
 _NC8 = os.environ.get("C2M_NC8", "1") != "0"        # bf16 3x3 stride-1 layers on channel-blocked input (A/B knob)
 _PATCH_FILL = tuple(float(v) for v in os.environ.get("C2M_PATCH_FILL", "1.15,1.4").split(","))     # tuning knobs (A/B runs)

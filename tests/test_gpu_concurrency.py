@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 VICTIMS = ["direct_s2", "direct_3d_s2", "patch3x3", "thin7x7", "thin3x3", "wino2_deep", "wino2_32rows", "wino4_zeros",
-           "wino4_reflect", "wino3d", "norm", "warp", "glue", "adam"]
+           "wino4_reflect", "wino3d", "nc8_3x3", "nc8_s2", "norm", "warp", "glue", "adam"]
 NEIGHBOURS = ["bf16_igemm", "bf16_patch", "fp32_wino", "bandwidth"]
 
 

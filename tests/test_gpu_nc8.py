@@ -1,0 +1,167 @@
+"""Channel-blocked (NC8) bf16 convolution kernels of round 4 (c2m_amd/csrc/conv_nc8.hip) against an fp32 convolution of the same
+bf16-representable operands (every product exact in fp32: only the summation order differs) -- the layout pass, every tile /
+buffering variant of the 3x3 patch kernel, the stride-2 parity form, the transposed-read weight gradient; ragged tiles, channel
+counts off the 8 / 16 / 64 grids, split-K, zeros and reflect padding, NaNs planted behind the tensors.  Every case asserts that the
+plan really routes to the NC8 kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from c2m_amd import ops
+from gpu_util import rel_close, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.fixture(autouse=True)
+def _bf16_mode():
+    prev = ops.set_conv_precision("bf16")
+    v0 = ops._NC8_VARIANT
+    yield
+    ops._NC8_VARIANT = v0
+    ops._geom_cache.clear()
+    ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 8, 8, 16), (3, 13, 6, 20), (1, 64, 16, 32), (2, 3, 4, 8)])
+def test_nchw_to_nc8_layout(N, C, H, W):
+    x = rnd(1, N, C, H, W).to(DEV).bfloat16()
+    got = ops._to_nc8(x)
+    CB = (C + 7) // 8
+    ref = torch.zeros(N, CB * 8, H, W, device=DEV, dtype=torch.bfloat16)
+    ref[:, :C] = x
+    ref = ref.view(N, CB, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    assert got.shape == (N, CB, H, W, 8) and torch.equal(got, ref)
+
+
+def _ref(x, w, b, stride, mode):
+    pad = 1
+    xp = F.pad(x, (pad,) * 4, mode="reflect") if mode == "reflect" else F.pad(x, (pad,) * 4)
+    return F.conv2d(xp, w, b, stride=stride)
+
+
+PATCH_CASES = [   # N, Cin, H, W, Cout, mode
+    (2, 32, 16, 32, 64, "zeros"), (1, 40, 24, 64, 200, "reflect"), (2, 16, 20, 40, 32, "reflect"), (1, 72, 36, 96, 24, "zeros"),
+    (3, 28, 12, 40, 136, "reflect"), (1, 128, 32, 64, 128, "zeros"),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_patch_nc8_forward_backward(case, variant):
+    N, Cin, H, W, Cout, mode = case
+    if (variant in (4, 5)) != (Cout <= 32) and variant != 0:
+        pytest.skip("32-row variants serve <= 32 output channels, the others more")
+    ops._NC8_VARIANT = variant
+    ops._geom_cache.clear()
+    x, w = _bf(rnd(11, N, Cin, H, W)), _bf(rnd(12, Cout, Cin, 3, 3, scale=(1.0 / (Cin * 9)) ** 0.5))
+    b = rnd(13, Cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = _ref(xr, wr, br, 1, mode)
+    go = _bf(rnd(14, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    pl = ops._plan(xg.bfloat16(), wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
+    assert pl.nc8 and pl.fwd_patch, "the forward must run on the NC8 patch kernel"
+    # (the data gradient reduces over Cout: 24 output channels would pad a 16-channel chunk by a third -> gather kernel)
+    assert any(c["patch"] for c in pl.classes) == (Cout != 24), "data gradient on the NC8 patch kernel"
+    y = ops.conv(xg, wg, bg, stride=1, padding=1, padding_mode=mode)
+    (y * go.to(DEV)).sum().backward()
+    assert y.dtype == torch.bfloat16
+    rel_close(y.float(), yr, 4e-3, "NC8 forward (one RNE rounding of the exact sum)")
+    rel_close(xg.grad, xr.grad, 5e-5, "NC8 data gradient")
+    rel_close(wg.grad, wr.grad, 1e-4, "weight gradient")
+    rel_close(bg.grad, br.grad, 1e-4, "bias gradient")
+    assert pl.wgrad_nc8 == (Cout >= 64 and Cin >= 16)
+
+
+def test_patch_nc8_split_k_and_deep_reduction():
+    """A 512-deep layer on a 8x32 map: few pixel tiles -> split-K slabs + c2m_splitk_reduce; and the 16-row-tile rule."""
+    N, Cin, H, W, Cout = 2, 512, 8, 32, 64
+    x, w = _bf(rnd(21, N, Cin, H, W)), _bf(rnd(22, Cout, Cin, 3, 3, scale=(1.0 / (Cin * 9)) ** 0.5))
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    pl = ops._plan(xg.bfloat16(), wg, (1, 1, 1), (0, 1, 1), False)
+    assert pl.nc8 and pl.fwd_patch and pl.fwd_splits > 1, "split-K case"
+    y = ops.conv(xg, wg, None, stride=1, padding=1)
+    rel_close(y.float(), F.conv2d(x, w, None, padding=1), 4e-3, "NC8 forward through split-K slabs")
+
+
+WGRAD_CASES = [(2, 16, 12, 40, 64, "zeros"), (1, 40, 9, 72, 72, "reflect"), (3, 64, 8, 32, 128, "reflect"), (1, 24, 21, 64, 200, "zeros")]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_wgrad_nc8_ragged_chunks(case):
+    """Weight gradient from NC8 operands where the 4 x 32-pixel chunks hang over the map (H % 4 != 0, W % 32 != 0) and the channel
+    tiles over Cout / Cin (not multiples of 64 / 32 / 8)."""
+    N, Cin, H, W, Cout, mode = case
+    x, w = _bf(rnd(31, N, Cin, H, W)), _bf(rnd(32, Cout, Cin, 3, 3, scale=(1.0 / (Cin * 9)) ** 0.5))
+    b = rnd(33, Cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = _ref(xr, wr, br, 1, mode)
+    go = _bf(rnd(34, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    pl = ops._plan(xg.bfloat16(), wg, (1, 1, 1), (0, 1, 1), mode == "reflect")
+    assert pl.wgrad_nc8, "the case must run on conv_wgrad_nc8_kernel"
+    y = ops.conv(xg, wg, bg, stride=1, padding=1, padding_mode=mode)
+    (y * go.to(DEV)).sum().backward()
+    rel_close(wg.grad, wr.grad, 1e-4, "NC8 weight gradient")
+    rel_close(bg.grad, br.grad, 1e-4, "NC8 bias gradient")
+    rel_close(xg.grad, xr.grad, 5e-5, "data gradient")
+    # bit-repeatable (fixed-order slab reduction, no atomics)
+    wg2, xg2 = w.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+    y2 = ops.conv(xg2, wg2, bg.detach(), stride=1, padding=1, padding_mode=mode)
+    (y2 * go.to(DEV)).sum().backward()
+    assert torch.equal(wg2.grad, wg.grad)
+
+
+S2_CASES = [(2, 16, 16, 64, 64, "reflect"), (1, 40, 24, 96, 100, "zeros"), (3, 64, 16, 64, 32, "reflect"), (1, 32, 36, 72, 136, "reflect")]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_stride2_parity_form_forward(case):
+    N, Cin, H, W, Cout, mode = case
+    x, w = _bf(rnd(41, N, Cin, H, W)), _bf(rnd(42, Cout, Cin, 4, 4, scale=(1.0 / (Cin * 16)) ** 0.5))
+    b = rnd(43, Cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.leaky_relu(_ref(xr, wr, br, 2, mode), 0.2)
+    go = _bf(rnd(44, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    pl = ops._plan(xg.bfloat16(), wg, (1, 2, 2), (0, 1, 1), mode == "reflect")
+    assert pl.s2_nc8, "the case must run on the stride-2 parity form of the NC8 kernel"
+    y = ops.conv(xg, wg, bg, stride=2, padding=1, padding_mode=mode, act="lrelu")
+    (y.float() * go.to(DEV)).sum().backward()
+    rel_close(y.float(), yr, 4e-3, "stride-2 NC8 forward")
+    rel_close(xg.grad, xr.grad, 2e-2, "data gradient (through the bf16-rounded activation)")
+    rel_close(wg.grad, wr.grad, 2e-2, "weight gradient")
+
+
+def test_nc8_kernels_never_read_past_their_inputs():
+    """The DMAs carry the channel block in an offset the hardware does not range-check: an odd number of 8-channel blocks (last
+    16-channel chunk half empty) must read zeros, not the NaNs planted behind the tensors."""
+    N, Cin, Cout, H, W = 1, 40, 72, 16, 64
+    pool = torch.full((2 * N * Cin * H * W + 8192,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    x = pool[:N * Cin * H * W].view(N, Cin, H, W)
+    x.copy_(_bf(rnd(51, N, Cin, H, W)).to(DEV))
+    gpool = torch.full((2 * N * Cout * H * W + 8192,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    go = gpool[:N * Cout * H * W].view(N, Cout, H, W)
+    go.copy_(_bf(rnd(52, N, Cout, H, W)).to(DEV))
+    w = _bf(rnd(53, Cout, Cin, 3, 3, scale=(1.0 / (Cin * 9)) ** 0.5)).to(DEV).requires_grad_(True)
+    xg = x.requires_grad_(True)
+    y = ops.conv(xg, w, None, stride=1, padding=1)
+    y.backward(go)
+    for t in (y, xg.grad, w.grad):
+        assert bool(torch.isfinite(t.float()).all())
+    xr, wr = x.detach().float().cpu().requires_grad_(True), w.detach().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, padding=1)
+    yr.backward(go.float().cpu())
+    rel_close(y.float(), yr, 4e-3, "forward")
+    rel_close(xg.grad.float(), xr.grad, 4e-3, "data gradient (bf16 result)")
+    rel_close(w.grad, wr.grad, 1e-4, "weight gradient")

@@ -69,6 +69,18 @@ def make_victims():
     # 3x3x3 layer as a 2-D Winograd over (time tap, channel)
     v["wino3d"] = _conv_case((8, 34, 5, 128, 256), 32, (3, 3, 3), 1, 1, "reflect", seed=100)
 
+    # bf16 data path, channel-blocked kernels (conv_nc8.hip: counted-wait LDS-DMA, transposed LDS reads): 3x3 forward / data /
+    # weight gradient and the stride-2 parity form
+    def _bf16_case(*a, **k):
+        fn = _conv_case(*a, **k)
+
+        def run():
+            with ops.conv_precision("bf16"):
+                return fn()
+        return run
+    v["nc8_3x3"] = _bf16_case((40, 128, 32, 64), 128, (3, 3), 1, 1, "reflect", seed=160)
+    v["nc8_s2"] = _bf16_case((40, 64, 64, 128), 128, (4, 4), 2, 1, "reflect", seed=170)
+
     # norm + activation: batch statistics, affine instance norm, SPADE
     xn, gam, bet = _rnd(110, 40, 128, 32, 64), _rnd(111, 128), _rnd(112, 128)
     gbm, gon = _rnd(113, 40, 256, 32, 64, scale=0.3), _rnd(114, 40, 128, 32, 64)
