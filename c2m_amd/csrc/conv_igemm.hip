@@ -2723,6 +2723,14 @@ __device__ __forceinline__ void pack_weights_bf16_patch_body(const float* __rest
             const int t4 = (int)(r % 4); r /= 4;
             const int par = (int)(r % 4); chunk = (int)(r / 4);
             st = (2 * (t4 >> 1) + 1 - (par >> 1)) * 4 + 2 * (t4 & 1) + 1 - (par & 1);
+        } else if (flip == 3 || flip == 4) {
+            // data gradient of those layers (conv_s2_dgrad_nc8_kernel): 16 virtual taps vt = class (ri, rj) * 4 + a * 2 + b with
+            // ky = zeros: ri ? 2a : 2a + 1, reflect: ri ? 2a + 1 : 2a (same along x); rows = input channels, reduction = output channels
+            const int vt = (int)(r % 16); chunk = (int)(r / 16);
+            const int ri = vt >> 3, rj = (vt >> 2) & 1, a = (vt >> 1) & 1, b = vt & 1;
+            const int ky = flip == 3 ? (ri ? 2 * a : 2 * a + 1) : (ri ? 2 * a + 1 : 2 * a);
+            const int kx = flip == 3 ? (rj ? 2 * b : 2 * b + 1) : (rj ? 2 * b + 1 : 2 * b);
+            st = ky * 4 + kx;
         } else {
             tap = (int)(r % 9); chunk = (int)(r / 9);
             st = flip ? 8 - tap : tap;
@@ -2757,7 +2765,7 @@ C2M_API int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t
     if (M <= 0 || C <= 0) return 0;
     if ((((uintptr_t)out) & 15) != 0) return (int)hipErrorInvalidValue;
     const int Mpad = c2m_cdiv(M, 128) * 128;
-    const long units = (long)c2m_cdiv(C, 16) * (g[4] == 2 ? 16 : 9) * Mpad * 2;
+    const long units = (long)c2m_cdiv(C, 16) * (g[4] >= 2 ? 16 : 9) * Mpad * 2;
     hipLaunchKernelGGL(pack_weights_bf16_patch_kernel, dim3(c2m_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (uint4*)out, M, C, Mpad, (long)g[2], (long)g[3], (int)g[4], units);
     return (int)hipGetLastError();
@@ -2823,7 +2831,7 @@ C2M_API long c2m_pack_job_fill(void* job, int type, const void* w, void* out, co
         j.M = (int)g[0]; j.C = (int)g[1]; j.s_m = g[2]; j.s_c = g[3]; j.flip = (int)g[4];
         if (j.M <= 0 || j.C <= 0 || (((uintptr_t)out) & 15) != 0) return -1;
         j.Mpad = c2m_cdiv(j.M, 128) * 128;
-        j.units = (long)c2m_cdiv(j.C, 16) * (j.flip == 2 ? 16 : 9) * j.Mpad * 2;
+        j.units = (long)c2m_cdiv(j.C, 16) * (j.flip >= 2 ? 16 : 9) * j.Mpad * 2;
         j.xblocks = 1;
         j.nblocks = (unsigned)c2m_grid(j.units, 256);
     } else {

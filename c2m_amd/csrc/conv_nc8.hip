@@ -734,3 +734,163 @@ C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* sla
                        p.Mp, p.Cp, S);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ 4x4 stride-2 data gradient on NC8
+// dX of a 4x4 stride-2 pad-1 layer: output position i = 2q + ri takes only the taps ky of one parity -- two per axis -- so each of
+// the four output parity classes (ri, rj) is a 2x2 stride-1 correlation of dY.  One workgroup computes ALL FOUR classes of an
+// 8 x 32 tile of (q, p): they share one (8+2) x 34 patch of dY (rows q-1 .. q+1), every (class, tap) pair is one "virtual tap" with
+// its own weight tile and patch offset, and each class has its own accumulators (32 input channels x 4 classes x 64 positions =
+// 128 registers per wave).  Epilogue: the (rj = 0, 1) pair of a class row is two adjacent pixels -> one packed store per lane,
+// 128 contiguous bytes per half wave.  zeros padding: the target is dX itself; reflect: the padded (Hi+2) x (Wi+2) gradient,
+// folded afterwards by c2m_reflect_fold.
+//   zeros   : ri = 0: (ky 1, dY row q), (ky 3, q-1);  ri = 1: (ky 0, q+1), (ky 2, q)
+//   reflect : ri = 0: (ky 0, q), (ky 2, q-1);         ri = 1: (ky 1, q), (ky 3, q-1)        (padded coordinate i' = 2q + ri)
+struct S2DgP {
+    const void* A;       // pack mode 3 / 4: [chunk of 16 dY channels][virtual tap 16][Mpad rows = input channels][2 halves]
+    const void* dY;      // NC8 [N][CBy][Ho][Wo][8]
+    void* T;             // target [N][M][Ht][Wt] (bf16 or fp32)
+    int M, Mpad, nchunks, CBy, Nimg, Ho, Wo, Ht, Wt, reflect, th;
+    unsigned dy_bytes, a_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_s2_dgrad_nc8_kernel(const S2DgP p) {
+    constexpr int BM = 32, TR = 8, PW = 34, NPIX = (TR + 2) * PW, PPL = 384, NVT = 16;
+    constexpr int A_UNITS = NVT * BM * 2, NAI = A_UNITS / 256;    // 1024 units: 4 DMA rows per wave
+    constexpr int BUF = A_UNITS + 2 * PPL, NDMA = NAI + 3;
+    __shared__ uint4 smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Qh = p.Ht / 2, Qw = p.Wt / 2;
+    const int tiles_x = (Qw + 31) / 32, tiles_y = (Qh + TR - 1) / TR;
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Nimg * tiles_y * tiles_x), (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM;
+    int tb = blk.x;
+    const int tx = tb % tiles_x; tb /= tiles_x;
+    const int ty = tb % tiles_y; const int n_img = tb / tiles_y;
+    const int q0 = ty * TR, p0 = tx * 32;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
+
+    const unsigned long aaddr = (unsigned long)p.A, yaddr = (unsigned long)p.dY;
+    const u32x4 ars = {(unsigned)aaddr, (unsigned)(aaddr >> 32) & 0xffffu, p.a_bytes, 0x00020000u};
+    const u32x4 yrs = {(unsigned)yaddr, (unsigned)(yaddr >> 32) & 0xffffu, p.dy_bytes, 0x00020000u};
+    unsigned avo[NAI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        const int d = (i * 4 + wave) * 64 + lane;                 // destination unit of [vt][half][row]
+        const int vt = d / (2 * BM), half = (d / BM) & 1, row = d % BM;
+        avo[i] = (unsigned)(((vt * p.Mpad + m0 + row) * 2 + half) * 16);
+    }
+    const unsigned a_chunk_bytes = (unsigned)(NVT * p.Mpad * 32);
+    const int phalf = wave >> 1, pj0 = 3 * (wave & 1);
+    const unsigned plane_bytes = (unsigned)(p.Ho * p.Wo * 16);
+    unsigned pvo[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int u = (pj0 + r) * 64 + lane;
+        const int iy = q0 - 1 + u / PW, ix = p0 - 1 + u % PW;
+        const bool ok = u < NPIX && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;      // dY outside its map: zeros
+        pvo[r] = ok ? (unsigned)n_img * (unsigned)p.CBy * plane_bytes + (unsigned)(iy * p.Wo + ix) * 16u : NC8_OOB;
+    }
+    auto issue_dma = [&](int chunk, int buf, bool live) {
+        const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
+        const int asoff = live ? (int)((unsigned)chunk * a_chunk_bytes) : 0;
+        u32x4 ark = ars;
+        ark[2] = live ? p.a_bytes : 0u;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+            const unsigned dst = base + (unsigned)((i * 4 + wave) * 64 * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(avo[i]), "s"(ark), "s"(asoff) : "memory");
+        }
+        const int cb = chunk * 2 + phalf;
+        u32x4 rsk = yrs;
+        rsk[2] = (live && cb < p.CBy) ? p.dy_bytes : 0u;
+        const int psoff = live ? (int)((unsigned)cb * plane_bytes) : 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned dst = base + (unsigned)((A_UNITS + phalf * PPL + (pj0 + r) * 64) * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(pvo[r]), "s"(rsk), "s"(psoff) : "memory");
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+    int pbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pbase[j] = A_UNITS + (lane >> 5) * PPL + (wave * 2 + j + 1) * PW + (lane & 31) + 1;   // dY (q, p)
+    const int abase = (lane >> 5) * BM + (lane & 31);
+    // patch offset of (class parity r, tap a) along one axis: zeros {0: (0, -1), 1: (+1, 0)}, reflect {(0, -1), (0, -1)}
+    const int o10 = p.reflect ? 0 : 1, o11 = p.reflect ? -1 : 0;
+
+    issue_dma(0, 0, p.nchunks > 0);
+    int cur = 0;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_dma(chunk + 1 < p.nchunks ? chunk + 1 : chunk, cur ^ 1, chunk + 1 < p.nchunks);
+        const uint4* __restrict__ s = smem + cur * BUF;
+#pragma unroll
+        for (int vt = 0; vt < NVT; ++vt) {
+            const int cls = vt >> 2, a = (vt >> 1) & 1, b = vt & 1, ri = cls >> 1, rj = cls & 1;
+            const int oy = ri == 0 ? (a == 0 ? 0 : -1) : (a == 0 ? o10 : o11);
+            const int ox = rj == 0 ? (b == 0 ? 0 : -1) : (b == 0 ? o10 : o11);
+            const bf16x8 A = __builtin_bit_cast(bf16x8, s[vt * 2 * BM + abase]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 B = __builtin_bit_cast(bf16x8, s[pbase[j] + oy * PW + ox]);
+                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[cls][j], 0, 0, 0);
+            }
+        }
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: T[n][m][2q + ri][2p + rj]; lane = position p, the rj pair is one packed store
+    const long plane = (long)p.Ht * p.Wt;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + wave * 2 + j, pp = p0 + (lane & 31);
+        if (q >= Qh || pp >= Qw) continue;
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                const long e = ((long)n_img * p.M + row) * plane + (long)(2 * q + ri) * p.Wt + 2 * pp;
+                const float v0 = acc[ri * 2][j][r], v1 = acc[ri * 2 + 1][j][r];
+                if (p.th) {
+                    typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+                    const bf16x2_t o = {(bf16_t)v0, (bf16_t)v1};
+                    *reinterpret_cast<bf16x2_t*>(reinterpret_cast<bf16_t*>(p.T) + e) = o;
+                } else {
+                    *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.T) + e) = make_float2(v0, v1);
+                }
+            }
+    }
+}
+
+// dY_nc8: NC8 of [N][K][Ho][Wo]; A: c2m_pack_weights_bf16_patch with g = {M = input channels, C = K, s_m = 16, s_c = M * 16, mode 3
+// (zeros) / 4 (reflect)}; T: [N][M][Ht][Wt] with (Ht, Wt) = (2 Ho, 2 Wo) (zeros: dX itself) or (2 Ho + 2, 2 Wo + 2) (reflect: the padded
+// gradient, to be folded); th: 1 = bf16 target.
+C2M_API int c2m_conv_s2_dgrad_nc8(const void* A, const void* dY_nc8, void* T, int M, int K, long N, int Ho, int Wo, int reflect,
+                                  int th, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    S2DgP p;
+    p.A = A; p.dY = dY_nc8; p.T = T; p.M = M; p.Mpad = c2m_cdiv(M, 128) * 128; p.nchunks = c2m_cdiv(K, 16); p.CBy = (K + 7) / 8;
+    p.Nimg = (int)N; p.Ho = Ho; p.Wo = Wo; p.reflect = reflect; p.th = th;
+    p.Ht = 2 * Ho + (reflect ? 2 : 0); p.Wt = 2 * Wo + (reflect ? 2 : 0);
+    const long yb = N * p.CBy * (long)Ho * Wo * 16, ab = (long)p.nchunks * 16 * p.Mpad * 32;
+    if (yb >= 0x80000000LL || ab >= 0x80000000LL || (((uintptr_t)A | (uintptr_t)dY_nc8 | (uintptr_t)T) & 15)) return (int)hipErrorInvalidValue;
+    p.dy_bytes = (unsigned)yb; p.a_bytes = (unsigned)ab;
+    const long tiles = N * c2m_cdiv(p.Ht / 2, 8) * c2m_cdiv(p.Wt / 2, 32);
+    hipLaunchKernelGGL(conv_s2_dgrad_nc8_kernel, dim3((unsigned)(tiles * c2m_cdiv(M, 32))), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

@@ -290,7 +290,7 @@ def _pack_bf16_patch(w, M, C, s_m, s_c, mode=0):
     """c2m_pack_weights_bf16_patch: contiguous native 3x3 weights -> bf16 [chunk][tap][Mpad][16]; mode 2: native 4x4 weights of a
     stride-2 layer -> [chunk][input parity][2x2 tap][Mpad][16] (conv_nc8.hip, S2)."""
     L = _lib.lib()
-    nbytes = L.c2m_pack_weights_bf16_s2_bytes(M, C) if mode == 2 else L.c2m_pack_weights_bf16_patch_bytes(M, C)
+    nbytes = L.c2m_pack_weights_bf16_s2_bytes(M, C) if mode >= 2 else L.c2m_pack_weights_bf16_patch_bytes(M, C)
     out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     g = np.array([M, C, s_m, s_c, mode], dtype=np.int64)
     _lib.check(L.c2m_pack_weights_bf16_patch(_p(w), _p(out), _gp(g), _stream()), "pack_weights_bf16_patch")
@@ -590,6 +590,11 @@ class _ConvPlan:
         self.s2_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and (ph, pw) == (1, 1)
                            and Hi % 2 == 0 and Wi % 2 == 0 and Cout > 4 and Cin >= 12 and Wo >= 16 and Ho >= 4 and
                            (_ceil(Wo, 32) * _ceil(Ho, 8)) <= _NC8_FILL * Wo * Ho)
+        # ... their data gradient (four output parity classes over one shared dY patch, one launch)
+        qh, qw = Hi // 2 + (1 if reflect else 0), Wi // 2 + (1 if reflect else 0)
+        self.s2_dgrad_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
+                                 (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cin >= 8 and Cout >= 12 and qw >= 16 and
+                                 dM == Cin and (_ceil(qw, 32) * _ceil(qh, 8)) <= _NC8_FILL * qw * qh)
         # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
         self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
                               (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)
@@ -955,6 +960,22 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
             Ti, Hi, Wi = pl.dims[3:6]
             _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, 0, _stream()),
                        "reflect border add")
+    elif pl.bf16 and pl.s2_dgrad_nc8:
+        # 4x4 stride-2 layers: all four output parity classes in one launch on the NC8 form of dY (conv_nc8.hip)
+        gy_b = _as(gy, BF16)
+        Ho_, Wo_ = pl.dims[7:9]
+        kdt = BF16 if out_dtype == BF16 else torch.float32
+        A = _packed(w, frozen_w, ("dgrad-bf16-s2", pl.reflect), lambda: _pack_bf16_patch(w, Cin, Cout, 16, Cin * 16, 4 if pl.reflect else 3))
+        gx = torch.empty(xshape, device=dev, dtype=kdt)
+        tgt = torch.empty(pl.dgrad_target, device=dev, dtype=kdt) if pl.reflect else gx
+        tag = ("dgrad", Cin, Cout * 16, int(N * Hi_ * Wi_), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+
+        def run_s2d():
+            gyn = _to_nc8(gy_b, keep)
+            return L.c2m_conv_s2_dgrad_nc8(_p(A), _p(gyn), _p(tgt), Cin, Cout, N, Ho_, Wo_, int(pl.reflect), _dt(tgt), _stream())
+        _lib.check(_timed("igemm_bf16", pl.dgrad_flops, run_s2d, tag, 2 * (gy.numel() + xnumel) + 4 * w.numel()), "conv_s2_dgrad_nc8")
+        if pl.reflect:
+            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, 1, Hi_, Wi_, 0, 1, 1, _dt(tgt), _stream()), "reflect fold (s2)")
     else:
         S = pl.dgrad_splits
         folded = pl.reflect and any(pl.pad)

@@ -106,6 +106,11 @@ int c2m_conv_patch_nc8(const void* A, const void* X_nc8, void* Y, void* Y_interi
 long c2m_pack_weights_bf16_s2_bytes(int M, int C);
 int c2m_conv_s2_nc8(const void* A, const void* X_nc8, void* Y, const float* bias, int M, int C, long N, int Hi, int Wi, int reflect,
                     int yh, int act, float slope, void* stream);
+/* Data gradient of those layers: the four output parity classes as 2x2 stride-1 correlations of dY over one shared patch, one
+ * launch.  A = c2m_pack_weights_bf16_patch with g = {M = input channels, C = output channels, s_m = 16, s_c = M * 16, mode 3 (zeros) /
+ * 4 (reflect)}; T = dX [N][M][2Ho][2Wo] (zeros) or the padded gradient [N][M][2Ho+2][2Wo+2] (reflect; c2m_reflect_fold finishes). */
+int c2m_conv_s2_dgrad_nc8(const void* A, const void* dY_nc8, void* T, int M, int K, long N, int Ho, int Wo, int reflect, int th,
+                          void* stream);
 /* Weight (+ bias) gradient of a 2-D 3x3 stride-1 pad-1 layer from NC8 operands: dW[m][c][ky][kx] = sum dY[n][m][y][x] *
  * X[n][c][y+ky-1][x+kx-1] (zeros or reflect padding), fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds
  * c2m_conv_wgrad_nc8_slab_floats(...) floats of scratch (per-split partial sums, reduced in a fixed order); db may be NULL.  */

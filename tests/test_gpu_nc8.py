@@ -121,26 +121,33 @@ def test_wgrad_nc8_ragged_chunks(case):
     assert torch.equal(wg2.grad, wg.grad)
 
 
-S2_CASES = [(2, 16, 16, 64, 64, "reflect"), (1, 40, 24, 96, 100, "zeros"), (3, 64, 16, 64, 32, "reflect"), (1, 32, 36, 72, 136, "reflect")]
+S2_CASES = [(2, 16, 32, 128, 64, "reflect"), (1, 40, 24, 96, 100, "zeros"), (3, 64, 24, 128, 32, "reflect"), (1, 32, 36, 72, 136, "zeros")]
 
 
 @pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_stride2_parity_form_forward(case):
+def test_stride2_parity_form_forward_and_data_gradient(case):
+    """4x4 stride-2 pad-1: forward on the input-parity form, data gradient as four output-parity classes over one dY patch."""
     N, Cin, H, W, Cout, mode = case
     x, w = _bf(rnd(41, N, Cin, H, W)), _bf(rnd(42, Cout, Cin, 4, 4, scale=(1.0 / (Cin * 16)) ** 0.5))
     b = rnd(43, Cout, scale=0.1)
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
-    yr = F.leaky_relu(_ref(xr, wr, br, 2, mode), 0.2)
+    yr = _ref(xr, wr, br, 2, mode)
     go = _bf(rnd(44, *yr.shape))
     (yr * go).sum().backward()
     xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
     pl = ops._plan(xg.bfloat16(), wg, (1, 2, 2), (0, 1, 1), mode == "reflect")
-    assert pl.s2_nc8, "the case must run on the stride-2 parity form of the NC8 kernel"
-    y = ops.conv(xg, wg, bg, stride=2, padding=1, padding_mode=mode, act="lrelu")
+    assert pl.s2_nc8 and pl.s2_dgrad_nc8, "the case must run on the stride-2 forms of the NC8 kernels"
+    y = ops.conv(xg, wg, bg, stride=2, padding=1, padding_mode=mode)
     (y.float() * go.to(DEV)).sum().backward()
     rel_close(y.float(), yr, 4e-3, "stride-2 NC8 forward")
-    rel_close(xg.grad, xr.grad, 2e-2, "data gradient (through the bf16-rounded activation)")
-    rel_close(wg.grad, wr.grad, 2e-2, "weight gradient")
+    rel_close(xg.grad, xr.grad, 5e-5, "stride-2 NC8 data gradient")
+    rel_close(wg.grad, wr.grad, 1e-4, "weight gradient")
+    # bf16 target of the data gradient (the type it has inside the network)
+    xb = x.to(DEV).bfloat16().requires_grad_(True)
+    yb = ops.conv(xb, wg.detach(), None, stride=2, padding=1, padding_mode=mode)
+    yb.backward(go.to(DEV).bfloat16())
+    assert xb.grad.dtype == torch.bfloat16
+    rel_close(xb.grad.float(), xr.grad, 4e-3, "stride-2 NC8 data gradient, bf16 result")
 
 
 def test_nc8_kernels_never_read_past_their_inputs():
