@@ -147,7 +147,8 @@ def test_stride2_parity_form_forward_and_data_gradient(case):
     yb = ops.conv(xb, wg.detach(), None, stride=2, padding=1, padding_mode=mode)
     yb.backward(go.to(DEV).bfloat16())
     assert xb.grad.dtype == torch.bfloat16
-    rel_close(xb.grad.float(), xr.grad, 4e-3, "stride-2 NC8 data gradient, bf16 result")
+    # (reflect: the padded gradient is rounded to bf16, then the fold adds up to four of those values and rounds again)
+    rel_close(xb.grad.float(), xr.grad, 8e-3 if mode == "reflect" else 4e-3, "stride-2 NC8 data gradient, bf16 result")
 
 
 def test_nc8_kernels_never_read_past_their_inputs():
