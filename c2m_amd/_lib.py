@@ -18,9 +18,9 @@ _SIGS = {
     "c2m_conv_s2_nc8": (c_int, [c_void_p] * 4 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "c2m_conv_s2_dgrad_nc8": (c_int, [c_void_p] * 3 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "c2m_pack_weights_bf16_s2_bytes": (c_long, [c_int, c_int]),
-    "c2m_conv_wgrad_nc8_splits": (c_int, [c_int, c_int, c_long, c_int, c_int]),
-    "c2m_conv_wgrad_nc8_slab_floats": (c_long, [c_int, c_int, c_long, c_int, c_int]),
-    "c2m_conv_wgrad_nc8": (c_int, [c_void_p] * 5 + [c_int, c_int, c_long, c_int, c_int, c_int, c_void_p]),
+    "c2m_conv_wgrad_nc8_splits": (c_int, [c_int, c_int, c_long, c_int, c_int, c_int]),
+    "c2m_conv_wgrad_nc8_slab_floats": (c_long, [c_int, c_int, c_long, c_int, c_int, c_int]),
+    "c2m_conv_wgrad_nc8": (c_int, [c_void_p] * 5 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "c2m_reflect_border_add": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 7 + [c_void_p]),
     "c2m_conv_igemm_splits": (c_int, [c_int, c_int, c_int]),
     "c2m_splitk_reduce": (c_int, [c_void_p] * 3 + [c_long, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),

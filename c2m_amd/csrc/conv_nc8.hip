@@ -485,7 +485,8 @@ struct WgNc8P {
     float* slab;          // [S][9][Mp][Cp]
     float* dbslab;        // [S][Mp]
     int M, C, Mp, Cp, CBy, CBx;
-    int Nimg, H, W, reflect;
+    int Nimg, H, W, reflect;        // H, W: the dY map
+    int Hin, Win;                   // the X map (= H, W; 2H, 2W for the stride-2 layers)
     int chunks_y, chunks_x, nchunks, chunks_per_split;
     unsigned dy_bytes, x_bytes;
 };
@@ -499,20 +500,31 @@ __device__ __forceinline__ bf16x8 nc8_tr_frag(const unsigned lds_byte, const int
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// S2 = true: the 4x4 stride-2 pad-1 layers.  dW[m][c][ky][kx] = sum dY[n][m][y][x] * X[n][c][2y + ky - 1][2x + kx - 1]: the taps of one
+// input-row parity py (ky = 2a + 1 - py) are 2 x 2 x 2 = 8 (column parity px, a, b) -- one workgroup takes one py (8 accumulator tiles),
+// its X image holds the two column-parity planes of that row parity ([px][channel block][5 x 33 positions], plane stride 180 units,
+// fetched with stride-2 addresses by the DMA), and tap (px, a, b) of pixel (r, c) is the unit (r + a, c + b) of plane px.
+template <bool S2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) {
-    constexpr int DPL = 132, XPL = 204;                           // plane strides (units)
-    constexpr int SD = 8 * DPL, SX = 4 * XPL + 16 + 64;           // dY image, X image (+ pad, + a dump row for the filler DMA)
-    constexpr int BUF = SD + SX;                                  // 1952 units = 31232 B
-    constexpr int NDMA = 8;
+    constexpr int DPL = 132;                                      // dY plane stride (units)
+    constexpr int XPL = S2 ? 180 : 204, PWX = S2 ? 33 : 34, XVAL = S2 ? 165 : 204, NPAR = S2 ? 2 : 1;
+    constexpr int NXU = NPAR * 4 * XPL;                           // X image units: 816 / 1440
+    constexpr int NXI = (NXU + 63) / 64, XPW = (NXI + 3) / 4;     // X DMA rows: 13 / 23; per wave 4 / 6
+    constexpr int NT = S2 ? 8 : 9, NH = (NT + 1) / 2;
+    constexpr int SD = 8 * DPL, SX = NXI * 64;                    // dY image, X image
+    constexpr int BUF = SD + SX;
+    constexpr int XCH = 2 * NH * 16 * 64 + 2 * 16 * 64;           // floats of the kh exchange
+    static_assert(XCH * 4 <= 2 * BUF * 16, "exchange fits the images");
     __shared__ uint4 smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mh = wave & 1, kh = wave >> 1;
-    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Cp / 32), (unsigned)(p.Mp / 64), 0);
-    const int m0 = blk.y * 64, c0 = blk.x * 32, split = blk.z;
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Cp / 32) * (S2 ? 2u : 1u), (unsigned)(p.Mp / 64), 0);
+    const int py = S2 ? (int)(blk.x & 1u) : 0;
+    const int m0 = blk.y * 64, c0 = (S2 ? blk.x >> 1 : blk.x) * 32, split = blk.z;
     const int cby0 = m0 >> 3, cbx0 = c0 >> 3;
-    const unsigned HW16 = (unsigned)(p.H * p.W) * 16u;
+    const unsigned HW16 = (unsigned)(p.H * p.W) * 16u, XHW16 = (unsigned)(p.Hin * p.Win) * 16u;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
 
     const unsigned long ya = (unsigned long)p.dY, xa = (unsigned long)p.X;
@@ -520,15 +532,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
     const u32x4 xrs = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
     // ---- dY DMA rows of this wave: I = wave * 4 + j -> channel block I >> 1, row pair I & 1; lane -> (row, column)
     const int d_r = lane >> 5, d_col = lane & 31;
-    // ---- X DMA rows: I = wave + 4 * j (I = 12 only in wave 0; the other waves issue a zero-record filler)
-    int x_plane[4], x_prow[4], x_pcol[4];
-    bool x_ok[4];
+    // ---- X DMA rows: I = wave + 4 * j < NXI (the waits of this kernel are vmcnt(0): the waves need not issue equal counts);
+    // per lane and row one packed word: column parity | channel block << 1 | patch row << 3 | patch column << 6 | valid << 12
+    unsigned x_code[XPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < XPW; ++j) {
         const int u = (wave + 4 * j) * 64 + lane;
-        const int pl = u / XPL, pos = u % XPL;
-        x_plane[j] = pl; x_prow[j] = pos / 34; x_pcol[j] = pos % 34;
-        x_ok[j] = u < 4 * XPL && cbx0 + pl < p.CBx;
+        const int par = u / (4 * XPL), rem = u % (4 * XPL);
+        const int pl = rem / XPL, pos = rem % XPL;
+        const bool ok = u < NXU && pos < XVAL && cbx0 + pl < p.CBx;
+        x_code[j] = (unsigned)(par | (pl << 1) | ((pos / PWX) << 3) | ((pos % PWX) << 6) | ((ok ? 1 : 0) << 12));
     }
     auto issue_dma = [&](int chunk, int buf, bool live) {
         int t = chunk;
@@ -548,25 +561,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(vo), "s"(rs) : "memory");
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < XPW; ++j) {
             const int I = wave + 4 * j;
-            int iy = y0 - 1 + x_prow[j], ix = x0 - 1 + x_pcol[j];
+            if (I >= NXI) continue;                        // (wave-uniform)
+            const int xpx = (int)(x_code[j] & 1u), xpl = (int)((x_code[j] >> 1) & 3u);
+            const int xpr = (int)((x_code[j] >> 3) & 7u), xpc = (int)((x_code[j] >> 6) & 63u);
+            int iy = S2 ? 2 * (y0 + xpr) - py : y0 - 1 + xpr;
+            int ix = S2 ? 2 * (x0 + xpc) - xpx : x0 - 1 + xpc;
             if (p.reflect) {
-                iy = iy < 0 ? -iy : iy; iy = iy >= p.H ? 2 * p.H - 2 - iy : iy;
-                ix = ix < 0 ? -ix : ix; ix = ix >= p.W ? 2 * p.W - 2 - ix : ix;
+                iy = iy < 0 ? -iy : iy; iy = iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= p.Win ? 2 * p.Win - 2 - ix : ix;
             }
-            const bool ok = x_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned vo = ok ? ((unsigned)(n * p.CBx + cbx0 + x_plane[j]) * HW16 + (unsigned)(iy * p.W + ix) * 16u) : NC8_OOB;
+            const bool ok = (x_code[j] >> 12) != 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const unsigned vo = ok ? ((unsigned)(n * p.CBx + cbx0 + xpl) * XHW16 + (unsigned)(iy * p.Win + ix) * 16u) : NC8_OOB;
             u32x4 rs = xrs;
-            rs[2] = (live && I < 13) ? p.x_bytes : 0u;
-            const unsigned dst = base + (unsigned)((SD + (I < 13 ? I * 64 : 4 * XPL + 16)) * 16);
+            rs[2] = live ? p.x_bytes : 0u;
+            const unsigned dst = base + (unsigned)((SD + I * 64) * 16);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(vo), "s"(rs) : "memory");
         }
     };
 
-    f32x16 acc[9], accb;
+    f32x16 acc[NT], accb;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
@@ -580,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
     // 4q + pp of the group supplies row (pixel) q, 8-byte half pp & 1 of channel block 2 * (g & 1) + (pp >> 1)
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const unsigned a_lane = (unsigned)((((mh * 4 + 2 * (g & 1) + (pp >> 1)) * DPL + 8 * (g >> 1) + q + kh * 64) * 16) + 8 * (pp & 1));
-    const unsigned b_lane = (unsigned)(((SD + (2 * (g & 1) + (pp >> 1)) * XPL + 8 * (g >> 1) + q + kh * 2 * 34) * 16) + 8 * (pp & 1));
+    const unsigned b_lane = (unsigned)(((SD + (2 * (g & 1) + (pp >> 1)) * XPL + 8 * (g >> 1) + q + kh * 2 * PWX) * 16) + 8 * (pp & 1));
 
     const int chunk_beg = split * p.chunks_per_split;
     int chunk_end = chunk_beg + p.chunks_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
@@ -596,8 +613,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
             const int r = ss >> 1, cc = (ss & 1) * 16;
             const bf16x8 A = nc8_tr_frag(ab, (r * 32 + cc) * 16);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const bf16x8 B = nc8_tr_frag(bb, ((r + t / 3) * 34 + cc + t % 3) * 16);
+            for (int t = 0; t < NT; ++t) {
+                const int off = S2 ? (t >> 2) * 4 * XPL + (r + ((t >> 1) & 1)) * PWX + cc + (t & 1) : (r + t / 3) * PWX + cc + t % 3;
+                const bf16x8 B = nc8_tr_frag(bb, off * 16);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[t], 0, 0, 0);
             }
             if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ones, accb, 0, 0, 0);
@@ -606,45 +624,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- the two pixel halves (kh) of a row tile are summed inside the workgroup (fixed order: kh 0 + kh 1) through the now free
-    // LDS images, five and four taps at a time (a tap tile of one wave = 4 KB); halves the slab traffic of the launch
+    // LDS images, half of the taps at a time (a tap tile of one wave = 4 KB); halves the slab traffic of the launch
     __syncthreads();
-    float* __restrict__ xch = reinterpret_cast<float*>(&smem[0]) + mh * (5 * 16 * 64);
+    float* __restrict__ xch = reinterpret_cast<float*>(&smem[0]) + mh * (NH * 16 * 64);
+    float* __restrict__ xcb = reinterpret_cast<float*>(&smem[0]) + 2 * NH * 16 * 64 + mh * 16 * 64;
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-        const int t0 = ph * 5, nt = ph ? 4 : 5;
+        const int t0 = ph * NH, nt = ph ? NT - NH : NH;
         if (kh == 1) {
 #pragma unroll
-            for (int t = 0; t < 5; ++t)
+            for (int t = 0; t < NH; ++t)
                 if (t < nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 64 + lane] = acc[t0 + t][r];
             if (ph == 0 && want_bias)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) reinterpret_cast<float*>(&smem[0])[2 * 5 * 16 * 64 + (mh * 16 + r) * 64 + lane] = accb[r];
+                for (int r = 0; r < 16; ++r) xcb[r * 64 + lane] = accb[r];
         }
         __syncthreads();
         if (kh == 0) {
 #pragma unroll
-            for (int t = 0; t < 5; ++t)
+            for (int t = 0; t < NH; ++t)
                 if (t < nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t0 + t][r] += xch[(t * 16 + r) * 64 + lane];
             if (ph == 0 && want_bias)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accb[r] += reinterpret_cast<float*>(&smem[0])[2 * 5 * 16 * 64 + (mh * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) accb[r] += xcb[r * 64 + lane];
         }
         __syncthreads();
     }
     if (kh != 0) return;
-    // ---- slabs: [split][tap][m][c]; an accumulator register is 32 consecutive c of one row
-    float* __restrict__ sb = p.slab + (long)split * 9 * p.Mp * p.Cp;
+    // ---- slabs: [split][tap][m][c] (9 taps; S2: 16, this workgroup's 8 are ky = 2a + 1 - py, kx = 2b + 1 - px); an accumulator
+    // register is 32 consecutive c of one row
+    constexpr int NTS = S2 ? 16 : 9;
+    float* __restrict__ sb = p.slab + (long)split * NTS * p.Mp * p.Cp;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t) {
+        const int ts = S2 ? (2 * ((t >> 1) & 1) + 1 - py) * 4 + 2 * (t & 1) + 1 - (t >> 2) : t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            sb[((long)t * p.Mp + row) * p.Cp + c0 + (lane & 31)] = acc[t][r];
+            sb[((long)ts * p.Mp + row) * p.Cp + c0 + (lane & 31)] = acc[t][r];
         }
+    }
     if (want_bias && (lane & 31) == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -657,22 +680,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
 // dW[m][c][tap] = sum over slabs; db[m] likewise.  Thread = (tap, m, c) with c fastest (coalesced slab reads); four interleaved
 // partial sums keep the loads in flight, combined in a fixed order -> bit-reproducible.
 __global__ void wgrad_nc8_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab, float* __restrict__ dW,
-                                        float* __restrict__ db, int M, int C, int Mp, int Cp, int nslab) {
+                                        float* __restrict__ db, int M, int C, int Mp, int Cp, int nslab, int NT) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long MC = (long)M * C;
-    if (i < 9 * MC) {
+    if (i < NT * MC) {
         const int t = (int)(i / MC);
         const long mc = i % MC;
         const int c = (int)(mc % C), m = (int)(mc / C);
         const float* __restrict__ q = slab + ((long)t * Mp + m) * Cp + c;
-        const long st = 9L * Mp * Cp;
+        const long st = (long)NT * Mp * Cp;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int k = 0;
         for (; k + 3 < nslab; k += 4) {
             s0 += q[(long)k * st]; s1 += q[(long)(k + 1) * st]; s2 += q[(long)(k + 2) * st]; s3 += q[(long)(k + 3) * st];
         }
         for (; k < nslab; ++k) s0 += q[(long)k * st];
-        dW[mc * 9 + t] = (s0 + s1) + (s2 + s3);
+        dW[mc * NT + t] = (s0 + s1) + (s2 + s3);
     }
     if (db && i < M) {
         float s = 0.f;
@@ -681,10 +704,10 @@ __global__ void wgrad_nc8_reduce_kernel(const float* __restrict__ slab, const fl
     }
 }
 
-static void wgrad_nc8_shape(int M, int C, long N, int H, int W, int& Mp, int& Cp, long& nchunks, int& S) {
+static void wgrad_nc8_shape(int M, int C, long N, int H, int W, int s2, int& Mp, int& Cp, long& nchunks, int& S) {
     Mp = c2m_cdiv(M, 64) * 64; Cp = c2m_cdiv(C, 32) * 32;
     nchunks = N * c2m_cdiv(H, 4) * c2m_cdiv(W, 32);
-    const long tiles = (long)(Mp / 64) * (Cp / 32);
+    const long tiles = (long)(Mp / 64) * (Cp / 32) * (s2 ? 2 : 1);
     long s = (768 + tiles - 1) / tiles;                           // ~1.5 resident rounds of 512 workgroups ...
     // ... but >= 16 chunks (2048 pixels, ~10 us of MFMAs) per split: every workgroup writes a 73 KB slab that is read back
     const long maxs = nchunks / 16 > 0 ? nchunks / 16 : 1;
@@ -694,44 +717,48 @@ static void wgrad_nc8_shape(int M, int C, long N, int H, int W, int& Mp, int& Cp
     S = (int)((nchunks + per - 1) / per);
 }
 
-// Floats the caller provides: slab = S * 9 * Mp * Cp, then dbslab = S * Mp (S = c2m_conv_wgrad_nc8_splits).
-C2M_API int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W) {
+// Floats the caller provides: slab = S * taps * Mp * Cp (taps = 9, or 16 for s2), then dbslab = S * Mp (S = c2m_conv_wgrad_nc8_splits).
+C2M_API int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W, int s2) {
     int Mp, Cp, S; long nch;
-    wgrad_nc8_shape(M, C, N, H, W, Mp, Cp, nch, S);
+    wgrad_nc8_shape(M, C, N, H, W, s2, Mp, Cp, nch, S);
     return S;
 }
-C2M_API long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W) {
+C2M_API long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W, int s2) {
     int Mp, Cp, S; long nch;
-    wgrad_nc8_shape(M, C, N, H, W, Mp, Cp, nch, S);
-    return (long)S * (9L * Mp * Cp + Mp);
+    wgrad_nc8_shape(M, C, N, H, W, s2, Mp, Cp, nch, S);
+    return (long)S * ((s2 ? 16L : 9L) * Mp * Cp + Mp);
 }
 
-// dY_nc8: [N][ceil(M/8)][H][W][8], X_nc8: [N][ceil(C/8)][H][W][8] (bf16); dW: [M][C][3][3] fp32; db: [M] fp32 or NULL.
+// dY_nc8: [N][ceil(M/8)][H][W][8]; s2 = 0: 3x3 stride-1 pad-1 layer, X_nc8 [N][ceil(C/8)][H][W][8], dW [M][C][3][3]; s2 = 1: 4x4
+// stride-2 pad-1 layer, X_nc8 [N][ceil(C/8)][2H][2W][8], dW [M][C][4][4]; db: [M] fp32 or NULL.
 C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N,
-                               int H, int W, int reflect, void* stream) {
+                               int H, int W, int reflect, int s2, void* stream) {
     C2M_ENTER();
     if (M <= 0 || C <= 0 || N <= 0) return 0;
     WgNc8P p;
     long nch; int S;
-    wgrad_nc8_shape(M, C, N, H, W, p.Mp, p.Cp, nch, S);
+    wgrad_nc8_shape(M, C, N, H, W, s2, p.Mp, p.Cp, nch, S);
     p.dY = dY_nc8; p.X = X_nc8; p.M = M; p.C = C; p.CBy = (M + 7) / 8; p.CBx = (C + 7) / 8;
     p.Nimg = (int)N; p.H = H; p.W = W; p.reflect = reflect;
+    p.Hin = s2 ? 2 * H : H; p.Win = s2 ? 2 * W : W;
     p.chunks_y = c2m_cdiv(H, 4); p.chunks_x = c2m_cdiv(W, 32); p.nchunks = (int)nch;
     p.chunks_per_split = c2m_cdiv(nch, S);
-    const long yb = N * p.CBy * (long)H * W * 16, xb = N * p.CBx * (long)H * W * 16;
+    const long yb = N * p.CBy * (long)H * W * 16, xb = N * p.CBx * (long)p.Hin * p.Win * 16;
     if (yb >= 0x80000000LL || xb >= 0x80000000LL || nch >= 0x7fffffffLL || (((uintptr_t)dY_nc8 | (uintptr_t)X_nc8) & 15) ||
-        (reflect && (H < 2 || W < 2)))
+        (reflect && (p.Hin < 2 || p.Win < 2)))
         return (int)hipErrorInvalidValue;
     p.dy_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
-    p.slab = slab; p.dbslab = slab + (long)S * 9 * p.Mp * p.Cp;
+    const int NTS = s2 ? 16 : 9;
+    p.slab = slab; p.dbslab = slab + (long)S * NTS * p.Mp * p.Cp;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((p.Mp / 64) * (p.Cp / 32) * S));
-    hipLaunchKernelGGL(conv_wgrad_nc8_kernel, grid, dim3(256), 0, s, p);
+    dim3 grid((unsigned)((p.Mp / 64) * (p.Cp / 32) * (s2 ? 2 : 1) * S));
+    if (s2) hipLaunchKernelGGL(conv_wgrad_nc8_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_nc8_kernel<false>, grid, dim3(256), 0, s, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    const long n = 9L * M * C;
+    const long n = (long)NTS * M * C;
     hipLaunchKernelGGL(wgrad_nc8_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.slab, p.dbslab, dW, db, M, C,
-                       p.Mp, p.Cp, S);
+                       p.Mp, p.Cp, S, NTS);
     return (int)hipGetLastError();
 }
 

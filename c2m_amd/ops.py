@@ -595,6 +595,9 @@ class _ConvPlan:
         self.s2_dgrad_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
                                  (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cin >= 8 and Cout >= 12 and qw >= 16 and
                                  dM == Cin and (_ceil(qw, 32) * _ceil(qh, 8)) <= _NC8_FILL * qw * qh)
+        self.s2_wgrad_nc8 = bool(self.nc8 and _NC8_S2 and _NC8_WGRAD and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
+                                 (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cout >= 64 and Cin >= 16 and
+                                 N * Ho * Wo >= 16384)      # (the few-pixel encoder tails: one or two chunks per split, slabs dominate)
         # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
         self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
                               (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)
@@ -1094,8 +1097,10 @@ class _ConvFn(torch.autograd.Function):
             Hi_, Wi_ = pl.dims[4:6]
             tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
 
+            ctx.nc8_keep = {} if (pl.s2_wgrad_nc8 and ctx.needs_input_grad[1]) else None
+
             def run_s2():
-                xn = _to_nc8(x)
+                xn = _to_nc8(x, ctx.nc8_keep)
                 return L.c2m_conv_s2_nc8(_p(A), _p(xn), _p(y), _p(b), Cout, Cin, N, Hi_, Wi_, int(pl.reflect), 1, ACT[act], slope,
                                          _stream())
             _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_s2, tag,
@@ -1157,7 +1162,7 @@ class _ConvFn(torch.autograd.Function):
         # NC8 form of dY: one layout pass shared by the data gradient and the weight gradient of this node (made on the main
         # stream BEFORE a fork, so the side stream's launch is ordered behind it)
         keep = {} if (pl.bf16 and pl.nc8) else None
-        if keep is not None and need_w and pl.wgrad_nc8:
+        if keep is not None and need_w and (pl.wgrad_nc8 or pl.s2_wgrad_nc8):
             gy = _as(gy, BF16)
             _to_nc8(gy, keep)
         if side is not None:
@@ -1185,18 +1190,19 @@ class _ConvFn(torch.autograd.Function):
         if not pl.bf16:
             gy = _as(gy, torch.float32)
         want = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        if want and pl.bf16 and pl.wgrad_nc8:
+        if want and pl.bf16 and (pl.wgrad_nc8 or pl.s2_wgrad_nc8):
             # both operands in NC8 form: X from the forward launch (ctx.nc8_keep) or converted now, dY shared with the data gradient
-            Hi, Wi = pl.dims[4:6]
+            s2 = int(pl.s2_wgrad_nc8)
+            Hi, Wi = pl.dims[7:9]                  # the dY map
             gyn = _to_nc8(_as(gy, BF16), keep)
             xn = next(iter(ctx.nc8_keep.values()))[1] if ctx.nc8_keep else _to_nc8(_as(x, BF16))
-            slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N, Hi, Wi), device=x.device, dtype=torch.float32)
+            slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N, Hi, Wi, s2), device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
             _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
                               lambda: L.c2m_conv_wgrad_nc8(_p(gyn), _p(xn), _p(slab), _p(gw), _p(gb_t), Cout, Cin, N, Hi, Wi,
-                                                           int(pl.reflect), _stream()), tag,
+                                                           int(pl.reflect), s2, _stream()), tag,
                               2 * (gyn.numel() + xn.numel()) + 4 * w.numel()), "conv_wgrad_nc8")
             return gw, (gb_t if ctx.has_bias else None)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and pl.wino_wgrad and pl.wino_wgrad3d:

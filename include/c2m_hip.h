@@ -111,13 +111,14 @@ int c2m_conv_s2_nc8(const void* A, const void* X_nc8, void* Y, const float* bias
  * 4 (reflect)}; T = dX [N][M][2Ho][2Wo] (zeros) or the padded gradient [N][M][2Ho+2][2Wo+2] (reflect; c2m_reflect_fold finishes). */
 int c2m_conv_s2_dgrad_nc8(const void* A, const void* dY_nc8, void* T, int M, int K, long N, int Ho, int Wo, int reflect, int th,
                           void* stream);
-/* Weight (+ bias) gradient of a 2-D 3x3 stride-1 pad-1 layer from NC8 operands: dW[m][c][ky][kx] = sum dY[n][m][y][x] *
- * X[n][c][y+ky-1][x+kx-1] (zeros or reflect padding), fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds
+/* Weight (+ bias) gradient from NC8 operands: s2 = 0: 2-D 3x3 stride-1 pad-1 layer, dW[m][c][ky][kx] = sum dY[n][m][y][x] *
+ * X[n][c][y+ky-1][x+kx-1]; s2 = 1: 4x4 stride-2 pad-1 layer, ... * X[n][c][2y+ky-1][2x+kx-1] (X is the [2H][2W] map; one workgroup per
+ * input-row parity, 8 taps each).  zeros or reflect padding; fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds
  * c2m_conv_wgrad_nc8_slab_floats(...) floats of scratch (per-split partial sums, reduced in a fixed order); db may be NULL.  */
-int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W);
-long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W);
+int c2m_conv_wgrad_nc8_splits(int M, int C, long N, int H, int W, int s2);
+long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W, int s2);
 int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int H,
-                       int W, int reflect, void* stream);
+                       int W, int reflect, int s2, void* stream);
 
 /* Winograd F(2x2,3x3) form of the 3x3 stride-1 layers (conv_wino.hip; same reference call sites as above: vgg.py:92-137,
  * spade_block.py:47-49, residual_block.py:13-71, up_block.py:9-13): 2.25x fewer MFMA FLOPs, fp32, bias/activation fused.

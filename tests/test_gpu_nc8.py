@@ -137,11 +137,13 @@ def test_stride2_parity_form_forward_and_data_gradient(case):
     xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
     pl = ops._plan(xg.bfloat16(), wg, (1, 2, 2), (0, 1, 1), mode == "reflect")
     assert pl.s2_nc8 and pl.s2_dgrad_nc8, "the case must run on the stride-2 forms of the NC8 kernels"
+    assert pl.s2_wgrad_nc8 == (Cout >= 64 and Cin >= 16), "weight gradient on the stride-2 transposed-read kernel"
     y = ops.conv(xg, wg, bg, stride=2, padding=1, padding_mode=mode)
     (y.float() * go.to(DEV)).sum().backward()
     rel_close(y.float(), yr, 4e-3, "stride-2 NC8 forward")
     rel_close(xg.grad, xr.grad, 5e-5, "stride-2 NC8 data gradient")
     rel_close(wg.grad, wr.grad, 1e-4, "weight gradient")
+    rel_close(bg.grad, br.grad, 1e-4, "bias gradient")
     # bf16 target of the data gradient (the type it has inside the network)
     xb = x.to(DEV).bfloat16().requires_grad_(True)
     yb = ops.conv(xb, wg.detach(), None, stride=2, padding=1, padding_mode=mode)
