@@ -278,6 +278,7 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
 
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+_NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
 _NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "2.6"))      # (18x34 padded domains of the 16x32 reflect data gradients: 2.5; still 1.5x+ the gather kernel)
 _NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
@@ -319,8 +320,13 @@ def _patch_splits(L, M, C, npix, bf16=False):
 
 def _to_nc8(x, keep=None):
     """c2m_nchw_to_nc8: contiguous bf16 [N, C, H, W] -> [N, ceil(C/8), H, W, 8] (the conv input form of conv_nc8.hip).
-    keep: a dict that remembers the result per source tensor (the data gradient and the weight gradient of one backward node
-    share the NC8 form of dY)."""
+    The result is remembered ON the source tensor (attribute, with the tensor's `_version`: any in-place change invalidates it),
+    so an activation that feeds several convolutions -- the SPADE maps, the shared conditioning features -- is converted once;
+    keep: a dict that additionally pins the result per source tensor for the duration of one backward node (the data gradient and
+    the weight gradient share the NC8 form of dY even when autograd hands them the gradient as a fresh tensor object)."""
+    hit = getattr(x, "_c2m_nc8", None)
+    if hit is not None and hit[0] == x._version and hit[1].device == x.device:
+        return hit[1]
     if keep is not None:
         hit = keep.get(x.data_ptr())
         if hit is not None and hit[0] is x:
@@ -330,6 +336,7 @@ def _to_nc8(x, keep=None):
     _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, H * W, _stream()), "nchw_to_nc8")
     if keep is not None:
         keep[x.data_ptr()] = (x, y)
+    x._c2m_nc8 = (x._version, y)
     return y
 
 
@@ -597,7 +604,7 @@ class _ConvPlan:
                                  dM == Cin and (_ceil(qw, 32) * _ceil(qh, 8)) <= _NC8_FILL * qw * qh)
         self.s2_wgrad_nc8 = bool(self.nc8 and _NC8_S2 and _NC8_WGRAD and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
                                  (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cout >= 64 and Cin >= 16 and
-                                 N * Ho * Wo >= 16384)      # (the few-pixel encoder tails: one or two chunks per split, slabs dominate)
+                                 N * Ho * Wo >= _NC8_S2_WGRAD_MIN_PIX)      # (the few-pixel encoder tails: one or two chunks per split, slabs dominate)
         # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
         self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
                               (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)

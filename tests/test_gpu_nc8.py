@@ -22,9 +22,11 @@ def _bf(t):
 @pytest.fixture(autouse=True)
 def _bf16_mode():
     prev = ops.set_conv_precision("bf16")
-    v0 = ops._NC8_VARIANT
+    v0, p0 = ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX
+    ops._NC8_S2_WGRAD_MIN_PIX = 0          # (the small test maps would otherwise stay on the NCHW weight-gradient kernel)
+    ops._geom_cache.clear()
     yield
-    ops._NC8_VARIANT = v0
+    ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX = v0, p0
     ops._geom_cache.clear()
     ops.set_conv_precision(prev)
 
