@@ -387,6 +387,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ex = float(t.item())
         result["allreduce_exposed_ms_per_step"] = None if ex is None else round(ex, 3)
+        pb = step.reducer.exposed_ms_per_bucket()     # rank 0's view: (bucket, ms its reduced gradients arrived after backward / the previous bucket)
+        result["allreduce_exposed_ms_per_bucket"] = None if pb is None else [[int(b), round(v, 3)] for b, v in pb]
     if args.check_grads or world > 1:
         # all-reduced gradients must be bit-identical on every rank although each rank saw different data
         gsum = torch.stack([p.grad.double().abs().sum() for p in model.parameters() if p.grad is not None])

@@ -101,6 +101,8 @@ class GradientReducer:
         self.use_avg = self.on_gpu and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         self.measure = measure and self.on_gpu
         self._exposed = []            # (event at end of backward compute, event after the side stream was joined)
+        self._exposed_buckets = []    # (event at arm(), event at end of backward, [(bucket, event: its reduced gradients final)])
+        self._launched_now, self._base_ev = [], None
         if self.world > 1:            # identical starting point on every rank, whatever the callers seeded
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
             with torch.no_grad():
@@ -134,6 +136,10 @@ class GradientReducer:
         self.armed = True
         self.fired_final.clear()
         self._fire_seq = []
+        if self.measure and self.collectives:         # time base of the per-bucket exposure (always before every bucket event)
+            self._base_ev = torch.cuda.Event(enable_timing=True)
+            self._base_ev.record(torch.cuda.current_stream(self.device))
+        self._launched_now = []
         if self.expected is not None:
             for b in self.buckets:
                 b.pending = sum(1 for p in b.params if id(p) in self.expected)
@@ -200,6 +206,13 @@ class GradientReducer:
                     b.work.wait()
                     b.work = None
                     self._expand(b)
+                if self.measure:                 # when this bucket's reduced gradients are final (per-bucket exposure)
+                    if b.work is not None:
+                        b.work.wait()            # (stream-side wait only: orders the event behind the collective)
+                        b.work = None
+                    b.done_ev = torch.cuda.Event(enable_timing=True)
+                    b.done_ev.record(self.stream)
+                    self._launched_now.append(b)
         else:
             self._collective(b)
             self._expand(b)
@@ -214,6 +227,8 @@ class GradientReducer:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record(torch.cuda.current_stream(self.device))
                 self._exposed.append((ev0, ev1))
+                self._exposed_buckets.append((self._base_ev, ev0, [(b.index, b.done_ev) for b in self._launched_now]))
+        self._launched_now = []
 
     def _mark(self):
         if self.measure and self.collectives:
@@ -241,6 +256,7 @@ class GradientReducer:
         if self.expected is None:
             raise RuntimeError("GradientReducer.reduce_all: run one eager step (arm / finish) first")
         ev0 = self._mark()
+        self._base_ev, self._launched_now = ev0, []
         for b in self.buckets:
             b.work, b.launched = None, False
             self._launch(b)
@@ -287,8 +303,27 @@ class GradientReducer:
         torch.cuda.synchronize(self.device)
         return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
+    def exposed_ms_per_bucket(self):
+        """[(bucket index in launch order, mean ms per step)]: how much later than the end of the backward kernels (and than
+        the previous bucket) each bucket's reduced gradients became final -- the share of the exposed all-reduce time every
+        bucket is responsible for; 0 for a bucket whose collective was hidden behind backward.  None unless measured."""
+        rows = [r for r in self._exposed_buckets if r[0] is not None and r[2]]
+        if not rows:
+            return None
+        torch.cuda.synchronize(self.device)
+        acc, cnt = {}, {}
+        for base, ev0, evs in rows:
+            t_prev = base.elapsed_time(ev0)               # end of backward on the time base
+            for k, (bi, ev) in enumerate(evs):
+                t = base.elapsed_time(ev)
+                acc[(k, bi)] = acc.get((k, bi), 0.0) + max(0.0, t - t_prev)
+                cnt[(k, bi)] = cnt.get((k, bi), 0) + 1
+                t_prev = max(t_prev, t)
+        return [(bi, acc[(k, bi)] / cnt[(k, bi)]) for (k, bi) in sorted(acc)]
+
     def reset_measurements(self):
         self._exposed = []
+        self._exposed_buckets = []
 
     def bytes_per_step(self):
         """Bytes each rank hands to the all-reduce per step."""

@@ -56,6 +56,9 @@ def test_bench_under_torchrun_with_rccl_reducer():
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["rccl_ranks"] == 1
     assert r["allreduce_bytes_per_step"] > 4e8 and r["allreduce_buckets"] >= 10
     assert r["allreduce_exposed_ms_per_step"] is not None
+    pb = r["allreduce_exposed_ms_per_bucket"]         # per-bucket share of the exposed time, in launch order
+    assert pb is not None and len(pb) == r["allreduce_buckets"] and all(v >= 0 for _, v in pb)
+    assert abs(sum(v for _, v in pb) - r["allreduce_exposed_ms_per_step"]) < 0.5
 
 
 def test_two_rank_rehearsal_on_one_gpu_gradients_identical():
