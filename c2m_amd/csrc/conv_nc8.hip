@@ -86,6 +86,13 @@ struct Nc8P {
     int iy0, ix0, pty[3], ptx[3];
     int reflect, act, yh, chunks_per_split;
     float slope;
+    // 3x3x3 layers (same_block.py:50-68, the fuse_convs of the motion decoder) as 2-D launches over (sample, frame) images with the
+    // chunk index running over (time tap, 16 channels): T frames per sample (1: a 2-D layer), nch2d chunks per time tap, input
+    // frame = t + kt + t0 (reflected or zero outside [0, T)); out_st = output frame stride
+    int T, nch2d, t0, treflect;
+    const int* ptab;     // data gradient of a 3x3x3 reflect layer: per output frame {npairs, (dY frame, time tap) x 5}: the pad frames'
+                         // contributions folded onto the frames they mirror (ops._time_pair_table_kt); chunk = (pair, 16 channels)
+    long out_st;
     long out_sn, out_sc, out_sh, out_off, slab_stride;
     int ps_y, ps_x, po_y, po_x, lo_y, lo_x, ext_y, ext_x;
     long y2_sn, y2_sc, y2_sh;
@@ -126,6 +133,14 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
     const int tx = tb % tiles_x; tb /= tiles_x;
     const int ty = tb % tiles_y; const int n_img = tb / tiles_y;
     const int oy0 = ty * TR, ox0 = tx * 32;
+    const int n_smp = n_img / p.T, t_img = n_img - n_smp * p.T;     // (sample, output frame); T = 1 for 2-D layers
+    int pr_n = 0, pr_to[5] = {0, 0, 0, 0, 0}, pr_kt[5] = {0, 0, 0, 0, 0};
+    if (p.ptab) {
+        const int* __restrict__ e = p.ptab + t_img * 11;
+        pr_n = __builtin_amdgcn_readfirstlane(e[0]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { pr_to[j] = __builtin_amdgcn_readfirstlane(e[1 + 2 * j]); pr_kt[j] = __builtin_amdgcn_readfirstlane(e[2 + 2 * j]); }
+    }
 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
     // ---- weight DMA: destination unit d = (i * 4 + wave) * 64 + lane of [tap][half][row]; source [tap][m0 + row][half]
@@ -158,14 +173,26 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
                 ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
             }
             const bool ok = u < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            pvo[par][r] = ok ? (unsigned)n_img * (unsigned)p.CB * plane_bytes + (unsigned)(iy * p.Wi + ix) * 16u : NC8_OOB;
+            pvo[par][r] = ok ? (unsigned)(iy * p.Wi + ix) * 16u : NC8_OOB;      // inside the plane; the plane rides in the scalar offset
         }
     // Every iteration issues exactly NDMA instructions per wave, so the counted waits below are constants: a chunk past the
     // split's end is "fetched" through zero-record descriptors (no memory traffic; zeros land in a buffer nobody reads again).
     auto issue_dma = [&](int chunk, int buf, bool live, auto PARC) {
         constexpr int parc = decltype(PARC)::value;        // S2: parity of `chunk` (compile time: the chunk loop is unrolled by 4)
         const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
-        const int asoff = live ? (int)((unsigned)chunk * a_chunk_bytes) : 0;
+        const int c2d = S2 ? chunk >> 2 : chunk;
+        int kt = S2 ? 0 : c2d / p.nch2d;                   // time tap (0 for 2-D layers: nch2d = all chunks); pair index with ptab
+        const int cc = c2d - kt * p.nch2d;
+        const int cb = cc * 2 + phalf;
+        int ti = t_img + kt + p.t0;
+        if (p.ptab) {                                      // (pair j) -> (dY frame, time tap): wave-uniform selects over SGPRs
+            ti = kt == 0 ? pr_to[0] : (kt == 1 ? pr_to[1] : (kt == 2 ? pr_to[2] : (kt == 3 ? pr_to[3] : pr_to[4])));
+            kt = kt == 0 ? pr_kt[0] : (kt == 1 ? pr_kt[1] : (kt == 2 ? pr_kt[2] : (kt == 3 ? pr_kt[3] : pr_kt[4])));
+        }
+        if (p.treflect) { ti = ti < 0 ? -ti : ti; ti = ti >= p.T ? 2 * p.T - 2 - ti : ti; }
+        const bool tok = (unsigned)ti < (unsigned)p.T;     // zero padding in time: the whole chunk reads zeros
+        const int achunk = S2 ? chunk : kt * p.nch2d + cc; // weight chunk: [time tap][16 channels]
+        const int asoff = live ? (int)((unsigned)achunk * a_chunk_bytes) : 0;
         u32x4 ark = ars;
         ark[2] = live ? p.a_bytes : 0u;
 #pragma unroll
@@ -175,10 +202,9 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
                          :: "s"(dst), "v"(avo[i]), "s"(ark), "s"(asoff) : "memory");
         }
         // a channel block past the tensor's last one (odd block count, last chunk): zero records instead of the next image
-        const int cb = (S2 ? chunk >> 2 : chunk) * 2 + phalf;
         u32x4 rsk = xrs;
-        rsk[2] = (live && cb < p.CB) ? p.x_bytes : 0u;
-        const int psoff = live ? (int)((unsigned)cb * plane_bytes) : 0;
+        rsk[2] = (live && cb < p.CB && tok) ? p.x_bytes : 0u;
+        const int psoff = (live && tok) ? (int)((unsigned)((n_smp * p.CB + cb) * p.T + ti) * plane_bytes) : 0;
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const unsigned dst = base + (unsigned)((A_PAD + phalf * PPL + (pj0 + r) * 64) * 16);
@@ -206,6 +232,8 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
 
     const int chunk_beg = blk.z * p.chunks_per_split;
     int chunk_end = chunk_beg + p.chunks_per_split; chunk_end = chunk_end < p.nchunks ? chunk_end : p.nchunks;
+    if (p.ptab) chunk_end = pr_n * p.nch2d;                // (no split-K with a pair table: the chunk list depends on the frame)
+    // (the table loads above are ordinary VMEM the compiler waits for before their first use -- before any DMA is in flight)
 
     struct Frag { bf16x8 a[MI], b[NI]; };
     auto read_frag = [&](int buf, int tap, Frag& f) {
@@ -286,7 +314,7 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
     const bool yh = p.yh && direct;
     float* __restrict__ Yb = p.Y + (long)blk.z * p.slab_stride;
     float* __restrict__ T = reinterpret_cast<float*>(&smem[0]) + wave * (CG * 64);
-    const bool vec_ok = !p.Y2 && (p.Wo & 7) == 0 && (p.out_off & 7) == 0 && (p.out_sc & 7) == 0 && (p.out_sn & 7) == 0 &&
+    const bool vec_ok = !p.Y2 && (p.Wo & 7) == 0 && (p.out_off & 7) == 0 && (p.out_sc & 7) == 0 && (p.out_sn & 7) == 0 && (p.out_st & 7) == 0 &&
                         (p.out_sh & 7) == 0 && (p.slab_stride & 7) == 0 && ((uintptr_t)p.Y & 15) == 0;
     if (vec_ok) {
 #pragma unroll
@@ -321,7 +349,7 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
                     const int row = m0 + h * CG + cl;
                     const int oy = oy0 + wave * NI + jp * 2 + (px >> 5), ox = ox0 + (px & 31);
                     if (row < p.M && oy < p.Ho && ox < p.Wo) {
-                        const long e = p.out_off + (long)n_img * p.out_sn + (long)row * p.out_sc + (long)oy * p.out_sh + ox;
+                        const long e = p.out_off + (long)n_smp * p.out_sn + (long)t_img * p.out_st + (long)row * p.out_sc + (long)oy * p.out_sh + ox;
                         if (yh) {
                             const bf16x8 o = {(bf16_t)v0.x, (bf16_t)v0.y, (bf16_t)v0.z, (bf16_t)v0.w,
                                               (bf16_t)v1.x, (bf16_t)v1.y, (bf16_t)v1.z, (bf16_t)v1.w};
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         const int oy = oy0 + wave * NI + j, ox = ox0 + (lane & 31);
         if (oy >= p.Ho || ox >= p.Wo) continue;
         float* ybase = Yb;                                 // element type: float, or bf16_t when yh
-        long yidx = p.out_off + (long)n_img * p.out_sn + (long)oy * p.out_sh + ox;
+        long yidx = p.out_off + (long)n_smp * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh + ox;
         long row_stride = p.out_sc;
         if (p.Y2) {
             const int yp = oy * p.ps_y + p.po_y - p.lo_y, xp = ox * p.ps_x + p.po_x - p.lo_x;
@@ -369,6 +397,8 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
             }
     }
 }
+
+static int nc8_launch_patch(Nc8P& p, int splits, int v, hipStream_t s);
 
 // geom[]: the indices of c2m_conv_igemm's LDS-patch path (include/c2m_hip.h) -- M, nk = 9 * chunks, lda = padded rows of the
 // weight image, Npix, Ho, Wo, Hi, Wi, output strides, reflect, splits, slab stride, cin, the two-target block [36..51], the patch
@@ -404,10 +434,13 @@ C2M_API int c2m_conv_patch_nc8(const void* A, const void* X, void* Y, void* Y_in
     for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
     p.chunks_per_split = c2m_cdiv(p.nchunks, splits);
     if (c2m_cdiv(p.nchunks, p.chunks_per_split) != splits) return (int)hipErrorInvalidValue;
-    hipStream_t s = (hipStream_t)stream;
-    // geom[93]: tile / buffering variant (tuning): 0 = rule below; (output rows, LDS buffers, workgroups per CU, tile rows):
+    p.T = 1; p.nch2d = p.nchunks; p.t0 = 0; p.treflect = 0; p.out_st = 0; p.ptab = nullptr;
+    return nc8_launch_patch(p, splits, (int)g[93], (hipStream_t)stream);
+}
+
+static int nc8_launch_patch(Nc8P& p, int splits, int v, hipStream_t s) {
+    // tile / buffering variant (tuning): 0 = rule below; (output rows, LDS buffers, workgroups per CU, tile rows):
     // 1 (64, 2, 2, 8)   2 (64, 2, 2, 16)   3 (128, 3, 1, 8)   4 (32, 3, 2, 8)   5 (32, 2, 2, 16)   6 (64, 3, 1, 16)
-    int v = (int)g[93];
     if (v == 0) {
         // 16-row tiles (half the weight traffic per MFMA, twice the work between barriers) where they still give two full rounds
         // of workgroups (512 resident: 256 CUs x 2); measured per shape on one box (tools/ab_nc8.py): 938-986 vs 883-910 TF/s on
@@ -455,6 +488,7 @@ C2M_API int c2m_conv_s2_nc8(const void* A, const void* X, void* Y, const float* 
     p.out_sn = (long)M * p.Ho * p.Wo; p.out_sc = (long)p.Ho * p.Wo; p.out_sh = p.Wo; p.out_off = 0;
     p.reflect = reflect; p.slab_stride = 0; p.act = act; p.slope = slope; p.yh = yh;
     p.chunks_per_split = p.nchunks;
+    p.T = 1; p.nch2d = p.nchunks; p.t0 = 0; p.treflect = 0; p.out_st = 0; p.ptab = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const long tiles = N * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
     if (M <= 32) {
@@ -465,6 +499,62 @@ C2M_API int c2m_conv_s2_nc8(const void* A, const void* X, void* Y, const float* 
         hipLaunchKernelGGL((conv_patch_nc8_kernel<64, 4, 2, 8, true>), grid, dim3(256), 0, s, p);
     }
     return (int)hipGetLastError();
+}
+
+// 3x3x3 stride-1 pad-1 convolution (zeros / reflect in all three dimensions) on [N][C][T][H][W]: X NC8 = [N][ceil(C/8)][T][H][W][8], A =
+// three c2m_pack_weights_bf16_patch images back to back (time tap kt: w + 9 kt with strides s_m = 27 C, s_c = 27), Y contiguous NCTHW.
+C2M_API int c2m_conv3d_nc8(const void* A, const void* X, void* Y, const float* bias, int M, int C, long N, int T, int H, int W,
+                           int reflect, int yh, int act, float slope, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || C <= 0 || N <= 0 || T <= 0) return 0;
+    if ((((uintptr_t)A | (uintptr_t)X | (uintptr_t)Y) & 15) || (reflect && (T < 2 || H < 2 || W < 2))) return (int)hipErrorInvalidValue;
+    Nc8P p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.X = X; p.Y = (float*)Y; p.Y2 = nullptr; p.bias = bias;
+    p.M = M; p.Mpad = c2m_cdiv(M, 128) * 128;
+    p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W; p.Nimg = (int)(N * T);
+    p.CB = (C + 7) / 8;
+    p.nch2d = c2m_cdiv(C, 16); p.nchunks = 3 * p.nch2d; p.T = T; p.t0 = -1; p.treflect = reflect; p.ptab = nullptr;
+    const long xb = N * p.CB * (long)T * H * W * 16, ab = (long)p.nchunks * 9 * p.Mpad * 32;
+    if (xb >= 0x80000000LL || ab >= 0x80000000LL || N * (long)M * T * H * W * 4 >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
+    p.out_sn = (long)M * T * H * W; p.out_sc = (long)T * H * W; p.out_st = (long)H * W; p.out_sh = W; p.out_off = 0;
+    p.reflect = reflect; p.act = act; p.slope = slope; p.yh = yh;
+    p.iy0 = -1; p.ix0 = -1;
+    for (int i = 0; i < 3; ++i) { p.pty[i] = i; p.ptx[i] = i; }
+    p.chunks_per_split = p.nchunks;
+    return nc8_launch_patch(p, 1, 0, (hipStream_t)stream);
+}
+
+// Data gradient of such a layer with REFLECT padding: dY NC8 [N][ceil(K/8)][T][H][W][8] -> the spatially padded gradient
+// T_ [N][M][T][H+2][W+2] (bf16 / fp32), launched over the T real frames: frame t sums its (dY frame, time tap) pairs from `ptab`
+// (device int32 [T][11]: {npairs, (frame, kt) x 5}; the pad frames folded onto the frames they mirror), taps rotated in the plane
+// (patch origin -2, tap order 2,1,0).  A = three pack images (kt: w + 9 kt, rows = input channels: s_m = 27, s_c = 27 M).
+// c2m_reflect_fold(pt = 0, ph = pw = 1) finishes.  Zero padding: the table lists the in-range (t + 1 - kt, kt) pairs, target
+// [N][M][T][H][W] (no fold).
+C2M_API int c2m_conv3d_dgrad_nc8(const void* A, const void* dY, void* Tgt, const int* ptab, int M, int K, long N, int T, int H, int W,
+                                 int reflect, int th, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || K <= 0 || N <= 0 || T <= 0) return 0;
+    if ((((uintptr_t)A | (uintptr_t)dY | (uintptr_t)Tgt) & 15) || !ptab) return (int)hipErrorInvalidValue;
+    Nc8P p;
+    memset(&p, 0, sizeof(p));
+    const int pad = reflect ? 1 : 0;
+    p.A = A; p.X = dY; p.Y = (float*)Tgt; p.Y2 = nullptr; p.bias = nullptr;
+    p.M = M; p.Mpad = c2m_cdiv(M, 128) * 128;
+    p.Hi = H; p.Wi = W; p.Ho = H + 2 * pad; p.Wo = W + 2 * pad; p.Nimg = (int)(N * T);
+    p.CB = (K + 7) / 8;
+    p.nch2d = c2m_cdiv(K, 16); p.nchunks = 3 * p.nch2d; p.T = T; p.treflect = 0;
+    p.ptab = ptab; p.t0 = 0;                               // (zeros padding: the table holds the in-range (t + 1 - kt, kt) pairs)
+    const long xb = N * p.CB * (long)T * H * W * 16, ab = (long)p.nchunks * 9 * p.Mpad * 32;
+    if (xb >= 0x80000000LL || ab >= 0x80000000LL || N * (long)M * T * p.Ho * p.Wo * 4 >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
+    p.out_sn = (long)M * T * p.Ho * p.Wo; p.out_sc = (long)T * p.Ho * p.Wo; p.out_st = (long)p.Ho * p.Wo; p.out_sh = p.Wo; p.out_off = 0;
+    p.reflect = 0; p.act = 0; p.slope = 0.f; p.yh = th;
+    p.iy0 = -1 - pad; p.ix0 = -1 - pad;
+    for (int i = 0; i < 3; ++i) { p.pty[i] = 2 - i; p.ptx[i] = 2 - i; }
+    p.chunks_per_split = p.nchunks;
+    return nc8_launch_patch(p, 1, 0, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient on NC8 operands
@@ -487,6 +577,7 @@ struct WgNc8P {
     int M, C, Mp, Cp, CBy, CBx;
     int Nimg, H, W, reflect;        // H, W: the dY map
     int Hin, Win;                   // the X map (= H, W; 2H, 2W for the stride-2 layers)
+    int T, kt, treflect;            // 3x3x3 layers: images are (sample, frame) pairs of T frames, X frame = t + kt - 1 (one launch per kt)
     int chunks_y, chunks_x, nchunks, chunks_per_split;
     unsigned dy_bytes, x_bytes;
 };
@@ -546,15 +637,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
     auto issue_dma = [&](int chunk, int buf, bool live) {
         int t = chunk;
         const int cx = t % p.chunks_x; t /= p.chunks_x;
-        const int cy = t % p.chunks_y; const int n = t / p.chunks_y;
+        const int cy = t % p.chunks_y; const int nimg = t / p.chunks_y;
         const int y0 = cy * 4, x0 = cx * 32;
+        const int ns = nimg / p.T, tf = nimg - ns * p.T;            // (sample, frame); T = 1: 2-D layers
+        int tx = tf + p.kt - (p.T > 1 ? 1 : 0);
+        if (p.treflect) { tx = tx < 0 ? -tx : tx; tx = tx >= p.T ? 2 * p.T - 2 - tx : tx; }
+        const bool tok = (unsigned)tx < (unsigned)p.T;
         const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
         // dY: 4 rows of 64 units
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int I = wave * 4 + j, cb = I >> 1, r = (I & 1) * 2 + d_r;
             const bool ok = y0 + r < p.H && x0 + d_col < p.W;
-            const unsigned vo = ok ? ((unsigned)(n * p.CBy + cby0 + cb) * HW16 + (unsigned)((y0 + r) * p.W + x0 + d_col) * 16u) : NC8_OOB;
+            const unsigned vo = ok ? ((unsigned)((ns * p.CBy + cby0 + cb) * p.T + tf) * HW16 + (unsigned)((y0 + r) * p.W + x0 + d_col) * 16u) : NC8_OOB;
             u32x4 rs = yrs;
             rs[2] = (live && cby0 + cb < p.CBy) ? p.dy_bytes : 0u;
             const unsigned dst = base + (unsigned)((cb * DPL + (I & 1) * 64) * 16);
@@ -573,9 +668,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
                 ix = ix < 0 ? -ix : ix; ix = ix >= p.Win ? 2 * p.Win - 2 - ix : ix;
             }
             const bool ok = (x_code[j] >> 12) != 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            const unsigned vo = ok ? ((unsigned)(n * p.CBx + cbx0 + xpl) * XHW16 + (unsigned)(iy * p.Win + ix) * 16u) : NC8_OOB;
+            const unsigned vo = ok ? ((unsigned)((ns * p.CBx + cbx0 + xpl) * p.T + tx) * XHW16 + (unsigned)(iy * p.Win + ix) * 16u) : NC8_OOB;
             u32x4 rs = xrs;
-            rs[2] = live ? p.x_bytes : 0u;
+            rs[2] = (live && tok) ? p.x_bytes : 0u;
             const unsigned dst = base + (unsigned)((SD + I * 64) * 16);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(vo), "s"(rs) : "memory");
         }
@@ -680,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_nc8_kernel(const WgNc8P p) 
 // dW[m][c][tap] = sum over slabs; db[m] likewise.  Thread = (tap, m, c) with c fastest (coalesced slab reads); four interleaved
 // partial sums keep the loads in flight, combined in a fixed order -> bit-reproducible.
 __global__ void wgrad_nc8_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab, float* __restrict__ dW,
-                                        float* __restrict__ db, int M, int C, int Mp, int Cp, int nslab, int NT) {
+                                        float* __restrict__ db, int M, int C, int Mp, int Cp, int nslab, int NT, int out_nt, int out_t0) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long MC = (long)M * C;
     if (i < NT * MC) {
@@ -695,7 +790,7 @@ __global__ void wgrad_nc8_reduce_kernel(const float* __restrict__ slab, const fl
             s0 += q[(long)k * st]; s1 += q[(long)(k + 1) * st]; s2 += q[(long)(k + 2) * st]; s3 += q[(long)(k + 3) * st];
         }
         for (; k < nslab; ++k) s0 += q[(long)k * st];
-        dW[mc * NT + t] = (s0 + s1) + (s2 + s3);
+        dW[mc * out_nt + out_t0 + t] = (s0 + s1) + (s2 + s3);      // (3x3x3 layers: 27 taps per (m, c), this launch's 9 at kt * 9)
     }
     if (db && i < M) {
         float s = 0.f;
@@ -729,28 +824,24 @@ C2M_API long c2m_conv_wgrad_nc8_slab_floats(int M, int C, long N, int H, int W, 
     return (long)S * ((s2 ? 16L : 9L) * Mp * Cp + Mp);
 }
 
-// dY_nc8: [N][ceil(M/8)][H][W][8]; s2 = 0: 3x3 stride-1 pad-1 layer, X_nc8 [N][ceil(C/8)][H][W][8], dW [M][C][3][3]; s2 = 1: 4x4
-// stride-2 pad-1 layer, X_nc8 [N][ceil(C/8)][2H][2W][8], dW [M][C][4][4]; db: [M] fp32 or NULL.
-C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N,
-                               int H, int W, int reflect, int s2, void* stream) {
-    C2M_ENTER();
-    if (M <= 0 || C <= 0 || N <= 0) return 0;
+static int wgrad_nc8_launch(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int T,
+                            int kt, int H, int W, int reflect, int s2, hipStream_t s) {
     WgNc8P p;
     long nch; int S;
-    wgrad_nc8_shape(M, C, N, H, W, s2, p.Mp, p.Cp, nch, S);
+    wgrad_nc8_shape(M, C, N * T, H, W, s2, p.Mp, p.Cp, nch, S);
     p.dY = dY_nc8; p.X = X_nc8; p.M = M; p.C = C; p.CBy = (M + 7) / 8; p.CBx = (C + 7) / 8;
-    p.Nimg = (int)N; p.H = H; p.W = W; p.reflect = reflect;
+    p.Nimg = (int)(N * T); p.H = H; p.W = W; p.reflect = reflect;
+    p.T = T; p.kt = kt; p.treflect = reflect;
     p.Hin = s2 ? 2 * H : H; p.Win = s2 ? 2 * W : W;
     p.chunks_y = c2m_cdiv(H, 4); p.chunks_x = c2m_cdiv(W, 32); p.nchunks = (int)nch;
     p.chunks_per_split = c2m_cdiv(nch, S);
-    const long yb = N * p.CBy * (long)H * W * 16, xb = N * p.CBx * (long)p.Hin * p.Win * 16;
+    const long yb = N * T * p.CBy * (long)H * W * 16, xb = N * T * p.CBx * (long)p.Hin * p.Win * 16;
     if (yb >= 0x80000000LL || xb >= 0x80000000LL || nch >= 0x7fffffffLL || (((uintptr_t)dY_nc8 | (uintptr_t)X_nc8) & 15) ||
-        (reflect && (p.Hin < 2 || p.Win < 2)))
+        (reflect && (p.Hin < 2 || p.Win < 2 || (T > 1 && T < 2))))
         return (int)hipErrorInvalidValue;
     p.dy_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
     const int NTS = s2 ? 16 : 9;
     p.slab = slab; p.dbslab = slab + (long)S * NTS * p.Mp * p.Cp;
-    hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((p.Mp / 64) * (p.Cp / 32) * (s2 ? 2 : 1) * S));
     if (s2) hipLaunchKernelGGL(conv_wgrad_nc8_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_wgrad_nc8_kernel<false>, grid, dim3(256), 0, s, p);
@@ -758,8 +849,30 @@ C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* sla
     if (rc) return rc;
     const long n = (long)NTS * M * C;
     hipLaunchKernelGGL(wgrad_nc8_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.slab, p.dbslab, dW, db, M, C,
-                       p.Mp, p.Cp, S, NTS);
+                       p.Mp, p.Cp, S, NTS, T > 1 ? 27 : NTS, T > 1 ? kt * 9 : 0);
     return (int)hipGetLastError();
+}
+
+// dY_nc8: [N][ceil(M/8)][H][W][8]; s2 = 0: 3x3 stride-1 pad-1 layer, X_nc8 [N][ceil(C/8)][H][W][8], dW [M][C][3][3]; s2 = 1: 4x4
+// stride-2 pad-1 layer, X_nc8 [N][ceil(C/8)][2H][2W][8], dW [M][C][4][4]; db: [M] fp32 or NULL.
+C2M_API int c2m_conv_wgrad_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N,
+                               int H, int W, int reflect, int s2, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || C <= 0 || N <= 0) return 0;
+    return wgrad_nc8_launch(dY_nc8, X_nc8, slab, dW, db, M, C, N, 1, 0, H, W, reflect, s2, (hipStream_t)stream);
+}
+
+// 3x3x3 stride-1 pad-1 layers: dY_nc8 [N][ceil(M/8)][T][H][W][8], X_nc8 [N][ceil(C/8)][T][H][W][8], dW [M][C][3][3][3]: one launch per
+// time tap over the N * T (sample, frame) images, X frame t + kt - 1 (reflected / zero); slab as for c2m_conv_wgrad_nc8 with N * T images.
+C2M_API int c2m_conv_wgrad3d_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int T,
+                                 int H, int W, int reflect, void* stream) {
+    C2M_ENTER();
+    if (M <= 0 || C <= 0 || N <= 0 || T <= 1) return (int)hipErrorInvalidValue;
+    for (int kt = 0; kt < 3; ++kt) {
+        const int rc = wgrad_nc8_launch(dY_nc8, X_nc8, slab, dW, kt == 1 ? db : nullptr, M, C, N, T, kt, H, W, reflect, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ 4x4 stride-2 data gradient on NC8

@@ -278,6 +278,7 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
 
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+_NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
 _NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
 _NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "2.6"))      # (18x34 padded domains of the 16x32 reflect data gradients: 2.5; still 1.5x+ the gather kernel)
@@ -331,13 +332,48 @@ def _to_nc8(x, keep=None):
         hit = keep.get(x.data_ptr())
         if hit is not None and hit[0] is x:
             return hit[1]
-    N, C, H, W = x.shape
-    y = torch.empty(N, _cdiv(C, 8), H, W, 8, device=x.device, dtype=BF16)
-    _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, H * W, _stream()), "nchw_to_nc8")
+    N, C = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])                 # (H, W), or (T, H, W): the pixel axis of the layout pass is everything behind C
+    y = torch.empty((N, _cdiv(C, 8)) + sp + (8,), device=x.device, dtype=BF16)
+    _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, int(np.prod(sp)), _stream()), "nchw_to_nc8")
     if keep is not None:
         keep[x.data_ptr()] = (x, y)
     x._c2m_nc8 = (x._version, y)
     return y
+
+
+def _time_pair_table_kt(T, reflect):
+    """Data gradient of a 3-tap pad-1 convolution in time: output frame t sums dY frame `to` through time tap kt for every
+    (to, kt) with reflect(to + kt - 1) == t (reflect padding: the pad frames' contributions land on the frames they mirror) or
+    to + kt - 1 == t (zeros).  int32 [T][11] = {npairs, (to, kt) x 5} -- c2m_conv3d_dgrad_nc8's ptab."""
+    tab = np.zeros((T, 11), dtype=np.int32)
+    for t in range(T):
+        pairs = []
+        for kt in range(3):
+            for to in range(T):
+                q = to + kt - 1
+                if reflect:
+                    q = -q if q < 0 else (2 * T - 2 - q if q >= T else q)
+                if q == t:
+                    pairs.append((to, kt))
+        assert 1 <= len(pairs) <= 5
+        tab[t, 0] = len(pairs)
+        for j, (to, kt) in enumerate(pairs):
+            tab[t, 1 + 2 * j], tab[t, 2 + 2 * j] = to, kt
+    return tab
+
+
+def _pack_bf16_k333(w, M, C, dgrad=False):
+    """Weights [Cout][Cin][3][3][3] of a 3x3x3 layer -> three c2m_pack_weights_bf16_patch images back to back (time tap kt = 0, 1, 2);
+    rows M = output channels, reduction C = input channels -- or, for the data gradient, rows = input channels over output channels."""
+    L = _lib.lib()
+    nb = L.c2m_pack_weights_bf16_patch_bytes(M, C)
+    out = torch.empty(3 * nb, device=w.device, dtype=torch.uint8)
+    wf = w.reshape(-1)
+    for kt in range(3):
+        g = np.array([M, C, 27, M * 27, 0] if dgrad else [M, C, C * 27, 27, 0], dtype=np.int64)
+        _lib.check(L.c2m_pack_weights_bf16_patch(_p(wf[kt * 9:]), _p(out[kt * nb:]), _gp(g), _stream()), "pack_weights_bf16_patch (3-D)")
+    return out
 
 
 def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope, keep=None):
@@ -593,6 +629,17 @@ class _ConvPlan:
         self.fwd_patch = False
         # channel-blocked input (conv_nc8.hip): 2-D bf16 patch layers whose planes are whole 8-pixel groups
         self.nc8 = bool(bf16 and _NC8 and nd == 2 and (Hi * Wi) % 8 == 0 and (Ho * Wo) % 8 == 0)
+        # ... the 3x3x3 stride-1 pad-1 layers as (sample, frame) images with (time tap, channel) chunks: forward and weight gradient
+        k333 = bool(bf16 and _NC8 and _NC8_3D and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and
+                    (pt, ph, pw) == (1, 1, 1) and (Hi * Wi) % 8 == 0 and Ti >= 2 and Cin >= 12 and _ceil(Cin, 16) <= 1.25 * Cin and
+                    Wo >= 32 and Ho >= 8 and (_ceil(Wo, 32) * _ceil(Ho, 8)) <= _NC8_FILL * Wo * Ho)
+        self.k333_nc8 = k333 and Cout > 4
+        self.k333_wgrad_nc8 = k333 and _NC8_WGRAD and Cout >= 64 and Cin >= 16
+        pd = 1 if reflect else 0
+        self.k333_dgrad_nc8 = bool(k333 and dM == Cin and Cout >= 12 and _ceil(Cout, 16) <= 1.25 * Cout and Cin > 4 and
+                                   (_ceil(Wi + 2 * pd, 32) * _ceil(Hi + 2 * pd, 8)) <= _NC8_FILL * (Wi + 2 * pd) * (Hi + 2 * pd))
+        if self.k333_dgrad_nc8:
+            self.k333_ptab = torch.from_numpy(_time_pair_table_kt(Ti, bool(reflect)).reshape(-1)).to(device)
         # ... the 4x4 stride-2 pad-1 layers on the parity-plane form of the patch kernel (forward)
         self.s2_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and (ph, pw) == (1, 1)
                            and Hi % 2 == 0 and Wi % 2 == 0 and Cout > 4 and Cin >= 12 and Wo >= 16 and Ho >= 4 and
@@ -970,6 +1017,22 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
             Ti, Hi, Wi = pl.dims[3:6]
             _lib.check(L.c2m_reflect_border_add(_p(tgt), _p(gx), N * Cin, Ti, Hi, Wi, 0, 1, 1, 0, _stream()),
                        "reflect border add")
+    elif pl.bf16 and pl.k333_dgrad_nc8:
+        # 3x3x3 layers: (sample, frame) images, frame t summing its (dY frame, time tap) pairs; reflect: spatially padded target + fold
+        gy_b = _as(gy, BF16)
+        kdt = BF16 if out_dtype == BF16 else torch.float32
+        A = _packed(w, frozen_w, ("dgrad-bf16-k333",), lambda: _pack_bf16_k333(w, Cin, Cout, dgrad=True))
+        gx = torch.empty(xshape, device=dev, dtype=kdt)
+        tgt = torch.empty((N, Cin, Ti_, Hi_ + 2, Wi_ + 2), device=dev, dtype=kdt) if pl.reflect else gx
+        tag = ("dgrad", Cin, Cout * 27, int(N * Ti_ * Hi_ * Wi_), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+
+        def run_k333d():
+            gyn = _to_nc8(gy_b, keep)
+            return L.c2m_conv3d_dgrad_nc8(_p(A), _p(gyn), _p(tgt), _p(pl.k333_ptab), Cin, Cout, N, Ti_, Hi_, Wi_, int(pl.reflect),
+                                          _dt(tgt), _stream())
+        _lib.check(_timed("igemm_bf16", pl.dgrad_flops, run_k333d, tag, 2 * (gy.numel() + xnumel) + 4 * w.numel()), "conv3d_dgrad_nc8")
+        if pl.reflect:
+            _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti_, Hi_, Wi_, 0, 1, 1, _dt(tgt), _stream()), "reflect fold (3-D, spatial)")
     elif pl.bf16 and pl.s2_dgrad_nc8:
         # 4x4 stride-2 layers: all four output parity classes in one launch on the NC8 form of dY (conv_nc8.hip)
         gy_b = _as(gy, BF16)
@@ -1097,6 +1160,23 @@ class _ConvFn(torch.autograd.Function):
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
             return y
+        if pl.bf16 and pl.k333_nc8:
+            x = _as(x, BF16)
+            A = _packed(w, ctx.frozen_w, ("fwd-bf16-k333",), lambda: _pack_bf16_k333(w, Cout, Cin))
+            y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
+            Ti_, Hi_, Wi_ = pl.dims[3:6]
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            ctx.nc8_keep = {} if (pl.k333_wgrad_nc8 and ctx.needs_input_grad[1]) else None
+
+            def run_k333():
+                xn = _to_nc8(x, ctx.nc8_keep)
+                return L.c2m_conv3d_nc8(_p(A), _p(xn), _p(y), _p(b), Cout, Cin, N, Ti_, Hi_, Wi_, int(pl.reflect), 1, ACT[act], slope,
+                                        _stream())
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_k333, tag,
+                              2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv3d_nc8 fwd")
+            ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
+            ctx.save_for_backward(x, w, y if ACT[act] else None)
+            return y
         if pl.bf16 and pl.s2_nc8:
             x = _as(x, BF16)
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-s2",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 16, 2))
@@ -1168,8 +1248,8 @@ class _ConvFn(torch.autograd.Function):
         side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
         # NC8 form of dY: one layout pass shared by the data gradient and the weight gradient of this node (made on the main
         # stream BEFORE a fork, so the side stream's launch is ordered behind it)
-        keep = {} if (pl.bf16 and pl.nc8) else None
-        if keep is not None and need_w and (pl.wgrad_nc8 or pl.s2_wgrad_nc8):
+        keep = {} if (pl.bf16 and (pl.nc8 or pl.k333_wgrad_nc8 or pl.k333_dgrad_nc8)) else None
+        if keep is not None and need_w and (pl.wgrad_nc8 or pl.s2_wgrad_nc8 or pl.k333_wgrad_nc8):
             gy = _as(gy, BF16)
             _to_nc8(gy, keep)
         if side is not None:
@@ -1197,6 +1277,19 @@ class _ConvFn(torch.autograd.Function):
         if not pl.bf16:
             gy = _as(gy, torch.float32)
         want = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if want and pl.bf16 and pl.k333_wgrad_nc8:
+            Ti, Hi, Wi = pl.dims[3:6]
+            gyn = _to_nc8(_as(gy, BF16), keep)
+            xn = next(iter(ctx.nc8_keep.values()))[1] if ctx.nc8_keep else _to_nc8(_as(x, BF16))
+            slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N * Ti, Hi, Wi, 0), device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+                              lambda: L.c2m_conv_wgrad3d_nc8(_p(gyn), _p(xn), _p(slab), _p(gw), _p(gb_t), Cout, Cin, N, Ti, Hi, Wi,
+                                                             int(pl.reflect), _stream()), tag,
+                              2 * (gyn.numel() + xn.numel()) + 4 * w.numel()), "conv_wgrad3d_nc8")
+            return gw, (gb_t if ctx.has_bias else None)
         if want and pl.bf16 and (pl.wgrad_nc8 or pl.s2_wgrad_nc8):
             # both operands in NC8 form: X from the forward launch (ctx.nc8_keep) or converted now, dY shared with the data gradient
             s2 = int(pl.s2_wgrad_nc8)

@@ -111,6 +111,21 @@ int c2m_conv_s2_nc8(const void* A, const void* X_nc8, void* Y, const float* bias
  * 4 (reflect)}; T = dX [N][M][2Ho][2Wo] (zeros) or the padded gradient [N][M][2Ho+2][2Wo+2] (reflect; c2m_reflect_fold finishes). */
 int c2m_conv_s2_dgrad_nc8(const void* A, const void* dY_nc8, void* T, int M, int K, long N, int Ho, int Wo, int reflect, int th,
                           void* stream);
+/* 3x3x3 stride-1 pad-1 layers (same_block.py:50-68; motion_autoencoder.py:107-149 fuse_convs / final_fuse) on the same patch
+ * kernel: the chunk index runs over (time tap, 16 channels), the workgroup's image is a (sample, frame) pair and the input frame of a
+ * chunk is t + kt - 1 (reflected / zero).  X NC8 = [N][ceil(C/8)][T][H][W][8] (c2m_nchw_to_nc8 with HW = T*H*W); A = three
+ * c2m_pack_weights_bf16_patch images back to back (kt = 0, 1, 2: w + 9 kt, s_m = 27 C, s_c = 27); Y contiguous [N][M][T][H][W].
+ * c2m_conv_wgrad3d_nc8: its weight gradient, one transposed-read launch per time tap (slab: c2m_conv_wgrad_nc8_slab_floats with N*T). */
+int c2m_conv3d_nc8(const void* A, const void* X_nc8, void* Y, const float* bias, int M, int C, long N, int T, int H, int W, int reflect,
+                   int yh, int act, float slope, void* stream);
+/* Its data gradient: launched over the T real frames, frame t summing its (dY frame, time tap) pairs from the device table ptab
+ * (int32 [T][11] = {npairs, (frame, kt) x 5}: reflect -- the pad frames folded onto the frames they mirror; zeros -- the in-range
+ * pairs); target [N][M][T][H+2][W+2] (reflect: spatially padded gradient, c2m_reflect_fold(pt 0, ph 1, pw 1) finishes) or
+ * [N][M][T][H][W] (zeros).  A: three pack images with rows = input channels (kt: w + 9 kt, s_m = 27, s_c = 27 M).             */
+int c2m_conv3d_dgrad_nc8(const void* A, const void* dY_nc8, void* target, const int* ptab, int M, int K, long N, int T, int H, int W,
+                         int reflect, int th, void* stream);
+int c2m_conv_wgrad3d_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int T, int H,
+                         int W, int reflect, void* stream);
 /* Weight (+ bias) gradient from NC8 operands: s2 = 0: 2-D 3x3 stride-1 pad-1 layer, dW[m][c][ky][kx] = sum dY[n][m][y][x] *
  * X[n][c][y+ky-1][x+kx-1]; s2 = 1: 4x4 stride-2 pad-1 layer, ... * X[n][c][2y+ky-1][2x+kx-1] (X is the [2H][2W] map; one workgroup per
  * input-row parity, 8 taps each).  zeros or reflect padding; fragments by ds_read_b64_tr_b16 out of plain NC8 images in LDS; slab holds

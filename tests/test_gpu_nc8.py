@@ -177,3 +177,31 @@ def test_nc8_kernels_never_read_past_their_inputs():
     rel_close(y.float(), yr, 4e-3, "forward")
     rel_close(xg.grad.float(), xr.grad, 4e-3, "data gradient (bf16 result)")
     rel_close(w.grad, wr.grad, 1e-4, "weight gradient")
+
+
+K333_CASES = [(1, 32, 3, 16, 64, 64, "reflect"), (2, 40, 5, 24, 32, 72, "zeros"), (1, 16, 2, 8, 96, 24, "reflect")]
+
+
+@pytest.mark.parametrize("case", K333_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_k333_forward_and_weight_gradient_on_nc8(case):
+    """3x3x3 stride-1 pad-1 layers: forward as (sample, frame) images with (time tap, channel) chunks, weight gradient as one
+    transposed-read launch per time tap; reflect (all three dimensions) and zeros."""
+    N, Cin, T, H, W, Cout, mode = case
+    x, w = _bf(rnd(61, N, Cin, T, H, W)), _bf(rnd(62, Cout, Cin, 3, 3, 3, scale=(1.0 / (Cin * 27)) ** 0.5))
+    b = rnd(63, Cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    xp = F.pad(xr, (1,) * 6, mode="reflect") if mode == "reflect" else F.pad(xr, (1,) * 6)
+    yr = F.conv3d(xp, wr, br)
+    go = _bf(rnd(64, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    pl = ops._plan(xg.bfloat16(), wg, (1, 1, 1), (1, 1, 1), mode == "reflect")
+    assert pl.k333_nc8 == (Cout > 4) and pl.k333_wgrad_nc8 == (Cout >= 64 and Cin >= 16), "routing of the 3x3x3 layer"
+    assert pl.k333_dgrad_nc8 == (Cout != 24), "data gradient of the 3x3x3 layer on the pair-table form of the NC8 kernel"
+    y = ops.conv(xg, wg, bg, stride=1, padding=1, padding_mode=mode)
+    (y * go.to(DEV)).sum().backward()
+    assert y.dtype == torch.bfloat16 and y.shape == yr.shape
+    rel_close(y.float(), yr, 4e-3, "3x3x3 NC8 forward")
+    rel_close(wg.grad, wr.grad, 1e-4, "3x3x3 weight gradient")
+    rel_close(bg.grad, br.grad, 1e-4, "bias gradient")
+    rel_close(xg.grad, xr.grad, 5e-5, "data gradient")
