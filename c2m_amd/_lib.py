@@ -17,7 +17,7 @@ _SIGS = {
     "c2m_conv_patch_nc8": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),
     "c2m_conv_s2_nc8": (c_int, [c_void_p] * 4 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "c2m_conv3d_nc8": (c_int, [c_void_p] * 4 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "c2m_conv3d_dgrad_nc8": (c_int, [c_void_p] * 4 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "c2m_conv3d_dgrad_nc8": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "c2m_conv_wgrad3d_nc8": (c_int, [c_void_p] * 5 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "c2m_conv_s2_dgrad_nc8": (c_int, [c_void_p] * 3 + [c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "c2m_pack_weights_bf16_s2_bytes": (c_long, [c_int, c_int]),

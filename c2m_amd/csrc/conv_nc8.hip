@@ -529,14 +529,15 @@ C2M_API int c2m_conv3d_nc8(const void* A, const void* X, void* Y, const float* b
 // Data gradient of such a layer with REFLECT padding: dY NC8 [N][ceil(K/8)][T][H][W][8] -> the spatially padded gradient
 // T_ [N][M][T][H+2][W+2] (bf16 / fp32), launched over the T real frames: frame t sums its (dY frame, time tap) pairs from `ptab`
 // (device int32 [T][11]: {npairs, (frame, kt) x 5}; the pad frames folded onto the frames they mirror), taps rotated in the plane
-// (patch origin -2, tap order 2,1,0).  A = three pack images (kt: w + 9 kt, rows = input channels: s_m = 27, s_c = 27 M).
+// (patch origin -2, tap order 2,1,0).  A = three pack images (kt: w + 9 kt, rows = the first M input channels: s_m = 27, s_c = 27 Ctot;
+// the target has Ctot >= M channels -- a concatenated input whose tail carries no gradient).
 // c2m_reflect_fold(pt = 0, ph = pw = 1) finishes.  Zero padding: the table lists the in-range (t + 1 - kt, kt) pairs, target
 // [N][M][T][H][W] (no fold).
-C2M_API int c2m_conv3d_dgrad_nc8(const void* A, const void* dY, void* Tgt, const int* ptab, int M, int K, long N, int T, int H, int W,
-                                 int reflect, int th, void* stream) {
+C2M_API int c2m_conv3d_dgrad_nc8(const void* A, const void* dY, void* Tgt, const int* ptab, int M, int Ctot, int K, long N, int T, int H,
+                                 int W, int reflect, int th, void* stream) {
     C2M_ENTER();
     if (M <= 0 || K <= 0 || N <= 0 || T <= 0) return 0;
-    if ((((uintptr_t)A | (uintptr_t)dY | (uintptr_t)Tgt) & 15) || !ptab) return (int)hipErrorInvalidValue;
+    if ((((uintptr_t)A | (uintptr_t)dY | (uintptr_t)Tgt) & 15) || !ptab || Ctot < M) return (int)hipErrorInvalidValue;
     Nc8P p;
     memset(&p, 0, sizeof(p));
     const int pad = reflect ? 1 : 0;
@@ -547,9 +548,9 @@ C2M_API int c2m_conv3d_dgrad_nc8(const void* A, const void* dY, void* Tgt, const
     p.nch2d = c2m_cdiv(K, 16); p.nchunks = 3 * p.nch2d; p.T = T; p.treflect = 0;
     p.ptab = ptab; p.t0 = 0;                               // (zeros padding: the table holds the in-range (t + 1 - kt, kt) pairs)
     const long xb = N * p.CB * (long)T * H * W * 16, ab = (long)p.nchunks * 9 * p.Mpad * 32;
-    if (xb >= 0x80000000LL || ab >= 0x80000000LL || N * (long)M * T * p.Ho * p.Wo * 4 >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    if (xb >= 0x80000000LL || ab >= 0x80000000LL || N * (long)Ctot * T * p.Ho * p.Wo * 4 >= 0x80000000LL) return (int)hipErrorInvalidValue;
     p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
-    p.out_sn = (long)M * T * p.Ho * p.Wo; p.out_sc = (long)T * p.Ho * p.Wo; p.out_st = (long)p.Ho * p.Wo; p.out_sh = p.Wo; p.out_off = 0;
+    p.out_sn = (long)Ctot * T * p.Ho * p.Wo; p.out_sc = (long)T * p.Ho * p.Wo; p.out_st = (long)p.Ho * p.Wo; p.out_sh = p.Wo; p.out_off = 0;
     p.reflect = 0; p.act = 0; p.slope = 0.f; p.yh = th;
     p.iy0 = -1 - pad; p.ix0 = -1 - pad;
     for (int i = 0; i < 3; ++i) { p.pty[i] = 2 - i; p.ptx[i] = 2 - i; }

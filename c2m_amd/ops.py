@@ -363,7 +363,7 @@ def _time_pair_table_kt(T, reflect):
     return tab
 
 
-def _pack_bf16_k333(w, M, C, dgrad=False):
+def _pack_bf16_k333(w, M, C, dgrad=False, cin_total=None):
     """Weights [Cout][Cin][3][3][3] of a 3x3x3 layer -> three c2m_pack_weights_bf16_patch images back to back (time tap kt = 0, 1, 2);
     rows M = output channels, reduction C = input channels -- or, for the data gradient, rows = input channels over output channels."""
     L = _lib.lib()
@@ -371,7 +371,7 @@ def _pack_bf16_k333(w, M, C, dgrad=False):
     out = torch.empty(3 * nb, device=w.device, dtype=torch.uint8)
     wf = w.reshape(-1)
     for kt in range(3):
-        g = np.array([M, C, 27, M * 27, 0] if dgrad else [M, C, C * 27, 27, 0], dtype=np.int64)
+        g = np.array([M, C, 27, (cin_total or M) * 27, 0] if dgrad else [M, C, C * 27, 27, 0], dtype=np.int64)
         _lib.check(L.c2m_pack_weights_bf16_patch(_p(wf[kt * 9:]), _p(out[kt * nb:]), _gp(g), _stream()), "pack_weights_bf16_patch (3-D)")
     return out
 
@@ -630,13 +630,14 @@ class _ConvPlan:
         # channel-blocked input (conv_nc8.hip): 2-D bf16 patch layers whose planes are whole 8-pixel groups
         self.nc8 = bool(bf16 and _NC8 and nd == 2 and (Hi * Wi) % 8 == 0 and (Ho * Wo) % 8 == 0)
         # ... the 3x3x3 stride-1 pad-1 layers as (sample, frame) images with (time tap, channel) chunks: forward and weight gradient
+        # (channel padding up to 45 %: final_fuse has 34 input channels = three 16-channel chunks, still 2x the gather kernel)
         k333 = bool(bf16 and _NC8 and _NC8_3D and nd == 3 and (kt, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and
-                    (pt, ph, pw) == (1, 1, 1) and (Hi * Wi) % 8 == 0 and Ti >= 2 and Cin >= 12 and _ceil(Cin, 16) <= 1.25 * Cin and
+                    (pt, ph, pw) == (1, 1, 1) and (Hi * Wi) % 8 == 0 and Ti >= 2 and Cin >= 12 and _ceil(Cin, 16) <= 1.45 * Cin and
                     Wo >= 32 and Ho >= 8 and (_ceil(Wo, 32) * _ceil(Ho, 8)) <= _NC8_FILL * Wo * Ho)
         self.k333_nc8 = k333 and Cout > 4
         self.k333_wgrad_nc8 = k333 and _NC8_WGRAD and Cout >= 64 and Cin >= 16
         pd = 1 if reflect else 0
-        self.k333_dgrad_nc8 = bool(k333 and dM == Cin and Cout >= 12 and _ceil(Cout, 16) <= 1.25 * Cout and Cin > 4 and
+        self.k333_dgrad_nc8 = bool(k333 and Cout >= 12 and _ceil(Cout, 16) <= 1.25 * Cout and dM > 4 and
                                    (_ceil(Wi + 2 * pd, 32) * _ceil(Hi + 2 * pd, 8)) <= _NC8_FILL * (Wi + 2 * pd) * (Hi + 2 * pd))
         if self.k333_dgrad_nc8:
             self.k333_ptab = torch.from_numpy(_time_pair_table_kt(Ti, bool(reflect)).reshape(-1)).to(device)
@@ -1021,18 +1022,21 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
         # 3x3x3 layers: (sample, frame) images, frame t summing its (dY frame, time tap) pairs; reflect: spatially padded target + fold
         gy_b = _as(gy, BF16)
         kdt = BF16 if out_dtype == BF16 else torch.float32
-        A = _packed(w, frozen_w, ("dgrad-bf16-k333",), lambda: _pack_bf16_k333(w, Cin, Cout, dgrad=True))
+        dM = pl.dM
+        A = _packed(w, frozen_w, ("dgrad-bf16-k333", dM), lambda: _pack_bf16_k333(w, dM, Cout, dgrad=True, cin_total=Cin))
         gx = torch.empty(xshape, device=dev, dtype=kdt)
         tgt = torch.empty((N, Cin, Ti_, Hi_ + 2, Wi_ + 2), device=dev, dtype=kdt) if pl.reflect else gx
         tag = ("dgrad", Cin, Cout * 27, int(N * Ti_ * Hi_ * Wi_), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
 
         def run_k333d():
             gyn = _to_nc8(gy_b, keep)
-            return L.c2m_conv3d_dgrad_nc8(_p(A), _p(gyn), _p(tgt), _p(pl.k333_ptab), Cin, Cout, N, Ti_, Hi_, Wi_, int(pl.reflect),
+            return L.c2m_conv3d_dgrad_nc8(_p(A), _p(gyn), _p(tgt), _p(pl.k333_ptab), dM, Cin, Cout, N, Ti_, Hi_, Wi_, int(pl.reflect),
                                           _dt(tgt), _stream())
         _lib.check(_timed("igemm_bf16", pl.dgrad_flops, run_k333d, tag, 2 * (gy.numel() + xnumel) + 4 * w.numel()), "conv3d_dgrad_nc8")
         if pl.reflect:
             _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, Ti_, Hi_, Wi_, 0, 1, 1, _dt(tgt), _stream()), "reflect fold (3-D, spatial)")
+        if dM < Cin:
+            gx[:, dM:].zero_()               # channels declared gradient-free by the caller (dgrad_channels); their planes of tgt were never written
     elif pl.bf16 and pl.s2_dgrad_nc8:
         # 4x4 stride-2 layers: all four output parity classes in one launch on the NC8 form of dY (conv_nc8.hip)
         gy_b = _as(gy, BF16)

@@ -121,9 +121,10 @@ int c2m_conv3d_nc8(const void* A, const void* X_nc8, void* Y, const float* bias,
 /* Its data gradient: launched over the T real frames, frame t summing its (dY frame, time tap) pairs from the device table ptab
  * (int32 [T][11] = {npairs, (frame, kt) x 5}: reflect -- the pad frames folded onto the frames they mirror; zeros -- the in-range
  * pairs); target [N][M][T][H+2][W+2] (reflect: spatially padded gradient, c2m_reflect_fold(pt 0, ph 1, pw 1) finishes) or
- * [N][M][T][H][W] (zeros).  A: three pack images with rows = input channels (kt: w + 9 kt, s_m = 27, s_c = 27 M).             */
-int c2m_conv3d_dgrad_nc8(const void* A, const void* dY_nc8, void* target, const int* ptab, int M, int K, long N, int T, int H, int W,
-                         int reflect, int th, void* stream);
+ * [N][M][T][H][W] (zeros); the target may have Ctot >= M channels (M = the leading input channels that need a gradient).  A: three
+ * pack images with rows = input channels (kt: w + 9 kt, s_m = 27, s_c = 27 Ctot).                                                */
+int c2m_conv3d_dgrad_nc8(const void* A, const void* dY_nc8, void* target, const int* ptab, int M, int Ctot, int K, long N, int T, int H,
+                         int W, int reflect, int th, void* stream);
 int c2m_conv_wgrad3d_nc8(const void* dY_nc8, const void* X_nc8, float* slab, float* dW, float* db, int M, int C, long N, int T, int H,
                          int W, int reflect, void* stream);
 /* Weight (+ bias) gradient from NC8 operands: s2 = 0: 2-D 3x3 stride-1 pad-1 layer, dW[m][c][ky][kx] = sum dY[n][m][y][x] *

@@ -205,3 +205,23 @@ def test_k333_forward_and_weight_gradient_on_nc8(case):
     rel_close(wg.grad, wr.grad, 1e-4, "3x3x3 weight gradient")
     rel_close(bg.grad, br.grad, 1e-4, "bias gradient")
     rel_close(xg.grad, xr.grad, 5e-5, "data gradient")
+
+
+def test_k333_final_fuse_shape_with_gradient_free_tail():
+    """final_fuse (motion_autoencoder.py:131-141): 34 -> 32 channels, the last two input channels (the rastered sparse motion) carry
+    no gradient (dgrad_channels = 32): three 16-channel chunks with 14 padded channels, data gradient for the leading 32 rows only."""
+    N, Cin, T, H, W, Cout = 1, 34, 3, 16, 64, 32
+    x, w = _bf(rnd(71, N, Cin, T, H, W)), _bf(rnd(72, Cout, Cin, 3, 3, 3, scale=(1.0 / (Cin * 27)) ** 0.5))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(F.pad(xr, (1,) * 6, mode="reflect"), wr)
+    go = _bf(rnd(74, *yr.shape))
+    (yr * go).sum().backward()
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    pl = ops._plan(xg.bfloat16(), wg, (1, 1, 1), (1, 1, 1), True, 32)
+    assert pl.k333_nc8 and pl.k333_dgrad_nc8 and pl.dM == 32 and not pl.k333_wgrad_nc8
+    y = ops.conv(xg, wg, None, stride=1, padding=1, padding_mode="reflect", dgrad_channels=32)
+    (y * go.to(DEV)).sum().backward()
+    rel_close(y.float(), yr, 4e-3, "final_fuse forward")
+    rel_close(xg.grad[:, :32], xr.grad[:, :32], 5e-5, "data gradient of the leading 32 channels")
+    assert float(xg.grad[:, 32:].abs().max()) == 0.0
+    rel_close(wg.grad, wr.grad, 1e-4, "weight gradient")
