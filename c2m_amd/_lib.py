@@ -59,8 +59,8 @@ _SIGS = {
     "c2m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_double] * 5 + [c_void_p]),
     "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),
     "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_int, c_void_p]),
-    "c2m_norm_apply": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
-    "c2m_norm_bwd": (c_int, [c_void_p] * 12 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "c2m_norm_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "c2m_norm_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_int, c_void_p]),
     "c2m_resample2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "c2m_channelnorm_fwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),

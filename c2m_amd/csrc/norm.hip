@@ -240,17 +240,99 @@ __global__ __launch_bounds__(256) void norm_apply_vec_kernel(const ApplyP<T> p, 
     }
 }
 
+// ------------------------------------------------------------------------------------------- NC8 side output (round 4)
+// bf16 data path: the normalised activation feeds a channel-blocked convolution (conv_nc8.hip), so the apply pass writes it in BOTH
+// layouts at once -- NCHW for everybody else, NC8 ([N][C/8][S][8], the 8 channels of a pixel in one 16-byte unit) for that conv --
+// instead of a separate c2m_nchw_to_nc8 pass over the tensor (one read of it less; the layout passes were 3.3 / 5.9 ms of a
+// configs[3] / configs[2] step).  A thread owns 8 consecutive pixels of 8 consecutive channels: eight 16-byte loads, the per-channel
+// arithmetic of norm_apply_vec_kernel, eight 16-byte NCHW stores, an 8x8 transpose of bf16 pairs in registers (v_perm_b32), eight
+// 16-byte NC8 stores (128 contiguous bytes).  Same values bit for bit in both outputs.
+__device__ __forceinline__ void nc8_transpose_store(const unsigned (&r)[8][4], uint4* __restrict__ dst) {
+#pragma unroll
+    for (int px = 0; px < 8; ++px) {
+        const int q = px >> 1;
+        const unsigned sel = (px & 1) ? 0x07060302u : 0x05040100u;
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(r[1][q], r[0][q], sel);
+        o.y = __builtin_amdgcn_perm(r[3][q], r[2][q], sel);
+        o.z = __builtin_amdgcn_perm(r[5][q], r[4][q], sel);
+        o.w = __builtin_amdgcn_perm(r[7][q], r[6][q], sel);
+        dst[px] = o;
+    }
+}
+__device__ __forceinline__ void nc8_unpack8(const uint4 v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned nc8_pack2(float a, float b) {
+    typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t q = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, q);
+}
+
+__global__ __launch_bounds__(256) void norm_apply_nc8_kernel(const ApplyP<bf16_t> p, uint4* __restrict__ yn, int CB, long S8, long total) {
+    const uint4* __restrict__ x4 = reinterpret_cast<const uint4*>(p.x);
+    const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(p.gb);
+    uint4* __restrict__ y4 = reinterpret_cast<uint4*>(p.y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i % S8, ncb = i / S8;
+        const int cb = (int)(ncb % CB), n = (int)(ncb / CB);
+        unsigned r[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb * 8 + j;
+            r[j][0] = r[j][1] = r[j][2] = r[j][3] = 0u;
+            if (c < p.C) {
+                const long plane = (long)n * p.C + c;
+                const int st = p.mode == 0 ? (int)plane : c;
+                const float mean = p.mean[st], invstd = p.invstd[st];
+                float xv[8], sc[8], sh[8], o[8];
+                nc8_unpack8(x4[plane * S8 + g], xv);
+                if (p.gb) {
+                    const long gpl = ((long)n * 2 * p.C + c) * S8 + g;
+                    nc8_unpack8(g4[gpl], sc);
+                    nc8_unpack8(g4[gpl + (long)p.C * S8], sh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sc[e] = 1.0f + sc[e];
+                } else {
+                    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sc[e] = ga; sh[e] = be; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = c2m_act((xv[e] - mean) * invstd * sc[e] + sh[e], p.act, p.slope);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[j][e] = nc8_pack2(o[2 * e], o[2 * e + 1]);
+                y4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);
+            }
+        }
+        nc8_transpose_store(r, yn + (((long)n * CB + cb) * S8 + g) * 8);
+    }
+}
+
 static inline bool norm_vec_ok(long S, const void* a, const void* b, const void* c, const void* d, int dt) {
     return S >= 1024 && (S & 3) == 0 &&
            ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & (dt == C2M_BF16 ? 7 : 15)) == 0;
 }
 
+// y_nc8 (optional, bf16 tensors with S % 8 == 0 only): the same result in the channel-blocked layout of conv_nc8.hip as well.
 C2M_API int c2m_norm_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
-                           const float* beta, const void* gb, void* y, int N, int C, long S, int mode, int act,
+                           const float* beta, const void* gb, void* y, void* y_nc8, int N, int C, long S, int mode, int act,
                            float slope, int dt, void* stream) {
     C2M_ENTER();
     const long total = (long)N * C * S;
     if (total <= 0) return 0;
+    if (y_nc8) {
+        if (dt != C2M_BF16 || (S & 7) || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gb) | ((uintptr_t)y_nc8)) & 15))
+            return (int)hipErrorInvalidValue;
+        ApplyP<bf16_t> p{(const bf16_t*)x, mean, invstd, gamma, beta, (const bf16_t*)gb, (bf16_t*)y, N, C, S, mode, act, slope};
+        const int CB = (C + 7) / 8;
+        const long n8 = (long)N * CB * (S / 8);
+        hipLaunchKernelGGL(norm_apply_nc8_kernel, dim3(c2m_grid(n8, 256)), dim3(256), 0, (hipStream_t)stream, p, (uint4*)y_nc8, CB, S / 8, n8);
+        return (int)hipGetLastError();
+    }
     const bool vec = norm_vec_ok(S, x, y, gb, nullptr, dt);
     C2M_DISPATCH_DT(dt,
         ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, (const T*)gb, (T*)y, N, C, S, mode, act, slope};
@@ -492,9 +574,57 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_vec_kernel(const BwdP<T> p
     }
 }
 
+// dx of the norm in both layouts (see norm_apply_nc8_kernel): the gradient it hands back is the dY of the convolution in front.
+__global__ __launch_bounds__(256) void norm_bwd_apply_nc8_kernel(const BwdP<bf16_t> p, uint4* __restrict__ dxn, int CB, long S8, long total) {
+    const uint4* __restrict__ x4 = reinterpret_cast<const uint4*>(p.x);
+    const uint4* __restrict__ gy4 = reinterpret_cast<const uint4*>(p.gy);
+    const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(p.gb);
+    uint4* __restrict__ d4 = reinterpret_cast<uint4*>(p.dx);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i % S8, ncb = i / S8;
+        const int cb = (int)(ncb % CB), n = (int)(ncb / CB);
+        unsigned r[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb * 8 + j;
+            r[j][0] = r[j][1] = r[j][2] = r[j][3] = 0u;
+            if (c < p.C) {
+                const long plane = (long)n * p.C + c;
+                const int st = p.mode == 0 ? (int)plane : c;
+                const float mean = p.mean[st], invstd = p.invstd[st], c1 = p.coef[st * 2 + 0], c2 = p.coef[st * 2 + 1];
+                float xv[8], gv[8], sc[8], sh[8], o[8];
+                nc8_unpack8(x4[plane * S8 + g], xv);
+                nc8_unpack8(gy4[plane * S8 + g], gv);
+                if (p.gb) {
+                    const long gpl = ((long)n * 2 * p.C + c) * S8 + g;
+                    nc8_unpack8(g4[gpl], sc);
+                    nc8_unpack8(g4[gpl + (long)p.C * S8], sh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sc[e] = 1.0f + sc[e];
+                } else {
+                    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sc[e] = ga; sh[e] = be; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mean) * invstd;
+                    const float gg = gv[e] * act_grad(xh * sc[e] + sh[e], p.act, p.slope);
+                    o[e] = invstd * (gg * sc[e] - c1 - xh * c2);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[j][e] = nc8_pack2(o[2 * e], o[2 * e + 1]);
+                d4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);
+            }
+        }
+        nc8_transpose_store(r, dxn + (((long)n * CB + cb) * S8 + g) * 8);
+    }
+}
+
 // workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
+// dx_nc8 (optional, bf16 tensors with S % 8 == 0 only): dx in the channel-blocked layout as well (see c2m_norm_apply).
 C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
-                         const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx,
+                         const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx, void* dx_nc8,
                          float* workspace, int N, int C, long S, int mode, int act, float slope, int dt, void* stream) {
     C2M_ENTER();
     const long total = (long)N * C * S;
@@ -516,10 +646,24 @@ C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const
             hipLaunchKernelGGL(norm_bwd_finalize_wave_kernel<T>, dim3(c2m_cdiv(C, 4)), dim3(256), 0, s, p);
         else
             hipLaunchKernelGGL(norm_bwd_finalize_kernel<T>, dim3(c2m_cdiv(nthreads, 128)), dim3(128), 0, s, p);
-        if (vec)
+        if (dx_nc8) { }
+        else if (vec)
             hipLaunchKernelGGL(norm_bwd_apply_vec_kernel<T>, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
         else
             hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(c2m_grid(total, 256)), dim3(256), 0, s, p););
+    if (dx_nc8) {
+        if (dt != C2M_BF16 || (S & 7) || ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gb) | ((uintptr_t)dx) | ((uintptr_t)dx_nc8)) & 15))
+            return (int)hipErrorInvalidValue;
+        BwdP<bf16_t> p;
+        p.x = (const bf16_t*)x; p.gy = (const bf16_t*)gy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+        p.gb = (const bf16_t*)gb; p.ggb = (bf16_t*)ggb; p.chunks = norm_chunks(S);
+        p.partial = workspace; p.coef = workspace + (long)N * C * p.chunks * 2;
+        p.dgamma = dgamma; p.dbeta = dbeta; p.dx = (bf16_t*)dx;
+        p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
+        const int CB = (C + 7) / 8;
+        const long n8 = (long)N * CB * (S / 8);
+        hipLaunchKernelGGL(norm_bwd_apply_nc8_kernel, dim3(c2m_grid(n8, 256)), dim3(256), 0, s, p, (uint4*)dx_nc8, CB, S / 8, n8);
+    }
     return (int)hipGetLastError();
 }
 

@@ -278,6 +278,10 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
 
 
 _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / buffering variant of conv_patch_nc8_kernel (0 = the library's rule)
+# norm kernels write the NC8 side output for the conv behind / in front.  OFF by default: measured on one box (configs[3] / [2] graph
+# replays) it removes 77 of 174 layout passes (-0.95 ms) but the 8-channel x 8-pixel apply kernels run 2x as long as the per-plane
+# ones they replace (+1.2 ms): 47.7 vs 47.05 ms, 71.5 vs 70.7 ms.  Kept as an A/B knob with its tests (tests/test_gpu_nc8.py).
+_NC8_NORM = os.environ.get("C2M_NC8_NORM", "0") != "0"
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
 _NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
@@ -1534,42 +1538,59 @@ class _NormActFn(torch.autograd.Function):
         _lib.check(L.c2m_norm_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), N, C, S, mode,
                                     eps, momentum, dt, _stream()), "norm_stats")
         y = torch.empty_like(x)
-        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(y), N, C, S, mode,
+        # bf16 data path: activations of conv-sized maps are ALSO written in the NC8 layout of the convolution they feed (and, in
+        # backward, the gradient they hand to the convolution in front): conv_nc8.hip then needs no layout pass of its own
+        ctx.nc8 = bool(_NC8 and _NC8_NORM and dt == 1 and x.dim() == 4 and S % 8 == 0 and C >= 16 and x.shape[3] >= 16 and S >= 512)
+        yn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if ctx.nc8 else None
+        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(y), _p(yn), N, C, S, mode,
                                     ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
         ctx.cfg = (N, C, S, mode, act)
         ctx.save_for_backward(x, gamma, beta, gb, mean, invstd)
-        return y
+        if yn is None:
+            return y, None
+        ctx.mark_non_differentiable(yn)
+        return y, yn
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gyn=None):
         x, gamma, beta, gb, mean, invstd = ctx.saved_tensors
         N, C, S, mode, act = ctx.cfg
         L = _lib.lib()
         gy = _as(gy, x.dtype)
         dx = torch.empty_like(x)
+        dxn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if ctx.nc8 else None
         ggb = torch.empty_like(gb) if gb is not None else None
         dgamma = torch.empty_like(gamma) if gamma is not None else None
         dbeta = torch.empty_like(beta) if gamma is not None else None
         ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
         _lib.check(L.c2m_norm_bwd(_p(x), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(ggb), _p(dgamma),
-                                  _p(dbeta), _p(dx), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _dt(x), _stream()),
+                                  _p(dbeta), _p(dx), _p(dxn), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _dt(x), _stream()),
                    "norm_bwd")
+        if dxn is not None:
+            dx._c2m_nc8 = (dx._version, dxn)      # autograd hands this very tensor object to the convolution's backward (see _to_nc8)
         if ggb is not None and ggb.dtype != ctx.gb_dtype:
             ggb = ggb.to(ctx.gb_dtype)
         return dx, dgamma, dbeta, ggb, None, None, None, None, None, None
 
 
+def _norm_act(*args):
+    y, yn = _NormActFn.apply(*args)
+    if yn is not None:
+        y._c2m_nc8 = (y._version, yn)             # the NC8 form travels with the tensor object (ops._to_nc8 picks it up)
+    return y
+
+
 def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1):
-    return _NormActFn.apply(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum)
+    return _norm_act(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum)
 
 
 def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5):
-    return _NormActFn.apply(x, gamma, beta, None, None, None, 0, act, eps, 0.1)
+    return _norm_act(x, gamma, beta, None, None, None, 0, act, eps, 0.1)
 
 
 def spade_norm_act(x, gamma_beta, act=None, eps=1e-5):
     """InstanceNorm(affine=False)(x) * (1 + gamma) + beta with [gamma, beta] = gamma_beta.chunk(2, 1), then act."""
-    return _NormActFn.apply(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1)
+    return _norm_act(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1)
 
 
 # =============================================================================================== warping / resampling
@@ -1860,6 +1881,6 @@ def norm_apply_eval(x, mean, invstd, gamma, beta, act=None):
     N, C = x.shape[0], x.shape[1]
     S = x.numel() // (N * C)
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().c2m_norm_apply(_p(x), _p(_f(mean)), _p(_f(invstd)), _p(gamma), _p(beta), None, _p(y), N, C, S, 1,
+    _lib.check(_lib.lib().c2m_norm_apply(_p(x), _p(_f(mean)), _p(_f(invstd)), _p(gamma), _p(beta), None, _p(y), None, N, C, S, 1,
                                          ACT[act], LRELU_SLOPE, _dt(x), _stream()), "norm_apply(eval)")
     return y

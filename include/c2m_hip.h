@@ -204,10 +204,13 @@ int c2m_reflect_fold(const void* dXpad, void* dX, long NC, int T, int H, int W, 
 long c2m_norm_workspace_floats(int N, int C, long S);
 int c2m_norm_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
                    float* workspace, int N, int C, long S, int mode, float eps, float momentum, int dt, void* stream);
+/* y_nc8 / dx_nc8 (optional; bf16 tensors with S % 8 == 0): the result ALSO in the channel-blocked layout [N][ceil(C/8)][S][8] the
+ * NC8 convolutions consume (c2m_nchw_to_nc8's), written by the same pass -- the activation feeds a convolution, the gradient is the
+ * dY of the convolution in front.                                                                                              */
 int c2m_norm_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                   const void* gb, void* y, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
+                   const void* gb, void* y, void* y_nc8, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
 int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
-                 const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx,
+                 const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx, void* dx_nc8,
                  float* workspace, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
 int c2m_act_bwd(const void* y, const void* gy, void* gx, long total, int act, float slope, int dt, void* stream);
 

@@ -225,3 +225,81 @@ def test_k333_final_fuse_shape_with_gradient_free_tail():
     rel_close(xg.grad[:, :32], xr.grad[:, :32], 5e-5, "data gradient of the leading 32 channels")
     assert float(xg.grad[:, 32:].abs().max()) == 0.0
     rel_close(wg.grad, wr.grad, 1e-4, "weight gradient")
+
+
+@pytest.mark.parametrize("kind", ["bn", "in", "spade"])
+def test_norm_kernels_write_the_nc8_side_output(kind):
+    """The norm apply / backward-apply passes of the bf16 data path also write their result in the NC8 layout (attribute on the
+    tensor, picked up by ops._to_nc8): bit-identical to the layout pass over the NCHW result, forward and backward."""
+    N, C, H, W = 3, 40, 16, 32
+    prev_on, ops._NC8_NORM = ops._NC8_NORM, True          # (off by default: see ops._NC8_NORM)
+    try:
+        _norm_side_output_case(kind, N, C, H, W)
+    finally:
+        ops._NC8_NORM = prev_on
+
+
+def _norm_side_output_case(kind, N, C, H, W):
+    x = rnd(81, N, C, H, W).to(DEV).bfloat16().requires_grad_(True)
+    gamma, beta = rnd(82, C).to(DEV).requires_grad_(True), rnd(83, C).to(DEV).requires_grad_(True)
+    gb = (rnd(84, N, 2 * C, H, W) * 0.3).to(DEV).bfloat16().requires_grad_(True)
+    if kind == "bn":
+        y = ops.batch_norm_act(x, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), act="lrelu")
+    elif kind == "in":
+        y = ops.instance_norm_act(x, gamma, beta, act="relu")
+    else:
+        y = ops.spade_norm_act(x, gb, act="lrelu")
+    side = getattr(y, "_c2m_nc8", None)
+    assert side is not None and side[0] == y._version
+    ref = y.detach().view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(side[1], ref), "forward side output"
+    assert ops._to_nc8(y) is side[1], "the conv picks the side output up instead of converting"
+    # the same values as the plain apply kernel
+    try:
+        ops._NC8_NORM = False
+        x2 = x.detach().clone().requires_grad_(True)
+        if kind == "bn":
+            y2 = ops.batch_norm_act(x2, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), act="lrelu")
+        elif kind == "in":
+            y2 = ops.instance_norm_act(x2, gamma, beta, act="relu")
+        else:
+            y2 = ops.spade_norm_act(x2, gb.detach(), act="lrelu")
+    finally:
+        ops._NC8_NORM = True
+    assert getattr(y2, "_c2m_nc8", None) is None
+    rel_close(y.float(), y2.float(), 8e-3, "NC8-writing apply vs the plain apply kernel (bf16 rounding of the same fp32 value)")
+    # backward: a consumer that records what it is handed
+    seen = {}
+
+    class Spy(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["g"] = g
+            return g
+
+    class Probe(torch.autograd.Function):          # stands where the convolution in front of the norm would stand
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["dx"], seen["side"] = g, getattr(g, "_c2m_nc8", None)
+            return g
+
+    x3 = x.detach().clone().requires_grad_(True)
+    h = Probe.apply(x3)
+    if kind == "bn":
+        y3 = ops.batch_norm_act(h, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), act="lrelu")
+    elif kind == "in":
+        y3 = ops.instance_norm_act(h, gamma, beta, act="relu")
+    else:
+        y3 = ops.spade_norm_act(h, gb, act="lrelu")
+    y3.backward(rnd(85, N, C, H, W).to(DEV).bfloat16())
+    assert seen["side"] is not None and seen["side"][0] == seen["dx"]._version
+    dref = seen["dx"].view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(seen["side"][1], dref), "backward side output = NC8 form of dx"
