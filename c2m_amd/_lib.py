@@ -37,6 +37,8 @@ _SIGS = {
     "c2m_pack_multi": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "c2m_pack_weights_bf16_patch_bytes": (c_long, [c_int, c_int]),
     "c2m_pack_weights_bf16_patch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "c2m_pack_weights_bf16_gather_bytes": (c_long, [c_void_p]),
+    "c2m_pack_weights_bf16_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "c2m_wino_upack_floats": (c_long, [c_int, c_int]),
     "c2m_wino_filter_transform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "c2m_conv_wino": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),

@@ -64,6 +64,11 @@ struct ConvP {
     long a_cls;                       // floats per class weight matrix
     long out_off_c[8];
     int po_c[8][3];
+    // NC8 gather kernel (conv_gather_nc8_kernel): X = [N][CB][Ti*Hi*Wi][8] bf16, A = c2m_pack_weights_bf16_gather image
+    // [class][tap][16-channel chunk][half][Mpad rows] 16-byte units, ktab = [class][ntaps] {dt, dy, dx, 1}
+    int g8_nch, g8_ntaps, g8_CB, g8_Mpad;
+    unsigned g8_a_bytes, g8_plane_bytes;      // bytes of ONE class image; bytes of one channel-block plane
+    int g8_dbg;                               // tuning only (geom[95] >> 8): 1 = no K loop, 2 = no stores
 };
 
 // spatial offset of one tap for this thread's pixel, or -1 when it falls in zero padding
@@ -505,6 +510,226 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NC8 gather (round 4)
+// The general bf16 forward / data-gradient kernel over CHANNEL-BLOCKED activations (conv_nc8.hip has the layout and the 3x3 /
+// 4x4-stride-2 / 3x3x3 patch forms): any tap set, stride, 2-D or 3-D, stride-parity classes, two-target reflect epilogue, split-K --
+// the geometry of conv_igemm_kernel -- for the layers the patch forms do not take ((3,4,4) / (4,4,4) stride-2 blocks, 7x7, 1x1,
+// small or ragged maps, the reflect data gradients of the stride-2 layers whose (W/2 + 1)-wide class planes waste half of a
+// 32-column tile).  A K-step is (tap, 16 channels); per K-step a wave fetches the two 16-byte units (channel blocks 2c, 2c + 1)
+// of ITS 64 pixels with two LDS-DMA instructions whose per-lane address is the pixel's tap offset, computed once per TAP (the
+// K loop runs tap-major: chunks inside) -- the NCHW gather kernel issued 16 two-byte loads, 8 packs and 2 ds_write_b128 per lane
+// for the same K-step and spent 105 VALU per 8 MFMAs on them.  Weights come pre-packed in bf16
+// ([tap][chunk][half][row]) by LDS-DMA as well.  Tile BM rows x 256 pixels, wave w owns pixels 64 w .. 64 w + 63 for all rows;
+// U K-steps per stage, NBUF stages, one barrier per stage with counted vmcnt (every wave issues NDMA instructions per stage;
+// steps past the split's end and channel blocks past the tensor's last go through zero-record descriptors).
+template <int BM, int U, int NBUF, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv_gather_nc8_kernel(const ConvP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int MI = BM / 32, NI = 2;
+    constexpr int A_ST = U * 2 * BM;                              // weight units per stage: [u][half][row]
+    constexpr int NAI = (A_ST + 255) / 256;
+    constexpr int A_PAD = NAI * 256;
+    constexpr int BUF = A_PAD + U * 512;                          // + [u][half][256 pixels]
+    constexpr int NDMA = NAI + 2 * U;
+    static_assert(64 % (2 * BM) == 0 || (2 * BM) % 64 == 0, "a 64-unit DMA row belongs to one K-step");
+    static_assert(NBUF * BUF * 16 * WGS <= 158 * 1024, "LDS");
+    __shared__ uint4 smem[NBUF * BUF];
+    __shared__ int4 s_taps[64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const C2mBlock blk = c2m_xcd_block((unsigned)(p.Npix + 255) / 256, (unsigned)(p.M + BM - 1) / BM, 1);
+    const int m0 = blk.y * BM, n0 = blk.x * 256;
+    const int cls = p.ncls > 1 ? (int)blk.z / p.splits : 0;
+    const int split = p.ncls > 1 ? (int)blk.z - cls * p.splits : (int)blk.z;
+    const int k_beg = split * p.ksteps_per_split;
+    int k_end = k_beg + p.ksteps_per_split; k_end = k_end < p.nk ? k_end : p.nk;
+    if (p.g8_dbg & 1) k_end = k_beg;
+    const int nch = p.g8_nch, ntaps = p.g8_ntaps;
+
+    if (tid < ntaps) s_taps[tid] = p.ktab[cls * ntaps + tid];
+
+    // ---- this lane's pixel (DMA side and MFMA column side agree: wave w holds pixels 64 w ..)
+    const int pix = n0 + wave * 64 + lane;
+    const bool pvalid = pix < p.Npix;
+    int pn, pt, py, px;
+    decompose_pix(pvalid ? pix : p.Npix - 1, p, pn, pt, py, px);
+    const int ots = pt * p.st, oys = py * p.sh, oxs = px * p.sw;
+    const int in_st = (int)p.in_st, in_sh = (int)p.in_sh;
+    const unsigned img_byte = (unsigned)pn * (unsigned)p.g8_CB * p.g8_plane_bytes;
+    auto tap_voff = [&](int tap) -> unsigned {
+        const int4 tp = s_taps[tap < ntaps ? tap : ntaps - 1];
+        int it = p.is3d ? ots + tp.x : 0, iy = oys + tp.y, ix = oxs + tp.z;
+        bool ok = pvalid;
+        if (p.reflect) {
+            if (p.is3d) { it = it < 0 ? -it : it; it = it >= p.Ti ? 2 * p.Ti - 2 - it : it; }
+            iy = iy < 0 ? -iy : iy; iy = iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix;
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (unsigned)it < (unsigned)p.Ti;
+        }
+        return ok ? img_byte + (unsigned)(it * in_st + iy * in_sh + ix) * 16u : C2M_OOB;
+    };
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) uint4*)&smem[0];
+    const unsigned long aaddr = (unsigned long)p.A + (unsigned long)cls * p.g8_a_bytes;
+    const u32x4 ars = {(unsigned)aaddr, (unsigned)(aaddr >> 32) & 0xffffu, p.g8_a_bytes, 0x00020000u};
+    const unsigned long xaddr = (unsigned long)p.X;
+    const u32x4 xrs = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    const unsigned a_step_bytes = (unsigned)(2 * p.g8_Mpad * 16);
+    unsigned avo[NAI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        const int d = (i * 4 + wave) * 64 + lane, within = d % (2 * BM);
+        avo[i] = d < A_ST ? (unsigned)(((within / BM) * p.g8_Mpad + m0 + within % BM) * 16) : C2M_OOB;
+    }
+
+    // issue-side running state: the K-steps are issued in ascending order, (tap, chunk) advance with them
+    int is_tap = __builtin_amdgcn_readfirstlane(k_beg / nch);
+    int is_chunk = __builtin_amdgcn_readfirstlane(k_beg - is_tap * nch);
+    __syncthreads();                                       // tap table visible
+    unsigned is_voff = tap_voff(is_tap);
+    auto issue = [&](int k0, int buf) {
+        const unsigned base = lds0 + (unsigned)(buf * BUF * 16);
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+            const int d0 = (i * 4 + wave) * 64;
+            const int ka = k0 + d0 / (2 * BM);
+            const bool live = d0 < A_ST && ka < k_end;
+            u32x4 r = ars;
+            r[2] = live ? p.g8_a_bytes : 0u;
+            const int soff = live ? (int)((unsigned)ka * a_step_bytes) : 0;
+            const unsigned dst = base + (unsigned)(d0 * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(avo[i]), "s"(r), "s"(soff) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = k0 + u < k_end;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cb = is_chunk * 2 + h;
+                u32x4 r = xrs;
+                const bool on = live && cb < p.g8_CB;
+                r[2] = on ? p.x_bytes : 0u;
+                const int soff = on ? (int)((unsigned)cb * p.g8_plane_bytes) : 0;
+                const unsigned dst = base + (unsigned)((A_PAD + (u * 2 + h) * 256 + wave * 64) * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(is_voff), "s"(r), "s"(soff) : "memory");
+            }
+            ++is_chunk;
+            if (is_chunk == nch) { is_chunk = 0; ++is_tap; is_voff = tap_voff(is_tap); }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s) issue(k_beg + s * U, s);
+    int cur = 0;
+    for (int k = k_beg; k < k_end; k += U) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(k + (NBUF - 1) * U, cur == 0 ? NBUF - 1 : cur - 1);
+        const uint4* __restrict__ sb = smem + cur * BUF;
+        bf16x8 a[U][MI], b[U][NI];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[u][i] = __builtin_bit_cast(bf16x8, sb[(u * 2 + (lane >> 5)) * BM + i * 32 + (lane & 31)]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[u][j] = __builtin_bit_cast(bf16x8, sb[A_PAD + (u * 2 + (lane >> 5)) * 256 + wave * 64 + j * 32 + (lane & 31)]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-record DMAs of the tail still write LDS
+
+    // ---- epilogue: the mappings of conv_igemm_kernel with one row block of BM and the wave's 64 pixel columns
+    if ((p.g8_dbg & 2) && acc[0][0][0] != 12345.f) return;
+    const bool direct = p.splits == 1;
+    const bool yh = p.yh && direct;
+    const int yes = yh ? 2 : 4;
+    float* __restrict__ Yb = yh ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(p.Y) + p.out_off_c[cls])
+                                : p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
+    const int po_t = p.po_c[cls][0], po_y = p.po_c[cls][1], po_x = p.po_c[cls][2];
+    if (m0 + BM <= p.M) {
+        unsigned voff[NI], voff2[NI];
+        bool ring = false;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int q = n0 + wave * 64 + j * 32 + (lane & 31);
+            int n, ot, oy, ox;
+            decompose_pix(q < p.Npix ? q : 0, p, n, ot, oy, ox);
+            const long e = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw +
+                           4L * (lane >> 5) * p.out_sc;
+            voff[j] = q < p.Npix ? (unsigned)(e * yes) : 0x80000000u;
+            voff2[j] = 0x80000000u;
+            if (p.Y2) {
+                const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y, xp = ox * p.ps_x + po_x - p.lo_x;
+                if (q < p.Npix && (unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y &&
+                    (unsigned)xp < (unsigned)p.ext_x) {
+                    const long e2 = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp + 4L * (lane >> 5) * p.y2_sc;
+                    voff2[j] = (unsigned)(e2 * yes);
+                    voff[j] = 0x80000000u;
+                }
+            }
+            ring = ring || voff[j] != 0x80000000u;
+        }
+        if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
+        if (!p.Y2 || __any(ring))
+            c2m_store_tile_fast<MI, NI>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int q = n0 + wave * 64 + j * 32 + (lane & 31);
+        if (q >= p.Npix) continue;
+        int n, ot, oy, ox;
+        decompose_pix(q, p, n, ot, oy, ox);
+        float* ybase = Yb;
+        long yidx = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw;
+        long row_stride = p.out_sc;
+        if (p.Y2) {
+            const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y, xp = ox * p.ps_x + po_x - p.lo_x;
+            if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+                ybase = p.Y2;
+                yidx = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
+                row_stride = p.y2_sc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) {
+                    float v = acc[i][j][r];
+                    if (direct) {
+                        if (p.bias) v += p.bias[row];
+                        v = c2m_act(v, p.act, p.slope);
+                    }
+                    if (yh) reinterpret_cast<bf16_t*>(ybase)[yidx + (long)row * row_stride] = (bf16_t)v;
+                    else ybase[yidx + (long)row * row_stride] = v;
+                }
+            }
     }
 }
 
@@ -1208,6 +1433,39 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
     }
     if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;
+    if (g[94] == 1) {
+        // NC8 gather form (conv_gather_nc8_kernel): X = NC8 of the gathered bf16 tensor ([N][ceil(C/8)][Ti*Hi*Wi][8], geom[32] its bytes),
+        // A = c2m_pack_weights_bf16_gather image(s) of this launch's first class, ktab = [ncls][taps] {dt, dy, dx, 1}, nk = taps *
+        // ceil(C/16) K-steps in (tap, chunk) order; C = geom[28], taps = geom[29]; geom[95] = tile variant (0 = rule)
+        const int C = (int)g[28], taps = (int)g[29];
+        if (g[34] != 1 || !p.xh || g[52] || C <= 0 || taps <= 0 || taps > 64 || (((uintptr_t)A | (uintptr_t)X) & 15))
+            return (int)hipErrorInvalidValue;
+        p.g8_nch = c2m_cdiv(C, 16); p.g8_ntaps = taps; p.g8_CB = c2m_cdiv(C, 8); p.g8_Mpad = c2m_cdiv(p.M, 128) * 128;
+        if (p.nk != taps * p.g8_nch || p.in_st != (long)p.Hi * p.Wi || p.in_sh != p.Wi) return (int)hipErrorInvalidValue;
+        const long plane = (long)p.Ti * p.Hi * p.Wi * 16, ab = (long)p.nk * 2 * p.g8_Mpad * 16;
+        if (plane * p.g8_CB > (long)p.x_bytes || p.x_bytes % (plane * p.g8_CB) || ab * p.ncls >= 0x80000000LL)
+            return (int)hipErrorInvalidValue;
+        p.g8_plane_bytes = (unsigned)plane; p.g8_a_bytes = (unsigned)ab;
+        const unsigned ptiles = (unsigned)c2m_cdiv(p.Npix, 256);
+        int v = (int)g[95] & 255;
+        p.g8_dbg = (int)(g[95] >> 8);
+        if (v == 0) v = p.M <= 32 ? 1 : ((p.M <= 64 || (p.M % 128 >= 1 && p.M % 128 <= 64)) ? 2 : 3);
+#define G8_LAUNCH(BM, UU, NB, WG) do {                                                                                     \
+            dim3 grid(ptiles * (unsigned)c2m_cdiv(p.M, BM) * (unsigned)(splits * p.ncls));                                  \
+            hipLaunchKernelGGL((conv_gather_nc8_kernel<BM, UU, NB, WG>), grid, dim3(256), 0, s, p); } while (0)
+        switch (v) {
+            case 1: G8_LAUNCH(32, 4, 2, 2); break;         // (rows, K-steps per stage, stages, workgroups per CU)
+            case 2: G8_LAUNCH(64, 2, 3, 2); break;
+            case 3: G8_LAUNCH(128, 2, 3, 2); break;
+            case 4: G8_LAUNCH(64, 1, 4, 3); break;
+            case 5: G8_LAUNCH(64, 2, 2, 3); break;
+            case 6: G8_LAUNCH(128, 1, 4, 2); break;
+            case 7: G8_LAUNCH(32, 2, 3, 2); break;
+            default: return (int)hipErrorInvalidValue;
+        }
+#undef G8_LAUNCH
+        return (int)hipGetLastError();
+    }
     if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
         if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
         p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
@@ -2745,6 +3003,35 @@ __device__ __forceinline__ void pack_weights_bf16_patch_body(const float* __rest
     }
 }
 
+// bf16 weights of the NC8 gather kernel: out[class][tap][16-channel chunk][half][row (padded to Mpad)] 16-byte units, RNE; the
+// source element of (class, tap, m, c) is the one pack_weights_row reads (PackP with CK = 16); rows >= M and channels >= C are zero.
+__device__ __forceinline__ void pack_weights_bf16_gather_body(const float* __restrict__ w, uint4* __restrict__ out, const PackP& q,
+                                                              int Mpad, long units, long b0, long nb) {
+    const int taps = q.At * q.Ay * q.Ax;
+    for (long u = b0 * (long)blockDim.x + threadIdx.x; u < units; u += nb * blockDim.x) {
+        const int m = (int)(u % Mpad); long r = u / Mpad;
+        const int half = (int)(r & 1); r >>= 1;
+        const int chunk = (int)(r % q.nch); r /= q.nch;
+        const int tap = (int)(r % taps); int cls = (int)(r / taps);
+        const int rx = cls % q.sw; cls /= q.sw;
+        const int ry = cls % q.sh; const int rt = cls / q.sh;
+        const int ax = tap % q.Ax, ay = (tap / q.Ax) % q.Ay, at = tap / (q.Ax * q.Ay);
+        const long toff = ((at * q.st + rt) * q.KH + (ay * q.sh + ry)) * q.KW + (ax * q.sw + rx);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 16 + half * 8 + j;
+            v[j] = (__bf16)((m < q.M && c < q.C) ? w[m * q.s_m + c * q.s_c + toff] : 0.f);
+        }
+        out[u] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+__global__ void pack_weights_bf16_gather_kernel(const float* __restrict__ w, uint4* __restrict__ out, const PackP q, int Mpad,
+                                                long units) {
+    pack_weights_bf16_gather_body(w, out, q, Mpad, units, blockIdx.x, gridDim.x);
+}
+
 __global__ void pack_weights_bf16_patch_kernel(const float* __restrict__ w, uint4* __restrict__ out, int M, int C, int Mpad,
                                                long s_m, long s_c, int flip, long units) {
     pack_weights_bf16_patch_body(w, out, M, C, Mpad, s_m, s_c, flip, units, blockIdx.x, gridDim.x);
@@ -2791,6 +3078,27 @@ static int pack_params(const int64_t* g, PackP& q, long& rows, int& lda) {
     return 0;
 }
 
+// g[] as c2m_pack_weights (g[2] = CK must be 16).  out: prod(stride) class images of taps * ceil(C/16) * 2 * Mpad 16-byte units
+// (taps = (KT/st)(KH/sh)(KW/sw), Mpad = ceil(M/128)*128), classes in (rt, ry, rx) row-major order.
+C2M_API long c2m_pack_weights_bf16_gather_bytes(const int64_t* g) {
+    PackP q; long rows; int lda;
+    if (pack_params(g, q, rows, lda) || rows == 0 || q.CK != 16) return -1;
+    return (long)q.st * q.sh * q.sw * q.At * q.Ay * q.Ax * q.nch * 2 * (c2m_cdiv(q.M, 128) * 128) * 16;
+}
+
+C2M_API int c2m_pack_weights_bf16_gather(const float* w, void* out, const int64_t* g, void* stream) {
+    C2M_ENTER();
+    PackP q; long rows; int lda;
+    const int rc = pack_params(g, q, rows, lda);
+    if (rc || rows == 0) return rc;
+    if (q.CK != 16 || (((uintptr_t)out) & 15)) return (int)hipErrorInvalidValue;
+    const int Mpad = c2m_cdiv(q.M, 128) * 128;
+    const long units = (long)q.st * q.sh * q.sw * q.At * q.Ay * q.Ax * q.nch * 2 * Mpad;
+    hipLaunchKernelGGL(pack_weights_bf16_gather_kernel, dim3(c2m_grid(units, 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)out,
+                       q, Mpad, units);
+    return (int)hipGetLastError();
+}
+
 C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void* stream) {
     C2M_ENTER();
     PackP q; long rows; int lda;
@@ -2807,7 +3115,8 @@ C2M_API int c2m_pack_weights(const float* w, float* out, const int64_t* g, void*
 // step and layout -- ~195 launches of 5-7 us in a full G + D step (1.3 ms of GPU time, more host time than that in eager mode).
 // The host keeps one PackJob per (weight, layout) it has packed before (c2m_pack_job_fill), the table lives in device memory,
 // and after the optimizer step one launch refreshes every pack in place: workgroup b finds its job by bisection over the jobs'
-// first workgroup index.  type 0: c2m_pack_weights (g[11]); type 1: c2m_pack_weights_bf16_patch (g[5]).
+// first workgroup index.  type 0: c2m_pack_weights (g[11]); type 1: c2m_pack_weights_bf16_patch (g[5]); type 2:
+// c2m_pack_weights_bf16_gather (g[11]).
 struct PackJob {
     const float* w; void* out;
     PackP q;                                                  // type 0
@@ -2834,6 +3143,13 @@ C2M_API long c2m_pack_job_fill(void* job, int type, const void* w, void* out, co
         j.units = (long)c2m_cdiv(j.C, 16) * (j.flip >= 2 ? 16 : 9) * j.Mpad * 2;
         j.xblocks = 1;
         j.nblocks = (unsigned)c2m_grid(j.units, 256);
+    } else if (type == 2) {                                   // c2m_pack_weights_bf16_gather (g[11])
+        long rows; int lda;
+        if (pack_params(g, j.q, rows, lda) || rows == 0 || j.q.CK != 16 || (((uintptr_t)out) & 15) != 0) return -1;
+        j.Mpad = c2m_cdiv(j.q.M, 128) * 128;
+        j.units = (long)j.q.st * j.q.sh * j.q.sw * j.q.At * j.q.Ay * j.q.Ax * j.q.nch * 2 * j.Mpad;
+        j.xblocks = 1;
+        j.nblocks = (unsigned)c2m_grid(j.units, 256);
     } else {
         return -1;
     }
@@ -2854,6 +3170,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         if (q.CK == 16)     pack_weights_row<16>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
         else if (q.CK == 8) pack_weights_row<8>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
         else                pack_weights_row<4>(j.w, (float*)j.out, q, toff, r, bx, (int)j.xblocks);
+    } else if (j.type == 2) {
+        const PackP q = j.q;
+        pack_weights_bf16_gather_body(j.w, (uint4*)j.out, q, j.Mpad, j.units, lb, j.nblocks);
     } else {
         pack_weights_bf16_patch_body(j.w, (uint4*)j.out, j.M, j.C, j.Mpad, j.s_m, j.s_c, j.flip, j.units, lb, j.nblocks);
     }

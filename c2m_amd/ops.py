@@ -282,6 +282,9 @@ _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / bufferi
 # replays) it removes 77 of 174 layout passes (-0.95 ms) but the 8-channel x 8-pixel apply kernels run 2x as long as the per-plane
 # ones they replace (+1.2 ms): 47.7 vs 47.05 ms, 71.5 vs 70.7 ms.  Kept as an A/B knob with its tests (tests/test_gpu_nc8.py).
 _NC8_NORM = os.environ.get("C2M_NC8_NORM", "0") != "0"
+# NC8 gather kernel (conv_gather_nc8_kernel, conv_igemm.hip): every bf16 forward / data gradient the NC8 patch forms do not take
+_G8 = os.environ.get("C2M_G8", "1") != "0"
+_G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
 _NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
@@ -385,6 +388,58 @@ def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope, keep=None):
     xn = _to_nc8(x, keep)
     geom[93] = _NC8_VARIANT
     return L.c2m_conv_patch_nc8(_p(A), _p(xn), _p(dst), _p(y2), _p(b), _gp(geom), act, slope, _stream())
+
+
+def _pack_bf16_gather(w, M, C, kdims, stride, s_m, s_c):
+    """c2m_pack_weights_bf16_gather: contiguous native weights -> prod(stride) class images [tap][16-channel chunk][half][Mpad] of
+    16-byte bf16 units (the NC8 gather kernel's K order: tap-major)."""
+    L = _lib.lib()
+    kt, kh, kw = kdims
+    st, sh, sw = stride
+    g = np.array([M, C, 16, kt, kh, kw, st, sh, sw, s_m, s_c], dtype=np.int64)
+    nbytes = L.c2m_pack_weights_bf16_gather_bytes(_gp(g))
+    if nbytes <= 0:
+        raise RuntimeError("c2m_pack_weights_bf16_gather_bytes: bad geometry")
+    out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _lib.check(L.c2m_pack_weights_bf16_gather(_p(w), _p(out), _gp(g), _stream()), "pack_weights_bf16_gather")
+    out._c2m_job = (2, g)
+    return out
+
+
+def _g8_bm(M):
+    """Row tile of conv_gather_nc8_kernel for M output rows (the rule of c2m_conv_igemm's NC8 gather form)."""
+    return 32 if M <= 32 else (64 if (M <= 64 or 1 <= M % 128 <= 64) else 128)
+
+
+_G8_SPLIT_WGS = int(os.environ.get("C2M_G8_SPLIT_WGS", "320"))
+
+
+def _g8_splits(M, nk, npix, ncls=1):
+    """K splits of an NC8 gather launch (256-pixel tiles): only launches that leave CUs empty are split, towards ~1.25 workgroups
+    per CU with >= 8 K-steps per split -- at bf16 MFMA rates the fp32 slabs (4 bytes per output and split, written and read back)
+    cost more than a second round of workgroups saves."""
+    tiles = _cdiv(M, _g8_bm(M)) * _cdiv(npix, 256) * ncls
+    if tiles >= 200 or nk < 16:
+        return 1
+    S = min(_cdiv(_G8_SPLIT_WGS, tiles), nk // 8, 16)
+    if S < 2:
+        return 1
+    return _cdiv(nk, _cdiv(nk, S))
+
+
+def _g8_geom(geom, C, taps, S):
+    """geom of the same launch on the NC8 gather form: nk = taps * ceil(C/16) K-steps in (tap, chunk) order."""
+    g = geom.copy()
+    nk = taps * _cdiv(C, 16)
+    g[[1, 2, 24, 26, 28, 29, 34, 52, 94, 95]] = (nk, nk * 16, 1, S, C, taps, 1, 0, 1, _G8_VARIANT)
+    return g
+
+
+def _g8_taps(offs, device):
+    t = np.zeros((len(offs), 4), dtype=np.int32)
+    t[:, :3] = np.asarray(offs, dtype=np.int32).reshape(len(offs), 3)
+    t[:, 3] = 1
+    return torch.from_numpy(t.reshape(-1)).to(device)
 
 
 def _set_patch(geom, iy0, ix0, pty, ptx):
@@ -757,7 +812,7 @@ class _ConvPlan:
                         if bf16:
                             geom[2] = _ceil(dM, 128)
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
-                                             tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom))
+                                             tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom, offs=coffs))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
         S = min(_splits(L, dM, c["nk"], c["npix"], bf16) for c in self.classes) if self.classes else 1
         if S > 1:
@@ -811,6 +866,39 @@ class _ConvPlan:
             if len(groups) < ncls:
                 self.cls_batch = dict(groups=groups, ncls=ncls, ck=ck0, taps=cl[0]["taps"], nk=nk0)
                 self.dgrad_splits = SB
+        # ---- NC8 gather form (conv_gather_nc8_kernel) of every bf16 forward / data gradient the NC8 patch forms above do not take:
+        # the same launches (geometry, classes, two-target epilogue, split-K) with channel-blocked input, a compact tap table and
+        # bf16 weights in (tap, chunk) order.  Channel padding up to 45 % (34 -> 48); <= 4 output rows stay on the vector-ALU kernels.
+        chan_ok = lambda c: c >= 12 and _ceil(c, 16) <= 1.45 * c
+        g8 = bool(bf16 and _NC8 and _G8)
+        self.g8_fwd = bool(g8 and not (self.k333_nc8 or self.s2_nc8 or (self.fwd_patch and self.nc8)) and Cout > 4 and chan_ok(Cin)
+                           and in_sc % 8 == 0 and taps <= 64)
+        if self.g8_fwd:
+            self.g8_fwd_splits = _g8_splits(Cout, taps * _cdiv(Cin, 16), N * osp)
+            self.g8_fwd_geom = _g8_geom(self.fwd_geom, Cin, taps, self.g8_fwd_splits)
+            self.g8_fwd_tab = _g8_taps(offs, device)
+        patch_nc8 = any(c["patch"] for c in cl) and not is3d and (Ho * Wo) % 8 == 0
+        self.g8_dgrad = bool(g8 and cl and not (self.k333_dgrad_nc8 or self.s2_dgrad_nc8 or patch_nc8) and dM > 4 and chan_ok(Cout)
+                             and osp % 8 == 0 and self.classes_packable and max(c["taps"] for c in cl) <= 64 and
+                             not any(c["patch"] for c in cl))
+        if self.g8_dgrad:
+            ctaps = cl[0]["taps"]
+            nk8 = ctaps * _cdiv(Cout, 16)
+            self.g8_a_cls = nk8 * 2 * _ceil(dM, 128) * 16          # bytes of one class image
+            if self.cls_batch is not None:
+                S8 = min(_g8_splits(dM, nk8, grp["npix"], grp["ncls"]) for grp in self.cls_batch["groups"])
+            else:
+                S8 = min(_g8_splits(dM, nk8, c["npix"]) for c in cl)
+            if S8 > 1 and _cdiv(nk8, _cdiv(nk8, S8)) != S8:
+                S8 = 1
+            self.g8_dgrad_splits = S8
+            for c in cl:
+                c["g8"] = _g8_geom(c["geom"], Cout, ctaps, S8)
+                c["g8tab"] = _g8_taps(c["offs"], device)
+            for grp in (self.cls_batch["groups"] if self.cls_batch else ()):
+                grp["g8"] = _g8_geom(grp["geom"], Cout, ctaps, S8)
+                grp["g8"][62], grp["g8"][63] = 0, 0
+                grp["g8tab"] = torch.cat([c["g8tab"] for c in cl[grp["first"]:grp["first"] + grp["ncls"]]])
 
 
 def _plan(x, w, stride, pad, reflect, dgrad_rows=None):
@@ -1058,7 +1146,8 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
         if pl.reflect:
             _lib.check(L.c2m_reflect_fold(_p(tgt), _p(gx), N * Cin, 1, Hi_, Wi_, 0, 1, 1, _dt(tgt), _stream()), "reflect fold (s2)")
     else:
-        S = pl.dgrad_splits
+        g8 = pl.bf16 and pl.g8_dgrad                 # the NC8 gather form of the same launches (conv_gather_nc8_kernel)
+        S = pl.g8_dgrad_splits if g8 else pl.dgrad_splits
         folded = pl.reflect and any(pl.pad)
         two_target = folded and S == 1 and not pl.dgrad_needs_zero
         alloc = torch.zeros if pl.dgrad_needs_zero else torch.empty
@@ -1082,7 +1171,26 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
         dst = tgt if S == 1 else alloc(S * tgt.numel(), device=dev, dtype=torch.float32)
         st, sh, sw = pl.stride
         w5 = w if pl.is3d else w.unsqueeze(2)
-        if cb is not None:
+        if g8:
+            kt, kh, kw = pl.dims[9:12]
+            A8 = _packed(w, frozen_w, ("dgrad-bf16-g8", pl.dM, pl.stride), lambda: _pack_bf16_gather(
+                w, pl.dM, Cout, (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
+            launches = [(grp["g8"], grp["g8tab"], grp["first"], cb["taps"] * grp["npix"] * grp["ncls"], grp["npix"] * grp["ncls"])
+                        for grp in cb["groups"]] if cb is not None else \
+                       [(c["g8"], c["g8tab"], ci, c["taps"] * c["npix"], c["npix"]) for ci, c in enumerate(pl.classes)]
+            for geom8, tab8, first, work, npix in launches:
+                tag = ("dgrad", Cin, Cout * pl.classes[0]["taps"], npix, pl.dims[9:12], pl.stride, pl.reflect, S, "nc8g")
+                Ag = A8[first * pl.g8_a_cls:]
+
+                def run_g8d():
+                    gyn = _to_nc8(gy_b, keep)
+                    _set_io(geom8, gyn, kdt)
+                    return L.c2m_conv_igemm(_p(Ag), _p(gyn), _p(dst), _p(gx) if two_target else None, None, _p(tab8), _gp(geom8),
+                                            0, 0.0, _stream())
+                _lib.check(_timed("igemm_bf16", pl.dgrad_flops * work / pl.dgrad_work, run_g8d, tag,
+                                  (2 * (gy.numel() + xnumel) + 4 * w.numel()) * work // int(pl.dgrad_work)),
+                           "conv_igemm dgrad (NC8 gather)")
+        elif cb is not None:
             kt, kh, kw = pl.dims[9:12]
             A = _packed(w, frozen_w, ("dgrad-all", cb["ck"], pl.stride), lambda: _pack_native(
                 w, Cin, Cout, cb["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
@@ -1102,10 +1210,10 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
                            "conv_igemm dgrad (batched classes)")
         kt, kh, kw = pl.dims[9:12]
         Aall = None
-        if cb is None and pl.classes_packable and not (pl.bf16 and all(c["patch"] for c in pl.classes)):
+        if cb is None and not g8 and pl.classes_packable and not (pl.bf16 and all(c["patch"] for c in pl.classes)):
             Aall = _packed(w, frozen_w, ("dgrad-all", pl.classes[0]["ck"], pl.stride), lambda: _pack_native(
                 w, Cin, Cout, pl.classes[0]["ck"], (kt, kh, kw), pl.stride, kt * kh * kw, Cin * kt * kh * kw))
-        for ci, c in enumerate(pl.classes if cb is None else ()):
+        for ci, c in enumerate(pl.classes if (cb is None and not g8) else ()):
             rt, ry, rx = c["r"]
             A = _packed(w, frozen_w, ("dgrad-bf16-patch", pl.dM), lambda: _pack_bf16_patch(
                 w, pl.dM, Cout, 9, Cin * 9)) if (c["patch"] and pl.bf16) else \
@@ -1200,6 +1308,28 @@ class _ConvFn(torch.autograd.Function):
                                          _stream())
             _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_s2, tag,
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_s2_nc8 fwd")
+            ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
+            ctx.save_for_backward(x, w, y if ACT[act] else None)
+            return y
+        if pl.bf16 and pl.g8_fwd:
+            # the NC8 gather form: channel-blocked input, bf16 weights in (tap, chunk) order (conv_gather_nc8_kernel)
+            x = _as(x, BF16)
+            A = _packed(w, ctx.frozen_w, ("fwd-bf16-g8",), lambda: _pack_bf16_gather(w, Cout, Cin, pl.dims[9:12], (1, 1, 1), pl.K, pl.K // Cin))
+            S = pl.g8_fwd_splits
+            y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
+            dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S, "nc8g")
+
+            def run_g8():
+                xn = _to_nc8(x)
+                _set_io(pl.g8_fwd_geom, xn, BF16)
+                return L.c2m_conv_igemm(_p(A), _p(xn), _p(dst), None, _p(b), _p(pl.g8_fwd_tab), _gp(pl.g8_fwd_geom), ACT[act], slope,
+                                        _stream())
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_g8, tag,
+                              2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_igemm fwd (NC8 gather)")
+            if S > 1:
+                _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
+                                               slope, _dt(y), _stream()), "splitk_reduce")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
             return y

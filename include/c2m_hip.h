@@ -51,6 +51,13 @@ enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 
  *   61 ncls: stride parity classes batched into this launch (blockIdx.z = class*splits + split); 62 floats per class
  *      weight matrix, 63 int4 entries per class tap table, 64+c out_off of class c, 96+3c.. its (po_t, po_y, po_x)
  *      (geom[] holds 120 entries; 90 / 91 / 92 are the element-type and weight-gradient-form flags)
+ *   94 NC8 gather form (conv_gather_nc8_kernel, round 4; every bf16 forward / data gradient that is not a 3x3 / 4x4-stride-2 /
+ *      3x3x3 patch layer -- down_block.py:14-23 and same_block.py:50-68 in 3-D, the discriminator tails, 1x1 and 7x7 layers, the
+ *      reflect data gradients over (W/2 + 1)-wide class planes): 1 = X is the NC8 form ([N][ceil(C/8)][Ti*Hi*Wi][8] bf16, geom[32]
+ *      its bytes) of the gathered tensor, A the c2m_pack_weights_bf16_gather image of the launch's first class, ktab a compact
+ *      table [ncls][taps] of {dt, dy, dx, 1}, geom[1] = taps * ceil(C/16) K-steps in (tap, chunk) order (C = geom[28], taps =
+ *      geom[29] <= 64), geom[24] = 1; classes, splits, the two-target epilogue and the output types as for the NCHW gather kernel.
+ *      95: tile variant (0 = by rows: 32 / 64 / 128-row tiles x 256 pixels).
  * With splits > 1, Y must point at a slab of splits*slab_stride floats and c2m_splitk_reduce finishes the op
  * (sum over splits in a fixed order, + bias[(i / chan_stride) % M], activation).                               */
 int c2m_conv_igemm_splits(int M, int nk, int Npix);
@@ -76,7 +83,7 @@ int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW, float*
 int c2m_pack_weights(const float* w, float* packed, const int64_t* g, void* stream);
 /* Every pack of a model in ONE launch (after an optimizer step each trainable weight needs each of its layouts rebuilt once:
  * ~195 launches of 5-7 us in a full G + D step).  The host fills one job record per (weight, layout) -- type 0: the arguments of
- * c2m_pack_weights, type 1: those of c2m_pack_weights_bf16_patch -- with the index of its first workgroup (ascending, dense),
+ * c2m_pack_weights, type 1: those of c2m_pack_weights_bf16_patch, type 2: those of c2m_pack_weights_bf16_gather -- with the index of its first workgroup (ascending, dense),
  * keeps the table (and one (job, workgroup) pair per workgroup of the launch) in device memory and refreshes all packs in place
  * with c2m_pack_multi.  c2m_pack_job_fill returns the number of workgroups of the job (< 0: bad geometry).                                                           */
 int c2m_pack_job_bytes(void);
@@ -88,6 +95,11 @@ int c2m_pack_multi(const void* device_jobs, const void* device_blocktab /* int32
  * data gradient (rotated taps).  Pass the result as A to c2m_conv_igemm with geom[2] (lda) = the padded row count. */
 long c2m_pack_weights_bf16_patch_bytes(int M, int C);
 int c2m_pack_weights_bf16_patch(const float* w, void* out, const int64_t* g, void* stream);
+/* bf16 weight images of the NC8 gather form (geom[94] of c2m_conv_igemm): g[] as c2m_pack_weights with g[2] = 16; out = prod(stride)
+ * class images ((rt, ry, rx) row-major) of [tap][16-channel chunk][half][row padded to a multiple of 128] 16-byte units (8 bf16,
+ * RNE; zero rows / channels past M / C).  Job type 2 of c2m_pack_job_fill / c2m_pack_multi. */
+long c2m_pack_weights_bf16_gather_bytes(const int64_t* g);
+int c2m_pack_weights_bf16_gather(const float* w, void* out, const int64_t* g, void* stream);
 
 /* Channel-blocked ("NC8") bf16 convolutions (conv_nc8.hip, round 4; the same 3x3 stride-1 call sites -- vgg.py:92-137,
  * residual_block.py:13-31,42-71, spade_block.py:47-49, up_block.py:9-13, same_block.py:14-23 -- in bf16 mode).
