@@ -1449,7 +1449,9 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
         const unsigned ptiles = (unsigned)c2m_cdiv(p.Npix, 256);
         int v = (int)g[95] & 255;
         p.g8_dbg = (int)(g[95] >> 8);
-        if (v == 0) v = p.M <= 32 ? 1 : ((p.M <= 64 || (p.M % 128 >= 1 && p.M % 128 <= 64)) ? 2 : 3);
+        // (kernel trace of tools/ab_g8.py on one box, all variants per shape: 64-row tiles 2 stages x 3 workgroups per CU >= 3 stages x 2
+        // everywhere (45-row (4,4,4) data gradient 160 vs 209 us); 128-row tiles: variants 3 / 6 within 3 %; <= 32 rows: 4 K-steps per stage)
+        if (v == 0) v = p.M <= 32 ? 1 : ((p.M <= 64 || (p.M % 128 >= 1 && p.M % 128 <= 64)) ? 5 : 3);
 #define G8_LAUNCH(BM, UU, NB, WG) do {                                                                                     \
             dim3 grid(ptiles * (unsigned)c2m_cdiv(p.M, BM) * (unsigned)(splits * p.ncls));                                  \
             hipLaunchKernelGGL((conv_gather_nc8_kernel<BM, UU, NB, WG>), grid, dim3(256), 0, s, p); } while (0)
@@ -2884,6 +2886,40 @@ __global__ void reflect_border_only_kernel(const T* __restrict__ dXp, T* __restr
     }
 }
 
+// The 2-D pad-1 case (every 3x3 / 4x4-stride-2 reflect layer; a 3-D layer folded in the plane only is T independent planes): the
+// elements that receive ring contributions are rows 1, H-2 and columns 1, W-2 of each plane.  The general kernel above finds its
+// element with ~8 integer divisions by run-time values (20 us per launch on a 40 x 128 x 64 x 128 gradient: ALU bound, 55 launches
+// per step); here one division splits (plane, e) and comparisons do the rest.  Same sources in the same order: bit-identical sums.
+template <class T>
+__global__ void reflect_border_p1_kernel(const T* __restrict__ dXp, T* __restrict__ dX, const int H, const int W, const long planes) {
+    const int Hp = H + 2, Wp = W + 2;
+    const int per = 2 * W + 2 * (H - 2);
+    const long total = planes * per;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long pl = idx / per;
+        const int e = (int)(idx - pl * per);
+        int y, x;
+        if (e < 2 * W) {                               // the two rows: contiguous in x
+            y = e < W ? 1 : H - 2;
+            x = e < W ? e : e - W;
+        } else {                                       // the two columns without the rows above
+            const int k2 = e - 2 * W;
+            x = k2 < H - 2 ? 1 : W - 2;
+            const int k = k2 < H - 2 ? k2 : k2 - (H - 2);
+            y = k == 0 ? 0 : (k == H - 3 ? H - 1 : k + 1);
+        }
+        int sy[3], sx[3];
+        const int ny = fold_sources(y, H, 1, sy), nx = fold_sources(x, W, 1, sx);
+        const T* __restrict__ base = dXp + pl * (long)Hp * Wp;
+        float acc = 0.f;
+        for (int b = 0; b < ny; ++b)
+            for (int c = 0; c < nx; ++c)
+                if (b + c > 0) acc += c2m_ld(base, (long)sy[b] * Wp + sx[c]);
+        const long di = pl * (long)H * W + (long)y * W + x;
+        c2m_st(dX, di, c2m_ld(dX, di) + acc);
+    }
+}
+
 C2M_API int c2m_reflect_border_add(const void* dXpad, void* dX, long NC, int T_, int H, int W, int pt, int ph, int pw,
                                    int dt, void* stream) {
     C2M_ENTER();
@@ -2891,6 +2927,13 @@ C2M_API int c2m_reflect_border_add(const void* dXpad, void* dX, long NC, int T_,
     if (f.total <= 0) return 0;
     const bool roomy = (pt == 0 || T_ >= 2 * pt + 2) && (ph == 0 || H >= 2 * ph + 2) && (pw == 0 || W >= 2 * pw + 2);
     const long per_l = (long)T_ * H * 2 * pw + (long)T_ * 2 * ph * (W - 2 * pw) + 2L * pt * (H - 2 * ph) * (W - 2 * pw);
+    if (pt == 0 && ph == 1 && pw == 1 && H >= 4 && W >= 4 && !getenv("C2M_FOLD_GENERAL")) {
+        const long planes = NC * T_;
+        C2M_DISPATCH_DT(dt,
+            hipLaunchKernelGGL(reflect_border_p1_kernel<T>, dim3(c2m_grid(planes * (2L * W + 2L * (H - 2)), 256)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)dXpad, (T*)dX, H, W, planes););
+        return (int)hipGetLastError();
+    }
     C2M_DISPATCH_DT(dt,
         if (roomy && per_l > 0 && per_l < (1L << 30)) {
             const int r1 = T_ * H * 2 * pw; const int r2 = T_ * 2 * ph * (W - 2 * pw); const int r3 = 2 * pt * (H - 2 * ph) * (W - 2 * pw);

@@ -283,6 +283,7 @@ _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / bufferi
 # ones they replace (+1.2 ms): 47.7 vs 47.05 ms, 71.5 vs 70.7 ms.  Kept as an A/B knob with its tests (tests/test_gpu_nc8.py).
 _NC8_NORM = os.environ.get("C2M_NC8_NORM", "0") != "0"
 # NC8 gather kernel (conv_gather_nc8_kernel, conv_igemm.hip): every bf16 forward / data gradient the NC8 patch forms do not take
+_NC8_LOG = None
 _G8 = os.environ.get("C2M_G8", "1") != "0"
 _G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
@@ -341,6 +342,9 @@ def _to_nc8(x, keep=None):
             return hit[1]
     N, C = x.shape[0], x.shape[1]
     sp = tuple(x.shape[2:])                 # (H, W), or (T, H, W): the pixel axis of the layout pass is everything behind C
+    if _NC8_LOG is not None:                # tools/nc8_producers.py: who produced the tensors that need a layout pass
+        fn = x.grad_fn
+        _NC8_LOG.append((type(fn).__name__ if fn is not None else ("leaf" if torch.is_grad_enabled() else "backward"), tuple(x.shape)))
     y = torch.empty((N, _cdiv(C, 8)) + sp + (8,), device=x.device, dtype=BF16)
     _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, int(np.prod(sp)), _stream()), "nchw_to_nc8")
     if keep is not None:

@@ -123,8 +123,9 @@ def test_trainable_weight_packs_are_built_once_per_optimizer_step():
 
 def test_adam_step_refreshes_every_pack_in_one_launch_bit_identically():
     """ops.refresh_trainable_packs (called by Adam.step): the cached packs of the updated weights -- K-order matrices of a strided
-    layer's forward and data gradient, bf16 patch images of a 3x3 layer -- are rebuilt IN PLACE by c2m_pack_multi and equal a
-    fresh c2m_pack_weights / c2m_pack_weights_bf16_patch of the new weights bit for bit; frozen weights have no job."""
+    layer's forward and data gradient, bf16 patch images of a 3x3 layer, bf16 gather images (NC8 gather form) -- are rebuilt IN PLACE
+    by c2m_pack_multi and equal a fresh c2m_pack_weights / c2m_pack_weights_bf16_patch / c2m_pack_weights_bf16_gather of the new
+    weights bit for bit; frozen weights have no job."""
     from c2m_amd import ops
     torch.manual_seed(5)
     with ops.conv_precision("bf16"):
@@ -158,7 +159,8 @@ def test_adam_step_refreshes_every_pack_in_one_launch_bit_identically():
             hit = ops._frozen_pack_cache[k]
             assert hit[1] == w._version and hit[3] is A
             fresh = torch.empty_like(A)
-            fn = ops._lib.lib().c2m_pack_weights if typ == 0 else ops._lib.lib().c2m_pack_weights_bf16_patch
+            L = ops._lib.lib()
+            fn = {0: L.c2m_pack_weights, 1: L.c2m_pack_weights_bf16_patch, 2: L.c2m_pack_weights_bf16_gather}[typ]
             ops._lib.check(fn(ops._p(w), ops._p(fresh), ops._gp(g_), ops._stream()), "pack")
             torch.cuda.synchronize()
             assert torch.equal(A.view(torch.uint8).flatten(), fresh.view(torch.uint8).flatten()), f"refreshed pack {k[1]} differs from a fresh one"
