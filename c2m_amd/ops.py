@@ -289,6 +289,7 @@ _G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
 _NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
+_NC8_S2_FILL_G8 = float(os.environ.get("C2M_NC8_S2_FILL_G8", "1.5"))      # stride-2 patch forms: largest tile waste where the gather form is the alternative
 _NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "2.6"))      # (18x34 padded domains of the 16x32 reflect data gradients: 2.5; still 1.5x+ the gather kernel)
 _NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
 _NC8 = os.environ.get("C2M_NC8", "1") != "0"        # bf16 3x3 stride-1 layers on channel-blocked input (A/B knob)
@@ -704,15 +705,21 @@ class _ConvPlan:
                                    (_ceil(Wi + 2 * pd, 32) * _ceil(Hi + 2 * pd, 8)) <= _NC8_FILL * (Wi + 2 * pd) * (Hi + 2 * pd))
         if self.k333_dgrad_nc8:
             self.k333_ptab = torch.from_numpy(_time_pair_table_kt(Ti, bool(reflect)).reshape(-1)).to(device)
-        # ... the 4x4 stride-2 pad-1 layers on the parity-plane form of the patch kernel (forward)
+        # ... the 4x4 stride-2 pad-1 layers on the parity-plane form of the patch kernel (forward).  Half-filled tiles (8 x 16 output maps)
+        # go to the NC8 gather form where it can take the layer: 40 vs 59 us on 256 -> 512 at 16x32, but 42 vs 36 us on 128 -> 256 at
+        # 32x64 whose tiles are full (profiles/r04_ab_nc8.txt)
+        # (only launches with >= 4096 output pixels: below that the gather form needs deep K splits -- configs[2]'s 20-image batches of
+        # the same layers measured +0.7 ms with the gather form, configs[3]'s 40-image batches -0.7 ms)
+        g8_in = bool(_G8 and Cin >= 12 and _ceil(Cin, 16) <= 1.45 * Cin and in_sc % 8 == 0 and N * osp >= 4096)
+        g8_out = bool(_G8 and Cout >= 12 and _ceil(Cout, 16) <= 1.45 * Cout and osp % 8 == 0 and N * osp >= 4096)
         self.s2_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and (ph, pw) == (1, 1)
                            and Hi % 2 == 0 and Wi % 2 == 0 and Cout > 4 and Cin >= 12 and Wo >= 16 and Ho >= 4 and
-                           (_ceil(Wo, 32) * _ceil(Ho, 8)) <= _NC8_FILL * Wo * Ho)
+                           (_ceil(Wo, 32) * _ceil(Ho, 8)) <= (_NC8_S2_FILL_G8 if g8_in else _NC8_FILL) * Wo * Ho)
         # ... their data gradient (four output parity classes over one shared dY patch, one launch)
         qh, qw = Hi // 2 + (1 if reflect else 0), Wi // 2 + (1 if reflect else 0)
         self.s2_dgrad_nc8 = bool(self.nc8 and _NC8_S2 and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
                                  (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cin >= 8 and Cout >= 12 and qw >= 16 and
-                                 dM == Cin and (_ceil(qw, 32) * _ceil(qh, 8)) <= _NC8_FILL * qw * qh)
+                                 dM == Cin and (_ceil(qw, 32) * _ceil(qh, 8)) <= (_NC8_S2_FILL_G8 if (g8_out and dM > 4) else _NC8_FILL) * qw * qh)
         self.s2_wgrad_nc8 = bool(self.nc8 and _NC8_S2 and _NC8_WGRAD and (kt, kh, kw) == (1, 4, 4) and tuple(stride) == (1, 2, 2) and
                                  (ph, pw) == (1, 1) and Hi % 2 == 0 and Wi % 2 == 0 and Cout >= 64 and Cin >= 16 and
                                  N * Ho * Wo >= _NC8_S2_WGRAD_MIN_PIX)      # (the few-pixel encoder tails: one or two chunks per split, slabs dominate)

@@ -832,3 +832,39 @@ def test_conv_relu_pool_matches_the_unfused_chain_bit_for_bit(shape, cout):
         res.append((p.detach().clone(), x.grad.clone()))
     assert float((res[0][0] == 0).float().mean()) > 0.05, "the case should contain all-zero pooling windows"
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6, 1, 8, 12), (4, 3, 5, 4), (3, 1, 4, 4), (2, 2, 33, 65)])
+def test_reflect_border_add_pad1_kernel_matches_the_general_one_and_autograd(shape, dtype):
+    """c2m_reflect_border_add for the 2-D pad-1 case runs a division-free kernel (round 4): same sources in the same order as the
+    general kernel -> bit-identical; and both equal the adjoint of F.pad(mode='reflect') restricted to the ring."""
+    import os
+    import torch.nn.functional as F
+    from c2m_amd import _lib
+    NC, T, H, W = shape
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(H * 100 + W)
+    tgt = torch.randn(NC, T, H + 2, W + 2, generator=g).to(DEV).to(dtype)
+    base = torch.randn(NC, T, H, W, generator=g).to(DEV).to(dtype)
+    dt = 1 if dtype == torch.bfloat16 else 0
+    outs = []
+    for general in (False, True):
+        if general:
+            os.environ["C2M_FOLD_GENERAL"] = "1"
+        try:
+            dx = base.clone()
+            _lib.check(L.c2m_reflect_border_add(ops._p(tgt), ops._p(dx), NC, T, H, W, 0, 1, 1, dt, ops._stream()), "border add")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("C2M_FOLD_GENERAL", None)
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1]), "pad-1 kernel vs general kernel"
+    # adjoint of the reflect pad: the ring of tgt folded onto the interior positions it mirrors, interior of tgt NOT added
+    x = torch.zeros(NC * T, 1, H, W, dtype=torch.float64, requires_grad=True)
+    ring = tgt.double().cpu().reshape(NC * T, 1, H + 2, W + 2).clone()
+    ring[:, :, 1:-1, 1:-1] = 0
+    F.pad(x, (1, 1, 1, 1), mode="reflect").backward(ring)
+    ref = base.double().cpu().reshape(NC * T, 1, H, W) + x.grad
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    close(outs[0].double().cpu().reshape(NC * T, 1, H, W), ref, tol, tol, "border fold vs the adjoint of reflect padding")
