@@ -262,7 +262,7 @@ def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
     return Wo >= 32 and Ho >= rows and (_ceil(Wo, 32) * _ceil(Ho, rows)) <= 1.15 * Wo * Ho
 
 
-def _patch_bf16_ok(C, stride, Ho, Wo, M):
+def _patch_bf16_ok(C, stride, Ho, Wo, M, fill_limit=None):
     """bf16 LDS-patch kernel (8 rows x 32 columns per workgroup): 3x3 stride-1.  Where it beats the bf16 gather kernel
     (per-shape A/B of BASELINE configs[2], gpurun_out/r02/table_cfg2*.txt): deep reductions (>= 128 channels: the weight
     image of a chunk is re-streamed per 256 pixels, which only pays with many chunks) or few output rows (<= 64), and
@@ -271,7 +271,7 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M):
         return False
     fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
     if _NC8:              # the channel-blocked kernel (conv_nc8.hip) has no 2-byte gathers to amortise: every layer whose tiles fit
-        return fill <= _NC8_FILL      # (the padded 34x66 domain of a reflect data gradient fills 58 % of its tiles: still 1.5x the gather kernel)
+        return fill <= (fill_limit or _NC8_FILL)      # (the padded 34x66 domain of a reflect data gradient fills 58 % of its tiles: still 1.5x the gather kernel)
     if C < 128:
         return (M <= 64 or _PATCH_SMALLC) and fill <= 1.2
     return fill <= _PATCH_FILL[0] or (fill <= _PATCH_FILL[1] and C >= 256)
@@ -289,6 +289,10 @@ _G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
 _NC8_S2_WGRAD_MIN_PIX = 16384
 _NC8_S2 = os.environ.get("C2M_NC8_S2", "1") != "0"           # bf16 4x4 stride-2 forward on the parity-plane kernel (A/B knob)
+# padded domains of the reflect data gradients: tile waste above which the NC8 gather form takes them (kernel times on one box,
+# patch kernel with the buffer-store two-target epilogue vs gather form: 66x130 domains, fill 1.34: 78 vs 111 us and 144 vs 151;
+# 34x66, fill 1.71: 106 vs 87; 18x34, fill 2.5: 68 vs 45)
+_NC8_DGRAD_FILL = float(os.environ.get("C2M_NC8_DGRAD_FILL", "1.5"))
 _NC8_S2_FILL_G8 = float(os.environ.get("C2M_NC8_S2_FILL_G8", "1.5"))      # stride-2 patch forms: largest tile waste where the gather form is the alternative
 _NC8_FILL = float(os.environ.get("C2M_NC8_FILL", "2.6"))      # (18x34 padded domains of the 16x32 reflect data gradients: 2.5; still 1.5x+ the gather kernel)
 _NC8_WGRAD = os.environ.get("C2M_NC8_WGRAD", "1") != "0"      # bf16 3x3 weight gradient from NC8 operands (A/B knob)
@@ -801,7 +805,7 @@ class _ConvPlan:
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
                     if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
-                            (_patch_bf16_ok(Cout, (1, 1, 1), Qy, Qx, dM) if bf16 else
+                            (_patch_bf16_ok(Cout, (1, 1, 1), Qy, Qx, dM, _NC8_DGRAD_FILL if (reflect and _G8) else None) if bf16 else
                              _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, dM)):
                         cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
