@@ -615,7 +615,8 @@ __global__ __launch_bounds__(256, WGS) void conv_gather_nc8_kernel(const ConvP p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-record DMAs of the tail still write LDS
 
-    // ---- epilogue: the mappings of conv_igemm_kernel with one row block of BM and the wave's 64 pixel columns
+    // ---- epilogue: the mappings of conv_igemm_kernel with one row block of BM and the wave's 64 pixel columns; buffer stores with
+    // per-pixel offsets for both targets (conv_store.h), rows past M masked per lane in the last row tile
     if ((p.g8_dbg & 2) && acc[0][0][0] != 12345.f) return;
     const bool direct = p.splits == 1;
     const bool yh = p.yh && direct;
@@ -623,66 +624,36 @@ __global__ __launch_bounds__(256, WGS) void conv_gather_nc8_kernel(const ConvP p
     float* __restrict__ Yb = yh ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(p.Y) + p.out_off_c[cls])
                                 : p.Y + (long)split * p.slab_stride + p.out_off_c[cls];
     const int po_t = p.po_c[cls][0], po_y = p.po_c[cls][1], po_x = p.po_c[cls][2];
-    if (m0 + BM <= p.M) {
-        unsigned voff[NI], voff2[NI];
-        bool ring = false;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int q = n0 + wave * 64 + j * 32 + (lane & 31);
-            int n, ot, oy, ox;
-            decompose_pix(q < p.Npix ? q : 0, p, n, ot, oy, ox);
-            const long e = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw +
-                           4L * (lane >> 5) * p.out_sc;
-            voff[j] = q < p.Npix ? (unsigned)(e * yes) : 0x80000000u;
-            voff2[j] = 0x80000000u;
-            if (p.Y2) {
-                const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y, xp = ox * p.ps_x + po_x - p.lo_x;
-                if (q < p.Npix && (unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y &&
-                    (unsigned)xp < (unsigned)p.ext_x) {
-                    const long e2 = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp + 4L * (lane >> 5) * p.y2_sc;
-                    voff2[j] = (unsigned)(e2 * yes);
-                    voff[j] = 0x80000000u;
-                }
-            }
-            ring = ring || voff[j] != 0x80000000u;
-        }
-        if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
-        if (!p.Y2 || __any(ring))
-            c2m_store_tile_fast<MI, NI>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
-        return;
-    }
+    unsigned voff[NI], voff2[NI];
+    bool ring = false;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int q = n0 + wave * 64 + j * 32 + (lane & 31);
-        if (q >= p.Npix) continue;
         int n, ot, oy, ox;
-        decompose_pix(q, p, n, ot, oy, ox);
-        float* ybase = Yb;
-        long yidx = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw;
-        long row_stride = p.out_sc;
+        decompose_pix(q < p.Npix ? q : 0, p, n, ot, oy, ox);
+        const long e = (long)n * p.out_sn + (long)ot * p.out_st + (long)oy * p.out_sh + (long)ox * p.out_sw +
+                       4L * (lane >> 5) * p.out_sc;
+        voff[j] = q < p.Npix ? (unsigned)(e * yes) : 0x80000000u;
+        voff2[j] = 0x80000000u;
         if (p.Y2) {
             const int tp = ot * p.ps_t + po_t - p.lo_t, yp = oy * p.ps_y + po_y - p.lo_y, xp = ox * p.ps_x + po_x - p.lo_x;
-            if ((unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
-                ybase = p.Y2;
-                yidx = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp;
-                row_stride = p.y2_sc;
+            if (q < p.Npix && (unsigned)tp < (unsigned)p.ext_t && (unsigned)yp < (unsigned)p.ext_y &&
+                (unsigned)xp < (unsigned)p.ext_x) {
+                const long e2 = (long)n * p.y2_sn + (long)tp * p.y2_st + (long)yp * p.y2_sh + xp + 4L * (lane >> 5) * p.y2_sc;
+                voff2[j] = (unsigned)(e2 * yes);
+                voff[j] = 0x80000000u;
             }
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p.M) {
-                    float v = acc[i][j][r];
-                    if (direct) {
-                        if (p.bias) v += p.bias[row];
-                        v = c2m_act(v, p.act, p.slope);
-                    }
-                    if (yh) reinterpret_cast<bf16_t*>(ybase)[yidx + (long)row * row_stride] = (bf16_t)v;
-                    else ybase[yidx + (long)row * row_stride] = v;
-                }
-            }
+        ring = ring || voff[j] != 0x80000000u;
+    }
+    if (m0 + BM <= p.M) {
+        if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
+        if (!p.Y2 || __any(ring))
+            c2m_store_tile_fast<MI, NI>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
+    } else {
+        if (p.Y2) c2m_store_tile_fast<MI, NI, true>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh, p.M);
+        if (!p.Y2 || __any(ring))
+            c2m_store_tile_fast<MI, NI, true>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh, p.M);
     }
 }
 

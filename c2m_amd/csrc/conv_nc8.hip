@@ -366,10 +366,11 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         }
         return;
     }
-    if (p.Y2 && m0 + BM <= p.M  && p.T == 1) {
-        // two-target launches (reflect data gradient over the padded domain) with whole row tiles: the buffer-store epilogue of the
-        // gather kernels (conv_store.h) -- one pass per target with the other target's pixels out of range, no per-element address
-        // arithmetic.  The generic form below cost a third of the launch on the full-resolution layers (32 -> 32 at 128x256: data
+    if (!p.Y2 || p.T == 1) {
+        // launches that cannot take the 16-byte stores above -- two-target launches (reflect data gradient over the padded
+        // domain), output widths off the 8-pixel grid (the spatially padded target of a 3x3x3 reflect data gradient) -- use the
+        // buffer-store epilogue of the gather kernels (conv_store.h): one pass per target with the other target's pixels out of
+        // range, no per-element address arithmetic.  The generic form below cost a third of the launch on the full-resolution layers (32 -> 32 at 128x256: data
         // gradient 148 us against 81 us for the forward of the same shape).
         const int yes = yh ? 2 : 4;
         unsigned voff[NI], voff2[NI];
@@ -378,19 +379,25 @@ __global__ __launch_bounds__(256, WGS) void conv_patch_nc8_kernel(const Nc8P p) 
         for (int j = 0; j < NI; ++j) {
             const int oy = oy0 + wave * NI + j, ox = ox0 + (lane & 31);
             const bool valid = oy < p.Ho && ox < p.Wo;
-            const long e = p.out_off + (long)n_smp * p.out_sn + (long)oy * p.out_sh + ox + 4L * (lane >> 5) * p.out_sc;
+            const long e = p.out_off + (long)n_smp * p.out_sn + (long)t_img * p.out_st + (long)oy * p.out_sh + ox + 4L * (lane >> 5) * p.out_sc;
             voff[j] = valid ? (unsigned)(e * yes) : 0x80000000u;
             voff2[j] = 0x80000000u;
             const int yp = oy * p.ps_y + p.po_y - p.lo_y, xp = ox * p.ps_x + p.po_x - p.lo_x;
-            if (valid && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
+            if (p.Y2 && valid && (unsigned)yp < (unsigned)p.ext_y && (unsigned)xp < (unsigned)p.ext_x) {
                 const long e2 = (long)n_img * p.y2_sn + (long)yp * p.y2_sh + xp + 4L * (lane >> 5) * p.y2_sc;
                 voff2[j] = (unsigned)(e2 * yes);
                 voff[j] = 0x80000000u;
             }
             ring = ring || voff[j] != 0x80000000u;
         }
-        c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
-        if (__any(ring)) c2m_store_tile_fast<MI, NI>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
+        if (m0 + BM <= p.M) {
+            if (p.Y2) c2m_store_tile_fast<MI, NI>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh);
+            if (!p.Y2 || __any(ring)) c2m_store_tile_fast<MI, NI>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh);
+        } else {                                           // last row tile hangs over M: rows masked per lane
+            if (p.Y2) c2m_store_tile_fast<MI, NI, true>(acc, p.Y2, voff2, m0, p.y2_sc, nullptr, false, 0, 0.f, lane, yh, p.M);
+            if (!p.Y2 || __any(ring))
+                c2m_store_tile_fast<MI, NI, true>(acc, Yb, voff, m0, p.out_sc, p.bias, direct, p.act, p.slope, lane, yh, p.M);
+        }
         return;
     }
 #pragma unroll

@@ -22,12 +22,14 @@ def _bf(t):
 @pytest.fixture(autouse=True)
 def _bf16_mode():
     prev = ops.set_conv_precision("bf16")
-    v0, p0, f0 = ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX, ops._NC8_S2_FILL_G8
+    v0, p0, f0, d0 = ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX, ops._NC8_S2_FILL_G8, ops._NC8_DGRAD_FILL
     ops._NC8_S2_WGRAD_MIN_PIX = 0          # (the small test maps would otherwise stay on the NCHW weight-gradient kernel)
-    ops._NC8_S2_FILL_G8 = ops._NC8_FILL    # (half-filled stride-2 tiles stay on the stride-2 forms here; the gather form has tests/test_gpu_g8.py)
+    # (half-filled stride-2 tiles and padded data-gradient domains stay on the patch forms here -- their two-target / ragged-row
+    # epilogues are what these cases are for; the gather form has tests/test_gpu_g8.py)
+    ops._NC8_S2_FILL_G8 = ops._NC8_DGRAD_FILL = ops._NC8_FILL
     ops._geom_cache.clear()
     yield
-    ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX, ops._NC8_S2_FILL_G8 = v0, p0, f0
+    ops._NC8_VARIANT, ops._NC8_S2_WGRAD_MIN_PIX, ops._NC8_S2_FILL_G8, ops._NC8_DGRAD_FILL = v0, p0, f0, d0
     ops._geom_cache.clear()
     ops.set_conv_precision(prev)
 
