@@ -284,6 +284,7 @@ _NC8_VARIANT = int(os.environ.get("C2M_NC8_VARIANT", "0"))      # tile / bufferi
 _NC8_NORM = os.environ.get("C2M_NC8_NORM", "0") != "0"
 # NC8 gather kernel (conv_gather_nc8_kernel, conv_igemm.hip): every bf16 forward / data gradient the NC8 patch forms do not take
 _NC8_LOG = None
+_NC8_LOG_TAG = [""]          # (tools/nc8_producers.py: what made the gradient tensor a backward conversion sees)
 _G8 = os.environ.get("C2M_G8", "1") != "0"
 _G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
@@ -349,7 +350,7 @@ def _to_nc8(x, keep=None):
     sp = tuple(x.shape[2:])                 # (H, W), or (T, H, W): the pixel axis of the layout pass is everything behind C
     if _NC8_LOG is not None:                # tools/nc8_producers.py: who produced the tensors that need a layout pass
         fn = x.grad_fn
-        _NC8_LOG.append((type(fn).__name__ if fn is not None else ("leaf" if torch.is_grad_enabled() else "backward"), tuple(x.shape)))
+        _NC8_LOG.append((type(fn).__name__ if fn is not None else ("leaf" if torch.is_grad_enabled() else "backward" + _NC8_LOG_TAG[0]), tuple(x.shape)))
     y = torch.empty((N, _cdiv(C, 8)) + sp + (8,), device=x.device, dtype=BF16)
     _lib.check(_lib.lib().c2m_nchw_to_nc8(_p(x), _p(y), N, C, int(np.prod(sp)), _stream()), "nchw_to_nc8")
     if keep is not None:
@@ -1385,6 +1386,8 @@ class _ConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         pl, L = ctx.pl, _lib.lib()
         gy = _f(gy)
+        if _NC8_LOG is not None:
+            _NC8_LOG_TAG[0] = " (own act_bwd)" if ACT[ctx.act] else " (incoming gradient)"
         if ACT[ctx.act]:
             gy = _as(gy, y.dtype)
             g = torch.empty_like(gy)
@@ -1553,6 +1556,8 @@ class _ConvReluTapFn(torch.autograd.Function):
         gy = None if gy is None else _as(gy, y.dtype)
         g = torch.empty_like(y)
         _lib.check(_lib.lib().c2m_relu_tap_bwd(_p(y), _p(t), _p(gy), _p(gl), _p(g), y.numel(), _dt(y), _stream()), "relu_tap_bwd")
+        if _NC8_LOG is not None:
+            _NC8_LOG_TAG[0] = " (relu_tap_bwd)"
         return _conv_dgrad(ctx.pl, w, g, True, ctx.x_dtype), None, None, None, None
 
 
