@@ -1400,7 +1400,8 @@ class _ConvFn(torch.autograd.Function):
         # split reductions) is issued on a side stream and joined at the end of this node, so the two launches share the chip
         # -- the tail of one (e.g. 1440 workgroups on 512 slots) is filled by the other and the ~10 us reductions disappear
         # behind MFMA kernels.  Fork / join are events, so a HIP-graph capture records the same parallel branches.
-        side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and pl.bf16 and torch.cuda.is_current_stream_capturing())
+        # (inside a capture for both precisions: fp32 configs[1] as a replay 66.6 -> 66.1 ms on one box, `bench.py --graph`)
+        side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and torch.cuda.is_current_stream_capturing())
         side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
         # NC8 form of dY: one layout pass shared by the data gradient and the weight gradient of this node (made on the main
         # stream BEFORE a fork, so the side stream's launch is ordered behind it)
