@@ -18,6 +18,7 @@
 #include "common.h"
 #include "dtype.h"
 #include "conv_store.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -839,7 +840,8 @@ static void wgrad_nc8_shape(int M, int C, long N, int H, int W, int s2, int& Mp,
     Mp = c2m_cdiv(M, 64) * 64; Cp = c2m_cdiv(C, 32) * 32;
     nchunks = N * c2m_cdiv(H, 4) * c2m_cdiv(W, 32);
     const long tiles = (long)(Mp / 64) * (Cp / 32) * (s2 ? 2 : 1);
-    long s = (768 + tiles - 1) / tiles;                           // ~1.5 resident rounds of 512 workgroups ...
+    static const long target = getenv("C2M_WGRAD_NC8_WGS") ? atol(getenv("C2M_WGRAD_NC8_WGS")) : 768;      // (tuning knob)
+    long s = (target + tiles - 1) / tiles;                        // ~1.5 resident rounds of 512 workgroups ...
     // ... but >= 16 chunks (2048 pixels, ~10 us of MFMAs) per split: every workgroup writes a 73 KB slab that is read back
     const long maxs = nchunks / 16 > 0 ? nchunks / 16 : 1;
     if (s > maxs) s = maxs;
