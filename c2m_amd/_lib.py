@@ -64,6 +64,7 @@ _SIGS = {
     "c2m_norm_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_norm_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_int, c_void_p]),
+    "c2m_grad_to_nc8": (c_int, [c_int] + [c_void_p] * 5 + [c_long, c_int, c_long, c_long, c_int, c_float, c_void_p]),
     "c2m_resample2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "c2m_channelnorm_fwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "c2m_correlation_out_size": (c_int, [c_int] * 5),

@@ -709,3 +709,72 @@ C2M_API int c2m_act_bwd(const void* y, const void* gy, void* gx, long total, int
                                (const T*)gy, (T*)gx, total, act, slope););
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------- gradients straight into NC8 (round 4)
+// The two element-wise kernels that produce the dY a bf16 convolution's backward consumes -- the convolution's own activation
+// backward (act_bwd) and the perceptual-loss tap backward of the VGG chain (losses.hip: relu_tap_bwd) -- with their result written
+// in the channel-blocked layout of conv_nc8.hip INSTEAD of NCHW: the caller uses them only where every consumer of that gradient
+// reads the NC8 form (ops._ConvFn.backward, ops._ConvReluTapFn.backward), so the NCHW write and the layout pass over it disappear.
+// Thread = 8 channels x 8 pixels (as nchw_to_nc8_kernel); same fp32 arithmetic per element, one RNE rounding to bf16.
+// MODE 0: g = act_bwd_elem(y, gy);  MODE 1: g = y > 0 ? gy + (gl / total) * sign(y - t) : 0  (gy may be null: 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void grad_to_nc8_kernel(const uint4* __restrict__ y, const uint4* __restrict__ t,
+                                                          const uint4* __restrict__ gy, const float* __restrict__ gl,
+                                                          uint4* __restrict__ gn, int C, int CB, long S8, long total, long count,
+                                                          int act, float slope) {
+    const float lg = MODE == 1 ? gl[0] / (float)count : 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i % S8, ncb = i / S8;
+        const int cb = (int)(ncb % CB); const long n = ncb / CB;
+        unsigned r[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb * 8 + j;
+            r[j][0] = r[j][1] = r[j][2] = r[j][3] = 0u;
+            if (c < C) {
+                const long q = (n * C + c) * S8 + g;
+                float yv[8], gv[8], tv[8], o[8];
+                nc8_unpack8(y[q], yv);
+                if (gy) nc8_unpack8(gy[q], gv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+                }
+                if (MODE == 1) nc8_unpack8(t[q], tv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (MODE == 0) o[e] = act_bwd_elem(yv[e], gv[e], act, slope);
+                    else {
+                        const float d = yv[e] - tv[e];
+                        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                        o[e] = yv[e] > 0.f ? gv[e] + lg * sgn : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[j][e] = nc8_pack2(o[2 * e], o[2 * e + 1]);
+            }
+        }
+        nc8_transpose_store(r, gn + ((n * CB + cb) * S8 + g) * 8);
+    }
+}
+
+// y, gy (and t): bf16 [N][C][S] with S % 8 == 0, 16-byte aligned; g_nc8: [N][ceil(C/8)][S][8] bf16.  mode 0: act / slope as
+// c2m_act_bwd; mode 1: t, gl, count (= the element count the tap's mean ran over) as c2m_relu_tap_bwd, gy may be NULL.
+C2M_API int c2m_grad_to_nc8(int mode, const void* y, const void* t, const void* gy, const float* gl, void* g_nc8, long N, int C,
+                            long S, long count, int act, float slope, void* stream) {
+    C2M_ENTER();
+    if (N <= 0 || C <= 0 || S <= 0) return 0;
+    if ((S & 7) || ((((uintptr_t)y) | ((uintptr_t)t) | ((uintptr_t)gy) | ((uintptr_t)g_nc8)) & 15) || (mode != 0 && mode != 1) ||
+        (mode == 0 && !gy) || (mode == 1 && (!t || !gl || count <= 0)))
+        return (int)hipErrorInvalidValue;
+    const int CB = (C + 7) / 8;
+    const long total = N * CB * (S / 8);
+    if (mode == 0)
+        hipLaunchKernelGGL(grad_to_nc8_kernel<0>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)y,
+                           (const uint4*)t, (const uint4*)gy, gl, (uint4*)g_nc8, C, CB, S / 8, total, count, act, slope);
+    else
+        hipLaunchKernelGGL(grad_to_nc8_kernel<1>, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)y,
+                           (const uint4*)t, (const uint4*)gy, gl, (uint4*)g_nc8, C, CB, S / 8, total, count, act, slope);
+    return (int)hipGetLastError();
+}
+

@@ -285,6 +285,8 @@ _NC8_NORM = os.environ.get("C2M_NC8_NORM", "0") != "0"
 # NC8 gather kernel (conv_gather_nc8_kernel, conv_igemm.hip): every bf16 forward / data gradient the NC8 patch forms do not take
 _NC8_LOG = None
 _NC8_LOG_TAG = [""]          # (tools/nc8_producers.py: what made the gradient tensor a backward conversion sees)
+_NC8_GRAD = os.environ.get("C2M_NC8_GRAD", "1") != "0"      # act_bwd / tap backward write NC8 only where every reader is an NC8 kernel
+_NC8_POISON = os.environ.get("C2M_NC8_POISON", "0") == "1"  # debug: the unused NCHW storage of such gradients is NaN
 _G8 = os.environ.get("C2M_G8", "1") != "0"
 _G8_VARIANT = int(os.environ.get("C2M_G8_VARIANT", "0"))
 _NC8_3D = os.environ.get("C2M_NC8_3D", "1") != "0"           # bf16 3x3x3 layers on the NC8 kernels (A/B knob)
@@ -917,6 +919,31 @@ class _ConvPlan:
                 grp["g8tab"] = torch.cat([c["g8tab"] for c in cl[grp["first"]:grp["first"] + grp["ncls"]]])
 
 
+def _bwd_reads_only_nc8(pl, need_x, need_w):
+    """True when every kernel of this bf16 layer's backward reads the output gradient in its NC8 form (conv_nc8.hip / the NC8 gather
+    form): the gradient then need not exist in NCHW at all (`_virtual_grad`)."""
+    if not (pl.bf16 and _NC8 and _NC8_GRAD and (pl.dims[6] * pl.dims[7] * pl.dims[8]) % 8 == 0):
+        return False
+    if need_x:
+        patch_nc8 = bool(pl.classes) and all(c["patch"] for c in pl.classes) and not pl.is3d and (pl.dims[7] * pl.dims[8]) % 8 == 0
+        if not (pl.k333_dgrad_nc8 or pl.s2_dgrad_nc8 or pl.g8_dgrad or patch_nc8):
+            return False
+    if need_w and not (pl.k333_wgrad_nc8 or pl.wgrad_nc8 or pl.s2_wgrad_nc8):
+        return False
+    return True
+
+
+def _virtual_grad(like, gn):
+    """A gradient that exists in NC8 form only: a tensor object of the NCHW shape that carries `gn` for `_to_nc8` and whose own
+    storage is never written or read (C2M_NC8_POISON=1 fills it with NaN -- the tests run the steps that way: a kernel that read
+    it would poison the losses)."""
+    g = torch.empty_like(like)
+    if _NC8_POISON:
+        g.fill_(float("nan"))
+    g._c2m_nc8 = (g._version, gn)
+    return g
+
+
 def _plan(x, w, stride, pad, reflect, dgrad_rows=None):
     key = (tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device.index, _conv_bf16, dgrad_rows)
     pl = _geom_cache.get(key)
@@ -1390,9 +1417,18 @@ class _ConvFn(torch.autograd.Function):
             _NC8_LOG_TAG[0] = " (own act_bwd)" if ACT[ctx.act] else " (incoming gradient)"
         if ACT[ctx.act]:
             gy = _as(gy, y.dtype)
-            g = torch.empty_like(gy)
-            _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], ctx.slope, _dt(y), _stream()), "act_bwd")
-            gy = g
+            need_w0 = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+            if y.dtype == BF16 and _bwd_reads_only_nc8(pl, ctx.needs_input_grad[0], need_w0):
+                # the masked gradient in NC8 form only: its readers below are all NC8 kernels (no NCHW write, no layout pass)
+                Nn, Cc = y.shape[0], y.shape[1]
+                gn = torch.empty((Nn, _cdiv(Cc, 8)) + tuple(y.shape[2:]) + (8,), device=y.device, dtype=BF16)
+                _lib.check(L.c2m_grad_to_nc8(0, _p(y), None, _p(gy), None, _p(gn), Nn, Cc, y.numel() // (Nn * Cc), 0, ACT[ctx.act],
+                                             ctx.slope, _stream()), "grad_to_nc8 (act_bwd)")
+                gy = _virtual_grad(y, gn)
+            else:
+                g = torch.empty_like(gy)
+                _lib.check(L.c2m_act_bwd(_p(y), _p(gy), _p(g), gy.numel(), ACT[ctx.act], ctx.slope, _dt(y), _stream()), "act_bwd")
+                gy = g
         N, Cin, Cout = pl.dims[0:3]
         gx = gw = gb = None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
@@ -1555,6 +1591,12 @@ class _ConvReluTapFn(torch.autograd.Function):
             gl = torch.zeros((), device=y.device, dtype=torch.float32)
         gl = _f(gl.reshape(1).float())
         gy = None if gy is None else _as(gy, y.dtype)
+        if y.dtype == BF16 and _bwd_reads_only_nc8(ctx.pl, True, False):
+            Nn, Cc = y.shape[0], y.shape[1]
+            gn = torch.empty((Nn, _cdiv(Cc, 8)) + tuple(y.shape[2:]) + (8,), device=y.device, dtype=BF16)
+            _lib.check(_lib.lib().c2m_grad_to_nc8(1, _p(y), _p(t), _p(gy), _p(gl), _p(gn), Nn, Cc, y.numel() // (Nn * Cc), y.numel(),
+                                                  0, 0.0, _stream()), "grad_to_nc8 (relu_tap_bwd)")
+            return _conv_dgrad(ctx.pl, w, _virtual_grad(y, gn), True, ctx.x_dtype), None, None, None, None
         g = torch.empty_like(y)
         _lib.check(_lib.lib().c2m_relu_tap_bwd(_p(y), _p(t), _p(gy), _p(gl), _p(g), y.numel(), _dt(y), _stream()), "relu_tap_bwd")
         if _NC8_LOG is not None:

@@ -225,6 +225,12 @@ int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* 
                  const float* beta, const void* gb, void* ggb, float* dgamma, float* dbeta, void* dx, void* dx_nc8,
                  float* workspace, int N, int C, long S, int mode, int act, float slope, int dt, void* stream);
 int c2m_act_bwd(const void* y, const void* gy, void* gx, long total, int act, float slope, int dt, void* stream);
+/* The same gradient (mode 0), or the perceptual-loss tap backward of c2m_relu_tap_bwd (mode 1: t, gl, count = the tap's element
+ * count, gy may be NULL), written in the NC8 layout of the bf16 convolutions INSTEAD of NCHW ([N][ceil(C/8)][S][8] bf16; y / t / gy
+ * bf16 [N][C][S], S % 8 == 0): for gradients whose only readers are NC8 convolution kernels (round 4; the layout pass and the NCHW
+ * write disappear).  Same fp32 arithmetic per element as the NCHW kernels. */
+int c2m_grad_to_nc8(int mode, const void* y, const void* t, const void* gy, const float* gl, void* g_nc8, long N, int C, long S,
+                    long count, int act, float slope, void* stream);
 
 /* ---- optical-flow warping / resampling (warp.hip) -----------------------------------------------------------
  * utils/ops.py:183-202 resample()/get_grid()/grid_sample() and its backward; callers generator.py:86,

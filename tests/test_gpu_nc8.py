@@ -306,3 +306,59 @@ def _norm_side_output_case(kind, N, C, H, W):
     assert seen["side"] is not None and seen["side"][0] == seen["dx"]._version
     dref = seen["dx"].view(N, C // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
     assert torch.equal(seen["side"][1], dref), "backward side output = NC8 form of dx"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 16), (3, 21, 4, 8), (1, 64, 2, 6, 8)])
+def test_grad_to_nc8_matches_the_nchw_kernel_plus_layout_pass(shape, mode):
+    """c2m_grad_to_nc8 (the convolution's own activation backward, mode 0; the VGG tap backward, mode 1) writes bit for bit what
+    c2m_act_bwd / c2m_relu_tap_bwd followed by c2m_nchw_to_nc8 write."""
+    from c2m_amd import _lib
+    L = _lib.lib()
+    y = rnd(101, *shape).to(DEV).bfloat16()
+    gy = rnd(102, *shape).to(DEV).bfloat16()
+    t = rnd(103, *shape).to(DEV).bfloat16()
+    gl = torch.tensor([0.37], device=DEV)
+    N, C = shape[0], shape[1]
+    S = y.numel() // (N * C)
+    gn = torch.empty((N, (C + 7) // 8) + tuple(shape[2:]) + (8,), device=DEV, dtype=torch.bfloat16)
+    ref = torch.empty_like(y)
+    if mode == 0:
+        _lib.check(L.c2m_act_bwd(ops._p(y), ops._p(gy), ops._p(ref), y.numel(), ops.ACT["lrelu"], 0.2, 1, ops._stream()), "act_bwd")
+        _lib.check(L.c2m_grad_to_nc8(0, ops._p(y), None, ops._p(gy), None, ops._p(gn), N, C, S, 0, ops.ACT["lrelu"], 0.2, ops._stream()), "g")
+    else:
+        _lib.check(L.c2m_relu_tap_bwd(ops._p(y), ops._p(t), ops._p(gy), ops._p(gl), ops._p(ref), y.numel(), 1, ops._stream()), "tap")
+        _lib.check(L.c2m_grad_to_nc8(1, ops._p(y), ops._p(t), ops._p(gy), ops._p(gl), ops._p(gn), N, C, S, y.numel(), 0, 0.0, ops._stream()), "g")
+    assert torch.equal(gn, ops._to_nc8(ref))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 16, 32, 64, 1, "reflect"), (2, 64, 16, 32, 64, 2, "reflect"), (1, 32, 24, 64, 64, 1, "zeros")])
+def test_activation_backward_in_nc8_only_is_bit_identical_and_never_reads_its_nchw_storage(case):
+    """A bf16 convolution with a fused activation whose backward runs on NC8 kernels only: the masked gradient exists in NC8 form
+    alone (ops._virtual_grad).  Same data / weight / bias gradients, bit for bit, as with the NCHW act_bwd + layout pass -- also
+    with the unused NCHW storage poisoned with NaN."""
+    N, Cin, H, W, Cout, stride, mode = case
+    k = 3 if stride == 1 else 4
+    x = _bf(rnd(111, N, Cin, H, W)).to(DEV).bfloat16()
+    w = _bf(rnd(112, Cout, Cin, k, k, scale=(1.0 / (Cin * k * k)) ** 0.5)).to(DEV)
+    b = rnd(113, Cout, scale=0.1).to(DEV)
+    outs = []
+    for grad_nc8, poison in ((False, False), (True, False), (True, True)):
+        ops._NC8_GRAD, ops._NC8_POISON = grad_nc8, poison
+        ops._geom_cache.clear()
+        try:
+            xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            pl = ops._plan(xg, wg, (1, stride, stride), (0, 1, 1), mode == "reflect")
+            elig = ops._bwd_reads_only_nc8(pl, True, True)
+            assert elig == grad_nc8 or not grad_nc8, "the case must be eligible when the knob is on"
+            if grad_nc8:
+                assert elig
+            y = ops.conv(xg, wg, bg, stride=stride, padding=1, padding_mode=mode, act="lrelu")
+            y.backward(_bf(rnd(114, *y.shape)).to(DEV).bfloat16())
+            outs.append((xg.grad.clone(), wg.grad.clone(), bg.grad.clone()))
+        finally:
+            ops._NC8_GRAD, ops._NC8_POISON = True, False
+            ops._geom_cache.clear()
+    for o in outs[1:]:
+        for a, b_ in zip(outs[0], o):
+            assert torch.isfinite(b_).all() and torch.equal(a, b_)
