@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void norm_apply_nc8_kernel(const ApplyP<bf16_t
                 for (int e = 0; e < 8; ++e) o[e] = c2m_act((xv[e] - mean) * invstd * sc[e] + sh[e], p.act, p.slope);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[j][e] = nc8_pack2(o[2 * e], o[2 * e + 1]);
-                y4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);
+                if (y4) y4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);      // (NULL: the NC8 form is the only output)
             }
         }
         nc8_transpose_store(r, yn + (((long)n * CB + cb) * S8 + g) * 8);

@@ -64,8 +64,16 @@ def flush_batch_counters():
         torch._foreach_add_(ts, cs)
 
 
-def batch_norm_module(x, bn, act=None):
-    """nn.BatchNorm{1,2,3}d container, train mode: batch statistics + running-stat update, fused activation."""
+def feeds_conv(conv, padding=None, padding_mode=None):
+    """`feeds=` of the norm helpers below: the ONE convolution container that reads the norm's result (ops.conv_consumer)."""
+    pad = conv.padding if padding is None else padding
+    mode = conv.padding_mode if padding_mode is None else padding_mode
+    return ops.conv_consumer(conv.weight, tuple(conv.stride), tuple(pad) if not isinstance(pad, int) else pad, mode)
+
+
+def batch_norm_module(x, bn, act=None, feeds=None):
+    """nn.BatchNorm{1,2,3}d container, train mode: batch statistics + running-stat update, fused activation.
+    feeds: `feeds_conv(...)` when the result goes into exactly one convolution and nowhere else (ops.conv_consumer)."""
     if bn.training:
         if not _defer_counters:
             bn.num_batches_tracked += 1
@@ -75,7 +83,7 @@ def batch_norm_module(x, bn, act=None):
                 _pending_counters[id(bn.num_batches_tracked)] = [bn.num_batches_tracked, 1]
             else:
                 ent[1] += 1
-        return ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, bn.eps, bn.momentum)
+        return ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, bn.eps, bn.momentum, feeds)
     # eval: running statistics (inference path) -- scale/shift folded into the same apply kernel
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     return ops.norm_apply_eval(x, bn.running_mean, invstd, bn.weight, bn.bias, act)

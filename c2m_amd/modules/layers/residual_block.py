@@ -2,7 +2,7 @@
 ReflectionPad2d before each conv is folded into the conv gather; norm+activation are fused kernels."""
 import torch.nn as nn
 
-from .common import conv_module, batch_norm_module
+from .common import conv_module, batch_norm_module, feeds_conv
 from .spade_block import SpatiallyAdaptiveNorm
 
 
@@ -17,9 +17,10 @@ class ResidualBlock(nn.Module):
         self._pad = padding
 
     def forward(self, x):
-        out = batch_norm_module(x, self.norm1, act="relu")
+        # (each norm result is read by the convolution behind it and by nothing else: feeds -> NC8-only output where that pays)
+        out = batch_norm_module(x, self.norm1, act="relu", feeds=feeds_conv(self.conv1, self._pad, "reflect"))
         out = conv_module(out, self.conv1, padding=self._pad, padding_mode="reflect")
-        out = batch_norm_module(out, self.norm2, act="relu")
+        out = batch_norm_module(out, self.norm2, act="relu", feeds=feeds_conv(self.conv2, self._pad, "reflect"))
         out = conv_module(out, self.conv2, padding=self._pad, padding_mode="reflect")
         return out + x
 
@@ -41,11 +42,11 @@ class ResidualSpadeBlock(nn.Module):
         self._pad = padding
 
     def forward(self, x, *cond_inputs):
-        dx = self.norm1(x, *cond_inputs, act="lrelu")
+        dx = self.norm1(x, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv1, self._pad, "reflect"))
         dx = conv_module(dx, self.conv1, padding=self._pad, padding_mode="reflect")
-        dx = self.norm2(dx, *cond_inputs, act="lrelu")
+        dx = self.norm2(dx, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv2, self._pad, "reflect"))
         dx = conv_module(dx, self.conv2, padding=self._pad, padding_mode="reflect")
         if self.learned_shortcut:
-            x_s = self.norm_s(x, *cond_inputs, act="lrelu")
+            x_s = self.norm_s(x, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv_s))
             return dx + conv_module(x_s, self.conv_s)
         return dx

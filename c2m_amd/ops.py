@@ -343,6 +343,8 @@ def _to_nc8(x, keep=None):
     the weight gradient share the NC8 form of dY even when autograd hands them the gradient as a fresh tensor object)."""
     hit = getattr(x, "_c2m_nc8", None)
     if hit is not None and hit[0] == x._version and hit[1].device == x.device:
+        if keep is not None:
+            keep[x.data_ptr()] = (x, hit[1])       # (a tensor that exists in NC8 form only must never depend on the attribute alone)
         return hit[1]
     if keep is not None:
         hit = keep.get(x.data_ptr())
@@ -931,6 +933,25 @@ def _bwd_reads_only_nc8(pl, need_x, need_w):
     if need_w and not (pl.k333_wgrad_nc8 or pl.wgrad_nc8 or pl.s2_wgrad_nc8):
         return False
     return True
+
+
+def _fwd_reads_only_nc8(pl, need_w):
+    """True when the forward AND the weight gradient of this bf16 layer read the input in its NC8 form only (the data gradient never
+    reads the input): an activation whose single consumer is this layer need not exist in NCHW (`feeds=` of the norm ops)."""
+    if not (pl.bf16 and _NC8 and _NC8_GRAD and (pl.dims[3] * pl.dims[4] * pl.dims[5]) % 8 == 0):
+        return False
+    if not (pl.k333_nc8 or pl.s2_nc8 or (pl.fwd_patch and pl.nc8) or pl.g8_fwd):
+        return False
+    if need_w and not (pl.k333_wgrad_nc8 or pl.wgrad_nc8 or pl.s2_wgrad_nc8):
+        return False
+    return True
+
+
+def conv_consumer(conv_w, stride=1, padding=0, padding_mode="zeros"):
+    """`feeds=` argument of batch_norm_act / instance_norm_act / spade_norm_act: the ONE convolution that consumes the op's result
+    (the caller guarantees nothing else reads it -- `out = norm(x); out = conv(out)` inside a block).  Where that layer's forward and
+    weight gradient run on NC8 kernels the result is produced in NC8 form only."""
+    return (conv_w, stride, padding, padding_mode)
 
 
 def _virtual_grad(like, gn):
@@ -1715,7 +1736,7 @@ class _NormActFn(torch.autograd.Function):
     """y = act(norm(x) * scale + shift); mode 0 instance / 1 batch statistics; gb = SPADE [N,2C,...] map or None."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum):
+    def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum, feeds=None):
         _dev(x, gamma, beta, gb)
         x = _f(x)
         ctx.gb_dtype = gb.dtype if gb is not None else None
@@ -1734,9 +1755,19 @@ class _NormActFn(torch.autograd.Function):
         # bf16 data path: activations of conv-sized maps are ALSO written in the NC8 layout of the convolution they feed (and, in
         # backward, the gradient they hand to the convolution in front): conv_nc8.hip then needs no layout pass of its own
         ctx.nc8 = bool(_NC8 and _NC8_NORM and dt == 1 and x.dim() == 4 and S % 8 == 0 and C >= 16 and x.shape[3] >= 16 and S >= 512)
-        yn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if ctx.nc8 else None
-        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(y), _p(yn), N, C, S, mode,
-                                    ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
+        # `feeds`: the result's only consumer is one convolution whose forward and weight gradient read NC8 -> NC8 is the ONLY output
+        only = False
+        if feeds is not None and dt == 1 and S % 8 == 0:
+            cw, cstride, cpad, cmode = feeds
+            nd = x.dim() - 2
+            pad3 = _pad3(cpad, nd)
+            cpl = _plan(x, _f(cw), _triple(cstride, nd), pad3, cmode == "reflect" and any(pad3), None)
+            only = _fwd_reads_only_nc8(cpl, cw.requires_grad)
+        yn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if (ctx.nc8 or only) else None
+        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), None if only else _p(y), _p(yn), N, C, S,
+                                    mode, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
+        if only and _NC8_POISON:
+            y.fill_(float("nan"))
         ctx.cfg = (N, C, S, mode, act)
         ctx.save_for_backward(x, gamma, beta, gb, mean, invstd)
         if yn is None:
@@ -1763,7 +1794,7 @@ class _NormActFn(torch.autograd.Function):
             dx._c2m_nc8 = (dx._version, dxn)      # autograd hands this very tensor object to the convolution's backward (see _to_nc8)
         if ggb is not None and ggb.dtype != ctx.gb_dtype:
             ggb = ggb.to(ctx.gb_dtype)
-        return dx, dgamma, dbeta, ggb, None, None, None, None, None, None
+        return dx, dgamma, dbeta, ggb, None, None, None, None, None, None, None
 
 
 def _norm_act(*args):
@@ -1773,17 +1804,18 @@ def _norm_act(*args):
     return y
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1):
-    return _norm_act(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1, feeds=None):
+    return _norm_act(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum, feeds)
 
 
-def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5):
-    return _norm_act(x, gamma, beta, None, None, None, 0, act, eps, 0.1)
+def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5, feeds=None):
+    return _norm_act(x, gamma, beta, None, None, None, 0, act, eps, 0.1, feeds)
 
 
-def spade_norm_act(x, gamma_beta, act=None, eps=1e-5):
-    """InstanceNorm(affine=False)(x) * (1 + gamma) + beta with [gamma, beta] = gamma_beta.chunk(2, 1), then act."""
-    return _norm_act(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1)
+def spade_norm_act(x, gamma_beta, act=None, eps=1e-5, feeds=None):
+    """InstanceNorm(affine=False)(x) * (1 + gamma) + beta with [gamma, beta] = gamma_beta.chunk(2, 1), then act.
+    feeds (all three ops): `conv_consumer(...)` of the one convolution that reads the result, see there."""
+    return _norm_act(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1, feeds)
 
 
 # =============================================================================================== warping / resampling

@@ -362,3 +362,35 @@ def test_activation_backward_in_nc8_only_is_bit_identical_and_never_reads_its_nc
     for o in outs[1:]:
         for a, b_ in zip(outs[0], o):
             assert torch.isfinite(b_).all() and torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("spade", [False, True])
+def test_residual_blocks_feed_their_convolutions_in_nc8_only(spade):
+    """ResidualBlock / ResidualSpadeBlock hand their norm + activation results to the convolution behind them as NC8-only tensors
+    (ops.conv_consumer): output and every gradient bit-identical to the NCHW hand-over, also with the unwritten NCHW storage
+    poisoned with NaN."""
+    from c2m_amd.modules.layers.residual_block import ResidualBlock, ResidualSpadeBlock
+    x = _bf(rnd(121, 2, 64, 16, 32)).to(DEV).bfloat16()
+    cond = _bf(rnd(122, 2, 16, 16, 32)).to(DEV).bfloat16()
+    outs = []
+    for grad_nc8, poison in ((False, False), (True, False), (True, True)):
+        ops._NC8_GRAD, ops._NC8_POISON = grad_nc8, poison
+        ops._geom_cache.clear()
+        try:
+            torch.manual_seed(3)
+            blk = (ResidualSpadeBlock(16, 64, 64, 3, 1, {}) if spade else ResidualBlock(64, 64, 3, 1)).to(DEV).train()
+            xg = x.clone().requires_grad_(True)
+            if grad_nc8:
+                w1 = blk.conv1.weight
+                pl = ops._plan(xg, w1, (1, 1, 1), (0, 1, 1), True)
+                assert ops._fwd_reads_only_nc8(pl, True), "the block's 3x3 layers must be eligible for an NC8-only input"
+            y = blk(xg, cond) if spade else blk(xg)
+            y.backward(_bf(rnd(123, *y.shape)).to(DEV).to(y.dtype))
+            outs.append([y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.grad is not None])
+        finally:
+            ops._NC8_GRAD, ops._NC8_POISON = True, False
+            ops._geom_cache.clear()
+    for o in outs[1:]:
+        assert len(o) == len(outs[0])
+        for a, b_ in zip(outs[0], o):
+            assert torch.isfinite(b_).all() and torch.equal(a, b_)
