@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_nc8_kernel(const BwdP<bf16
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[j][e] = nc8_pack2(o[2 * e], o[2 * e + 1]);
-                d4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);
+                if (d4) d4[plane * S8 + g] = make_uint4(r[j][0], r[j][1], r[j][2], r[j][3]);      // (NULL: dx exists in NC8 form only)
             }
         }
         nc8_transpose_store(r, dxn + (((long)n * CB + cb) * S8 + g) * 8);

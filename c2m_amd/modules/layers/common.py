@@ -71,7 +71,7 @@ def feeds_conv(conv, padding=None, padding_mode=None):
     return ops.conv_consumer(conv.weight, tuple(conv.stride), tuple(pad) if not isinstance(pad, int) else pad, mode)
 
 
-def batch_norm_module(x, bn, act=None, feeds=None):
+def batch_norm_module(x, bn, act=None, feeds=None, private_input=False):
     """nn.BatchNorm{1,2,3}d container, train mode: batch statistics + running-stat update, fused activation.
     feeds: `feeds_conv(...)` when the result goes into exactly one convolution and nowhere else (ops.conv_consumer)."""
     if bn.training:
@@ -83,14 +83,15 @@ def batch_norm_module(x, bn, act=None, feeds=None):
                 _pending_counters[id(bn.num_batches_tracked)] = [bn.num_batches_tracked, 1]
             else:
                 ent[1] += 1
-        return ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, bn.eps, bn.momentum, feeds)
+        return ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, bn.eps, bn.momentum, feeds,
+                                  private_input)
     # eval: running statistics (inference path) -- scale/shift folded into the same apply kernel
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     return ops.norm_apply_eval(x, bn.running_mean, invstd, bn.weight, bn.bias, act)
 
 
-def instance_norm_module(x, inorm, act=None):
-    return ops.instance_norm_act(x, inorm.weight, inorm.bias, act, inorm.eps)
+def instance_norm_module(x, inorm, act=None, feeds=None, private_input=False):
+    return ops.instance_norm_act(x, inorm.weight, inorm.bias, act, inorm.eps, feeds, private_input)
 
 
 def fold_time(x):

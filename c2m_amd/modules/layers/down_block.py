@@ -18,7 +18,7 @@ class DownBlock2d(nn.Module):
     def forward(self, x):
         if not self.use_norm:
             return conv_module(x, self.conv, act="lrelu")
-        return batch_norm_module(conv_module(x, self.conv), self.norm, act="lrelu")
+        return batch_norm_module(conv_module(x, self.conv), self.norm, act="lrelu", private_input=True)   # (the conv output is a temporary)
 
 
 class DownBlock3d(nn.Module):
@@ -39,4 +39,4 @@ class DownBlock3d(nn.Module):
         if not self.use_norm:
             return conv_module(x, self.conv, act="lrelu", padding=self._pad3, padding_mode="reflect")
         y = conv_module(x, self.conv, padding=self._pad3, padding_mode="reflect")
-        return batch_norm_module(y, self.norm, act="lrelu")
+        return batch_norm_module(y, self.norm, act="lrelu", private_input=True)

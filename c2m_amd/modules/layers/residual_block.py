@@ -20,7 +20,7 @@ class ResidualBlock(nn.Module):
         # (each norm result is read by the convolution behind it and by nothing else: feeds -> NC8-only output where that pays)
         out = batch_norm_module(x, self.norm1, act="relu", feeds=feeds_conv(self.conv1, self._pad, "reflect"))
         out = conv_module(out, self.conv1, padding=self._pad, padding_mode="reflect")
-        out = batch_norm_module(out, self.norm2, act="relu", feeds=feeds_conv(self.conv2, self._pad, "reflect"))
+        out = batch_norm_module(out, self.norm2, act="relu", feeds=feeds_conv(self.conv2, self._pad, "reflect"), private_input=True)
         out = conv_module(out, self.conv2, padding=self._pad, padding_mode="reflect")
         return out + x
 
@@ -44,7 +44,7 @@ class ResidualSpadeBlock(nn.Module):
     def forward(self, x, *cond_inputs):
         dx = self.norm1(x, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv1, self._pad, "reflect"))
         dx = conv_module(dx, self.conv1, padding=self._pad, padding_mode="reflect")
-        dx = self.norm2(dx, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv2, self._pad, "reflect"))
+        dx = self.norm2(dx, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv2, self._pad, "reflect"), private_input=True)
         dx = conv_module(dx, self.conv2, padding=self._pad, padding_mode="reflect")
         if self.learned_shortcut:
             x_s = self.norm_s(x, *cond_inputs, act="lrelu", feeds=feeds_conv(self.conv_s))

@@ -18,7 +18,7 @@ class SameBlock2d(nn.Module):
     def forward(self, x):
         if not self.use_norm:
             return conv_module(x, self.conv, act="lrelu")
-        return instance_norm_module(conv_module(x, self.conv), self.norm, act="lrelu")
+        return instance_norm_module(conv_module(x, self.conv), self.norm, act="lrelu", private_input=True)   # (the conv output is a temporary)
 
 
 class SameBlockTwoConv2d(nn.Module):
@@ -37,7 +37,7 @@ class SameBlockTwoConv2d(nn.Module):
 
     def forward(self, x):
         if self.use_norm:
-            y = instance_norm_module(conv_module(x, self.conv), self.norm, act="lrelu")
+            y = instance_norm_module(conv_module(x, self.conv), self.norm, act="lrelu", private_input=True)
         else:
             y = conv_module(x, self.conv, act="lrelu")
         return conv_module(y, self.conv2)
@@ -64,4 +64,4 @@ class SameBlock3d(nn.Module):
             return conv_module(x, self.conv, act="lrelu", padding=self._pad3, padding_mode="reflect",
                                dgrad_channels=dgrad_channels)
         y = conv_module(x, self.conv, padding=self._pad3, padding_mode="reflect", dgrad_channels=dgrad_channels)
-        return batch_norm_module(y, self.norm, act="lrelu")
+        return batch_norm_module(y, self.norm, act="lrelu", private_input=True)

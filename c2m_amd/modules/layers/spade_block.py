@@ -41,9 +41,9 @@ class SpatiallyAdaptiveNorm(nn.Module):
             h = layer(h) if isinstance(layer, SameBlock2d) else conv_module(h, layer)
         return h
 
-    def forward(self, x, *cond_inputs, act=None, feeds=None, **_kwargs):
+    def forward(self, x, *cond_inputs, act=None, feeds=None, private_input=False, **_kwargs):
         live = [(i, c) for i, c in enumerate(cond_inputs) if c is not None]
         if len(live) != 1 or self.bias_only:
             raise NotImplementedError("SPADE with other than one conditional map / bias_only is not on the C2M path")
         i, cond = live[0]
-        return ops.spade_norm_act(x, self._gamma_beta(i, cond, x.shape[2:]), act, self.norm.eps, feeds)
+        return ops.spade_norm_act(x, self._gamma_beta(i, cond, x.shape[2:]), act, self.norm.eps, feeds, private_input)

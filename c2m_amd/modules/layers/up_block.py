@@ -21,6 +21,6 @@ class UpBlock2d(nn.Module):
     def forward(self, x):
         flat = x if self.input_2d else fold_time(x)
         y = conv_module(ops.upsample2x(flat), self.main[1])
-        y = batch_norm_module(y, self.main[2], act="lrelu")
+        y = batch_norm_module(y, self.main[2], act="lrelu", private_input=True)       # (y: this block's conv output, read here only)
         # the reference hard-codes 5 predicted frames here (up_block.py:25)
         return unfold_time(y, 5) if self.reshape_3d else y

@@ -954,6 +954,17 @@ def conv_consumer(conv_w, stride=1, padding=0, padding_mode="zeros"):
     return (conv_w, stride, padding, padding_mode)
 
 
+def _tag_conv_output(ctx, pl, y, act):
+    """_ConvFn.forward: mark an output whose gradient this layer's backward will read through NC8 kernels only (no fused
+    activation: act_bwd reads the incoming gradient in NCHW).  A norm op told that it is the output's ONLY consumer
+    (`private_input=True`) then hands its dx back in NC8 form alone."""
+    if pl.bf16 and not ACT[act] and y.dtype == BF16:
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if _bwd_reads_only_nc8(pl, ctx.needs_input_grad[0], need_w):
+            y._c2m_bwd_nc8 = True
+    return y
+
+
 def _virtual_grad(like, gn):
     """A gradient that exists in NC8 form only: a tensor object of the NCHW shape that carries `gn` for `_to_nc8` and whose own
     storage is never written or read (C2M_NC8_POISON=1 fills it with NaN -- the tests run the steps that way: a kernel that read
@@ -1339,7 +1350,7 @@ class _ConvFn(torch.autograd.Function):
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
-            return y
+            return _tag_conv_output(ctx, pl, y, act)
         if pl.bf16 and pl.k333_nc8:
             x = _as(x, BF16)
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-k333",), lambda: _pack_bf16_k333(w, Cout, Cin))
@@ -1356,7 +1367,7 @@ class _ConvFn(torch.autograd.Function):
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv3d_nc8 fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
-            return y
+            return _tag_conv_output(ctx, pl, y, act)
         if pl.bf16 and pl.s2_nc8:
             x = _as(x, BF16)
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-s2",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 16, 2))
@@ -1374,7 +1385,7 @@ class _ConvFn(torch.autograd.Function):
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_s2_nc8 fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
-            return y
+            return _tag_conv_output(ctx, pl, y, act)
         if pl.bf16 and pl.g8_fwd:
             # the NC8 gather form: channel-blocked input, bf16 weights in (tap, chunk) order (conv_gather_nc8_kernel)
             x = _as(x, BF16)
@@ -1396,7 +1407,7 @@ class _ConvFn(torch.autograd.Function):
                                                slope, _dt(y), _stream()), "splitk_reduce")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
-            return y
+            return _tag_conv_output(ctx, pl, y, act)
         if pl.fwd_patch and pl.bf16:
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-patch",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 9))
         else:
@@ -1427,7 +1438,7 @@ class _ConvFn(torch.autograd.Function):
                                            slope, _dt(y), _stream()), "splitk_reduce")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
-        return y
+        return _tag_conv_output(ctx, pl, y, act)
 
     @staticmethod
     def backward(ctx, gy):
@@ -1736,7 +1747,7 @@ class _NormActFn(torch.autograd.Function):
     """y = act(norm(x) * scale + shift); mode 0 instance / 1 batch statistics; gb = SPADE [N,2C,...] map or None."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum, feeds=None):
+    def forward(ctx, x, gamma, beta, gb, running_mean, running_var, mode, act, eps, momentum, feeds=None, private_input=False):
         _dev(x, gamma, beta, gb)
         x = _f(x)
         ctx.gb_dtype = gb.dtype if gb is not None else None
@@ -1769,6 +1780,9 @@ class _NormActFn(torch.autograd.Function):
         if only and _NC8_POISON:
             y.fill_(float("nan"))
         ctx.cfg = (N, C, S, mode, act)
+        # x is the output of a convolution whose backward reads its gradient in NC8 only, and this op is x's only consumer (the
+        # caller's promise): dx is produced in NC8 form alone
+        ctx.dx_nc8_only = bool(private_input and _NC8_GRAD and dt == 1 and S % 8 == 0 and getattr(x, "_c2m_bwd_nc8", False))
         ctx.save_for_backward(x, gamma, beta, gb, mean, invstd)
         if yn is None:
             return y, None
@@ -1781,20 +1795,24 @@ class _NormActFn(torch.autograd.Function):
         N, C, S, mode, act = ctx.cfg
         L = _lib.lib()
         gy = _as(gy, x.dtype)
+        only = ctx.dx_nc8_only
         dx = torch.empty_like(x)
-        dxn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if ctx.nc8 else None
+        dxn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if (ctx.nc8 or only) else None
         ggb = torch.empty_like(gb) if gb is not None else None
         dgamma = torch.empty_like(gamma) if gamma is not None else None
         dbeta = torch.empty_like(beta) if gamma is not None else None
         ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
         _lib.check(L.c2m_norm_bwd(_p(x), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), _p(ggb), _p(dgamma),
-                                  _p(dbeta), _p(dx), _p(dxn), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _dt(x), _stream()),
+                                  _p(dbeta), None if only else _p(dx), _p(dxn), _p(ws), N, C, S, mode, ACT[act], LRELU_SLOPE, _dt(x),
+                                  _stream()),
                    "norm_bwd")
+        if only and _NC8_POISON:
+            dx.fill_(float("nan"))
         if dxn is not None:
             dx._c2m_nc8 = (dx._version, dxn)      # autograd hands this very tensor object to the convolution's backward (see _to_nc8)
         if ggb is not None and ggb.dtype != ctx.gb_dtype:
             ggb = ggb.to(ctx.gb_dtype)
-        return dx, dgamma, dbeta, ggb, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, ggb, None, None, None, None, None, None, None, None
 
 
 def _norm_act(*args):
@@ -1804,18 +1822,20 @@ def _norm_act(*args):
     return y
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1, feeds=None):
-    return _norm_act(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum, feeds)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, eps=1e-5, momentum=0.1, feeds=None, private_input=False):
+    """private_input: x is a convolution's output that NOTHING else reads (`y = conv(..); y = norm(y)` inside a block) -- where that
+    convolution's backward runs on NC8 kernels, dx is handed back in NC8 form only (no NCHW write, no layout pass)."""
+    return _norm_act(x, gamma, beta, None, running_mean, running_var, 1, act, eps, momentum, feeds, private_input)
 
 
-def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5, feeds=None):
-    return _norm_act(x, gamma, beta, None, None, None, 0, act, eps, 0.1, feeds)
+def instance_norm_act(x, gamma=None, beta=None, act=None, eps=1e-5, feeds=None, private_input=False):
+    return _norm_act(x, gamma, beta, None, None, None, 0, act, eps, 0.1, feeds, private_input)
 
 
-def spade_norm_act(x, gamma_beta, act=None, eps=1e-5, feeds=None):
+def spade_norm_act(x, gamma_beta, act=None, eps=1e-5, feeds=None, private_input=False):
     """InstanceNorm(affine=False)(x) * (1 + gamma) + beta with [gamma, beta] = gamma_beta.chunk(2, 1), then act.
     feeds (all three ops): `conv_consumer(...)` of the one convolution that reads the result, see there."""
-    return _norm_act(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1, feeds)
+    return _norm_act(x, None, None, gamma_beta, None, None, 0, act, eps, 0.1, feeds, private_input)
 
 
 # =============================================================================================== warping / resampling

@@ -394,3 +394,44 @@ def test_residual_blocks_feed_their_convolutions_in_nc8_only(spade):
         assert len(o) == len(outs[0])
         for a, b_ in zip(outs[0], o):
             assert torch.isfinite(b_).all() and torch.equal(a, b_)
+
+
+BLOCK_CASES = ["down2d_s2", "down2d_s1", "same2d", "same3d", "up2d"]
+
+
+@pytest.mark.parametrize("kind", BLOCK_CASES)
+def test_blocks_hand_the_norm_gradient_back_in_nc8_only(kind):
+    """conv -> norm -> activation blocks (DownBlock2d, SameBlock2d / 3d, UpBlock2d): the convolution's output is a temporary of the
+    block, so the norm hands its dx to the convolution's backward in NC8 form alone (private_input) where that backward runs on NC8
+    kernels.  Output and every gradient bit-identical to the NCHW hand-over, also with the unwritten NCHW storage NaN-poisoned."""
+    from c2m_amd.modules.layers.down_block import DownBlock2d
+    from c2m_amd.modules.layers.same_block import SameBlock2d, SameBlock3d
+    from c2m_amd.modules.layers.up_block import UpBlock2d
+    make = {
+        "down2d_s2": (lambda: DownBlock2d(32, 64, kernel_size=(4, 4), stride=(2, 2), padding=1, padding_mode="reflect"), (2, 32, 32, 64)),
+        "down2d_s1": (lambda: DownBlock2d(32, 64, padding_mode="reflect"), (2, 32, 16, 32)),
+        "same2d": (lambda: SameBlock2d(64, 64, padding_mode="reflect"), (2, 64, 16, 32)),
+        "same3d": (lambda: SameBlock3d(32, 64, kernel_size=3, padding=1, padding_mode="reflect"), (1, 32, 3, 16, 32)),
+        "up2d": (lambda: UpBlock2d(32, 64, padding_mode="reflect", reshape_3d=False, input_2d=True), (2, 32, 8, 16)),
+    }[kind]
+    x = _bf(rnd(131, *make[1])).to(DEV).bfloat16()
+    outs, used = [], []
+    for grad_nc8, poison in ((False, False), (True, False), (True, True)):
+        ops._NC8_GRAD, ops._NC8_POISON = grad_nc8, poison
+        ops._geom_cache.clear()
+        try:
+            torch.manual_seed(5)
+            blk = make[0]().to(DEV).train()
+            xg = x.clone().requires_grad_(True)
+            y = blk(xg)
+            used.append(bool(getattr(y.grad_fn, "dx_nc8_only", False)))
+            y.backward(_bf(rnd(132, *y.shape)).to(DEV).to(y.dtype))
+            outs.append([y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.grad is not None])
+        finally:
+            ops._NC8_GRAD, ops._NC8_POISON = True, False
+            ops._geom_cache.clear()
+    assert used == [False, True, True], f"the block's norm must take the NC8-only hand-over when the knob is on: {used}"
+    for o in outs[1:]:
+        assert len(o) == len(outs[0])
+        for a, b_ in zip(outs[0], o):
+            assert torch.isfinite(b_).all() and torch.equal(a, b_)
