@@ -15,7 +15,7 @@ GROUPS = collections.OrderedDict([
     ("reflect folds", r"reflect_"),
     ("x2 up-sampling / resize / pooling", r"upsample|resize|maxpool"),
     ("weight packing, filter transforms, Adam", r"pack_|adam|wino_filter|wino4_filter"),
-    ("act_bwd, tap backward, losses", r"act_bwd|relu_tap|l1_|ssim|final_sum"),
+    ("act_bwd, tap backward, losses", r"act_bwd|relu_tap|grad_to_nc8|l1_|ssim|final_sum"),
     ("warp / raster / splat / RoI", r"flow_warp|warp_inv|splat|raster|roi_"),
     ("hipBLASLt / rocBLAS GEMMs", r"Cijk|rocblas"),
     ("ATen copies / cat / memcpy", r"direct_copy|copyBuffer|CatArray|bfloat16_copy|bfloat16tofloat32|Memcpy|copy_kernel"),
