@@ -476,6 +476,61 @@ __global__ void upsample2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ 
     }
 }
 
+// The same x2 upsample on channel-blocked tensors (round 4): in [NCB][Hi][Wi][8] bf16 -> out [NCB][2Hi][2Wi][8] bf16 (NC8, conv_nc8.hip),
+// for the up block whose convolution reads NC8 only (ops.upsample2x feeds=): one thread per input pixel and channel block loads the
+// 2 x 2 source units of each of its four outputs (16 bytes = 8 channels each) and stores four 16-byte units.  Per channel the
+// expression and the lerp_src weights of upsample2x_fwd_kernel -> the same bits as that kernel followed by the layout pass.
+__device__ __forceinline__ void up_nc8_unpack(const uint4 v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__global__ __launch_bounds__(256) void upsample2x_nc8_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long NCB, int Hi,
+                                                             int Wi) {
+    const int Wo = 2 * Wi;
+    const long total = NCB * Hi * Wi;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wi); const long r = i / Wi;
+        const int y = (int)(r % Hi); const long ncb = r / Hi;
+        const uint4* __restrict__ p = in + ncb * Hi * Wi;
+        uint4* __restrict__ o = out + ncb * 4 * Hi * Wi + (long)(2 * y) * Wo + 2 * x;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const Lerp ly = lerp_src(2 * y + a, Hi, 0.5f, false);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const Lerp lx = lerp_src(2 * x + b, Wi, 0.5f, false);
+                float a00[8], a01[8], a10[8], a11[8];
+                up_nc8_unpack(p[ly.i0 * Wi + lx.i0], a00); up_nc8_unpack(p[ly.i0 * Wi + lx.i1], a01);
+                up_nc8_unpack(p[ly.i1 * Wi + lx.i0], a10); up_nc8_unpack(p[ly.i1 * Wi + lx.i1], a11);
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+                    const float v0 = ly.l0 * (lx.l0 * a00[2 * e] + lx.l1 * a01[2 * e]) + ly.l1 * (lx.l0 * a10[2 * e] + lx.l1 * a11[2 * e]);
+                    const float v1 = ly.l0 * (lx.l0 * a00[2 * e + 1] + lx.l1 * a01[2 * e + 1]) +
+                                     ly.l1 * (lx.l0 * a10[2 * e + 1] + lx.l1 * a11[2 * e + 1]);
+                    const bf16x2_t q = {(bf16_t)v0, (bf16_t)v1};
+                    w[e] = __builtin_bit_cast(unsigned, q);
+                }
+                o[(long)a * Wo + b] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+}
+
+// in / out: NC8 tensors (16-byte aligned), NCB = N * ceil(C/8)
+C2M_API int c2m_upsample2x_nc8(const void* in, void* out, long NCB, int Hi, int Wi, void* stream) {
+    C2M_ENTER();
+    const long total = NCB * Hi * Wi;
+    if (total <= 0) return 0;
+    if ((((uintptr_t)in) | ((uintptr_t)out)) & 15) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(upsample2x_nc8_kernel, dim3(c2m_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in,
+                       (uint4*)out, NCB, Hi, Wi);
+    return (int)hipGetLastError();
+}
+
 // adjoint of the x2 (align_corners=False, scale 0.5) upsample, gather form (deterministic, no atomics)
 template <class T = float>
 __device__ __forceinline__ float upsample2x_bwd_pixel(const T* __restrict__ g, int y, int x, int Hi, int Wi) {

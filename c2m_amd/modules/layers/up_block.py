@@ -3,7 +3,7 @@ time-folded frames.  `main` keeps the reference's Sequential layout so the keys 
 from torch import nn
 
 from ... import ops
-from .common import conv_module, batch_norm_module, fold_time, unfold_time
+from .common import conv_module, batch_norm_module, feeds_conv, fold_time, unfold_time
 
 
 class UpBlock2d(nn.Module):
@@ -20,7 +20,7 @@ class UpBlock2d(nn.Module):
 
     def forward(self, x):
         flat = x if self.input_2d else fold_time(x)
-        y = conv_module(ops.upsample2x(flat), self.main[1])
+        y = conv_module(ops.upsample2x(flat, feeds=feeds_conv(self.main[1])), self.main[1])     # (the up-sampled map: read by this conv only)
         y = batch_norm_module(y, self.main[2], act="lrelu", private_input=True)       # (y: this block's conv output, read here only)
         # the reference hard-codes 5 predicted frames here (up_block.py:25)
         return unfold_time(y, 5) if self.reshape_3d else y

@@ -947,6 +947,19 @@ def _fwd_reads_only_nc8(pl, need_w):
     return True
 
 
+def _consumer_reads_only_nc8(like, feeds):
+    """`feeds` = conv_consumer(...) and `like` a tensor of the consumer's input shape / dtype: True when that convolution will read
+    its input through NC8 kernels only AND in one piece -- `conv()` runs tensors past 2 GiB as batch chunks, i.e. on VIEWS of its
+    input, which do not carry the NC8 form."""
+    cw, cstride, cpad, cmode = feeds
+    nd = like.dim() - 2
+    stride3, pad3 = _triple(cstride, nd), _pad3(cpad, nd)
+    if _chunks_for_2gib(like.shape, cw.shape, stride3, pad3) > 1:
+        return False
+    cpl = _plan(like, _f(cw), stride3, pad3, cmode == "reflect" and any(pad3), None)
+    return _fwd_reads_only_nc8(cpl, cw.requires_grad)
+
+
 def conv_consumer(conv_w, stride=1, padding=0, padding_mode="zeros"):
     """`feeds=` argument of batch_norm_act / instance_norm_act / spade_norm_act: the ONE convolution that consumes the op's result
     (the caller guarantees nothing else reads it -- `out = norm(x); out = conv(out)` inside a block).  Where that layer's forward and
@@ -1769,11 +1782,7 @@ class _NormActFn(torch.autograd.Function):
         # `feeds`: the result's only consumer is one convolution whose forward and weight gradient read NC8 -> NC8 is the ONLY output
         only = False
         if feeds is not None and dt == 1 and S % 8 == 0:
-            cw, cstride, cpad, cmode = feeds
-            nd = x.dim() - 2
-            pad3 = _pad3(cpad, nd)
-            cpl = _plan(x, _f(cw), _triple(cstride, nd), pad3, cmode == "reflect" and any(pad3), None)
-            only = _fwd_reads_only_nc8(cpl, cw.requires_grad)
+            only = _consumer_reads_only_nc8(x, feeds)
         yn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if (ctx.nc8 or only) else None
         _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), None if only else _p(y), _p(yn), N, C, S,
                                     mode, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
@@ -1918,13 +1927,23 @@ def correlation(a, b, pad_size=20, kernel_size=1, max_displacement=20, stride1=1
 
 class _Upsample2xFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, feeds=None):
         _dev(x)
         x = _f(x)
         N, C, H, W = x.shape
         y = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
-        _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _dt(x), _stream()), "upsample2x")
         ctx.shape = (N, C, H, W)
+        if feeds is not None and x.dtype == BF16 and (H * W) % 8 == 0:
+            # the result's only reader is one convolution whose forward and weight gradient read NC8: NC8 -> NC8, no NCHW result
+            if _consumer_reads_only_nc8(y, feeds):
+                xn = _to_nc8(x)
+                yn = torch.empty((N, _cdiv(C, 8), 2 * H, 2 * W, 8), device=x.device, dtype=BF16)
+                _lib.check(_lib.lib().c2m_upsample2x_nc8(_p(xn), _p(yn), N * _cdiv(C, 8), H, W, _stream()), "upsample2x_nc8")
+                if _NC8_POISON:
+                    y.fill_(float("nan"))
+                y._c2m_nc8 = (y._version, yn)
+                return y
+        _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _dt(x), _stream()), "upsample2x")
         return y
 
     @staticmethod
@@ -1933,11 +1952,13 @@ class _Upsample2xFn(torch.autograd.Function):
         gy = _f(gy)
         gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
         _lib.check(_lib.lib().c2m_upsample2x_bwd(_p(gy), _p(gx), N * C, H, W, _dt(gy), _stream()), "upsample2x_bwd")
-        return gx
+        return gx, None
 
 
-def upsample2x(x):
-    return _Upsample2xFn.apply(x)
+def upsample2x(x, feeds=None):
+    """nn.Upsample(scale_factor=2, mode='bilinear').  feeds: `conv_consumer(...)` of the ONE convolution that reads the result (the up
+    block): where that layer reads NC8 only, the up-sampled map -- the largest tensors of the decoder -- is produced in NC8 alone."""
+    return _Upsample2xFn.apply(x, feeds)
 
 
 def resize_bilinear(x, size, align_corners=False):

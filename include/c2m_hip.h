@@ -249,6 +249,9 @@ int c2m_flow_warp_bwd(const void* img, const float* flow, const float* occ, cons
 int c2m_resize_bilinear(const void* in, void* out, long NC, int Hi, int Wi, int Ho, int Wo, int align,
                         double scale_factor, int dt, void* stream);
 int c2m_upsample2x_fwd(const void* in, void* out, long NC, int Hi, int Wi, int dt, void* stream);
+/* The same up-sampling (up_block.py:10) from an NC8 tensor to an NC8 tensor ([N*ceil(C/8)][H][W][8] bf16 -> [..][2H][2W][8]), for the
+ * up block whose convolution reads the channel-blocked form only (round 4); per channel the arithmetic of c2m_upsample2x_fwd. */
+int c2m_upsample2x_nc8(const void* in_nc8, void* out_nc8, long NCB, int Hi, int Wi, void* stream);
 int c2m_upsample2x_bwd(const void* gout, void* gin, long NC, int Hi, int Wi, int dt, void* stream);
 /* torchvision.ops.roi_align(aligned=False, sampling_ratio=-1), appearance_encoder/appearance_encoder.py:67-69.
  * boxes [K,5] = (batch, x1, y1, x2, y2) stay on the device; the backward gathers per feature pixel in a fixed order (no

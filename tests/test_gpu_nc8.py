@@ -435,3 +435,17 @@ def test_blocks_hand_the_norm_gradient_back_in_nc8_only(kind):
         assert len(o) == len(outs[0])
         for a, b_ in zip(outs[0], o):
             assert torch.isfinite(b_).all() and torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 4, 8), (1, 21, 6, 12), (3, 64, 8, 16)])
+def test_upsample2x_nc8_matches_the_nchw_kernel_plus_layout_pass(shape):
+    from c2m_amd import _lib
+    L = _lib.lib()
+    N, C, H, W = shape
+    x = rnd(141, *shape).to(DEV).bfloat16()
+    y = torch.empty(N, C, 2 * H, 2 * W, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.c2m_upsample2x_fwd(ops._p(x), ops._p(y), N * C, H, W, 1, ops._stream()), "up")
+    CB = (C + 7) // 8
+    yn = torch.empty(N, CB, 2 * H, 2 * W, 8, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.c2m_upsample2x_nc8(ops._p(ops._to_nc8(x)), ops._p(yn), N * CB, H, W, ops._stream()), "up nc8")
+    assert torch.equal(yn, ops._to_nc8(y))
