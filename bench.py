@@ -226,6 +226,72 @@ def _family(s, names, divide=1.0, peak=PEAK_FP32_MFMA_TFLOPS, step_s=None):
             "share_of_step_time": round(ms * 1e-3 / step_s, 3) if step_s else None}
 
 
+def side_config(k, dev, steps=10, warmup=3):
+    """One of the bf16 BASELINE configurations (2: 256x512 B4, 3: 128x256 B8; full adversarial step) measured in THIS process after
+    (and outside) the headline timed region: `warmup` eager steps, one eager step with HIP events around every conv launch (the conv
+    fraction of the bf16 matrix peak), then `steps` HIP-graph replays of zero_grad + forward + backward with the four Adam steps
+    eager behind each replay, bracketed by synchronize().  Same code path as `bench.py --config k` (its `hip_graph_replay` object)."""
+    import copy
+    import gc
+    c = CONFIGS[k]
+    cfg = bench_config(c["height"], c["width"], c["full_step"])
+    prev = ops.set_conv_precision("bf16" if c["dtype"] == "bf16" else "fp32")
+    try:
+        torch.manual_seed(0)
+        model = GeneratorFullModel(train_params=copy.deepcopy(cfg)["train_params"],
+                                   model_params=copy.deepcopy(cfg)["model_params"], dataset="cityscapes")
+        model.to(dev).train()
+        step = TrainStep(model, run_optimizers=c["full_step"], distributed=False)
+        clips = c["batch"] * c["windows"]
+        batch = batch_to(make_stream_batch(c["batch"], c["windows"], c["height"], c["width"], 2, seed=0), dev)
+        rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=0)
+        batch["rng"] = {kk: v.to(dev) for kk, v in rng.items()}
+        with torch.cuda.stream(step.graph_stream):
+            for _ in range(warmup):
+                step(batch)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            step(batch)
+            torch.cuda.synchronize(dev)
+            eager_ms = 1000.0 * (time.perf_counter() - t0)
+            prof = ops.ConvProfiler()
+            ops.ConvProfiler.active = prof
+            step(batch)
+            ops.ConvProfiler.active = None
+            s = prof.summary()
+            step.capture(batch)
+            step(batch)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(batch)
+            torch.cuda.synchronize(dev)
+            tg = time.perf_counter() - t0
+        bf = c["dtype"] == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+        fl = sum(d["flops"] for d in s.values())
+        ms = sum(d["ms"] for d in s.values())
+        fwd = _family(s, ["igemm_bf16" if bf else "igemm"], 1.0, peak)
+        wg = _family(s, ["wgrad_bf16" if bf else "wgrad"], 1.0, peak)
+        out = {"workload": f"BASELINE configs[{k}]: {c['height']}x{c['width']}, 7-frame clips, batch {c['batch']}/GPU"
+                           f"{'' if c['windows'] == 1 else ' x %d windows' % c['windows']}, "
+                           f"{'bf16 data path' if bf else 'fp32'}, full adversarial step (G + D_image + D_video, 4 Adam steps), VGG loss on",
+               "ms_per_step": round(1000.0 * tg / steps, 3), "value": round(clips * 7 * steps / tg, 2), "unit": "frames/s",
+               "steps": steps, "warmup": warmup, "mode": "HIP-graph replay of zero_grad + forward + backward, optimizers eager",
+               "eager_ms_per_step": round(eager_ms, 3),
+               "conv_launches_per_step": sum(d["launches"] for d in s.values()), "conv_ms_per_step": round(ms, 3),
+               "conv_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "conv_frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+               "peak_tflops": peak,
+               "conv_fwd_dgrad_tflops": fwd and fwd["algorithmic_tflops"], "conv_wgrad_tflops": wg and wg["algorithmic_tflops"],
+               "conv_timing": "HIP events around every conv launch of ONE eager step (layout passes of a launch's input included)"}
+        del step, model, batch, prof
+        return out
+    finally:
+        ops.set_conv_precision(prev)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +328,10 @@ def main():
                     help="keep fp32 gradient buckets on the wire in the bf16 configurations (default there: bf16 copies)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
+    ap.add_argument("--side-configs", default=None,
+                    help="comma-separated BASELINE configs measured as HIP-graph replays in the same process AFTER the headline timed "
+                         "region and reported as `side_configs` (default: '3,2' for the plain 1-GPU configs[1] run, '' otherwise)")
+    ap.add_argument("--side-steps", type=int, default=10)
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-index", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -466,6 +536,23 @@ def main():
                 f.write("kind pass M K Npix taps stride reflect | launches/step ms/step TFLOP/s\n")
                 for tag, n, ms, tf in prof.table():
                     f.write(f"{tag} | {n / sampled:.1f} {ms / sampled:.3f} {tf:.1f}\n")
+        side = args.side_configs
+        if side is None:
+            side = "3,2" if (world == 1 and args.config == 1 and not args.graph and not args.force_reducer and
+                             (args.batch, args.windows, args.height, args.width, args.dtype) == (8, 1, 128, 256, "f32")) else ""
+        if side and world == 1:
+            # the bf16 configurations, outside the timed region (after it): the headline objects must not hold HBM while they run
+            import gc
+            del step, model, batch
+            prof = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            result["side_configs"] = {}
+            for k in [int(v) for v in side.split(",") if v.strip()]:
+                try:
+                    result["side_configs"][f"configs[{k}]"] = side_config(k, dev, steps=args.side_steps)
+                except Exception as e:                     # a side measurement never takes the headline line down
+                    result["side_configs"][f"configs[{k}]"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(bench_config(args.height, args.width, False))
         print(json.dumps(result), flush=True)

@@ -68,7 +68,7 @@ def feeds_conv(conv, padding=None, padding_mode=None):
     """`feeds=` of the norm helpers below: the ONE convolution container that reads the norm's result (ops.conv_consumer)."""
     pad = conv.padding if padding is None else padding
     mode = conv.padding_mode if padding_mode is None else padding_mode
-    return ops.conv_consumer(conv.weight, tuple(conv.stride), tuple(pad) if not isinstance(pad, int) else pad, mode)
+    return ops.conv_consumer(conv.weight, tuple(conv.stride), tuple(pad) if not isinstance(pad, int) else pad, mode, conv.bias)
 
 
 def batch_norm_module(x, bn, act=None, feeds=None, private_input=False):

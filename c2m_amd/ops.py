@@ -262,7 +262,7 @@ def _patch_ok(C, taps3, stride, splits, Ho, Wo, M):
     return Wo >= 32 and Ho >= rows and (_ceil(Wo, 32) * _ceil(Ho, rows)) <= 1.15 * Wo * Ho
 
 
-def _patch_bf16_ok(C, stride, Ho, Wo, M, fill_limit=None):
+def _patch_bf16_ok(C, stride, Ho, Wo, M, fill_limit=None, nc8=True):
     """bf16 LDS-patch kernel (8 rows x 32 columns per workgroup): 3x3 stride-1.  Where it beats the bf16 gather kernel
     (per-shape A/B of BASELINE configs[2], gpurun_out/r02/table_cfg2*.txt): deep reductions (>= 128 channels: the weight
     image of a chunk is re-streamed per 256 pixels, which only pays with many chunks) or few output rows (<= 64), and
@@ -270,7 +270,8 @@ def _patch_bf16_ok(C, stride, Ho, Wo, M, fill_limit=None):
     if tuple(stride) != (1, 1, 1) or M <= 4 or C < 12 or Wo < 32 or Ho < 8 or _ceil(C, 16) > 1.25 * C:
         return False
     fill = (_ceil(Wo, 32) * _ceil(Ho, 8)) / float(Wo * Ho)
-    if _NC8:              # the channel-blocked kernel (conv_nc8.hip) has no 2-byte gathers to amortise: every layer whose tiles fit
+    if _NC8 and nc8:      # the channel-blocked kernel (conv_nc8.hip) has no 2-byte gathers to amortise: every layer whose tiles fit
+                          # (nc8: the plan can run it -- planes of whole 8-pixel groups; otherwise the NCHW kernel's own rule below)
         return fill <= (fill_limit or _NC8_FILL)      # (the padded 34x66 domain of a reflect data gradient fills 58 % of its tiles: still 1.5x the gather kernel)
     if C < 128:
         return (M <= 64 or _PATCH_SMALLC) and fill <= 1.2
@@ -335,6 +336,25 @@ def _patch_splits(L, M, C, npix, bf16=False):
     return _cdiv(nch, _cdiv(nch, s0))
 
 
+_nc8_only = {}      # storage address -> (weakref(NC8-only tensor), its _version, NC8 form)
+
+
+def _drop_nc8_only(key):
+    ent = _nc8_only.get(key)
+    if ent is not None and ent[0]() is None:
+        del _nc8_only[key]
+
+
+def _mark_nc8_only(t, tn):
+    """`t` is an NCHW-shaped tensor object whose storage is never written: its values exist as `tn` (NC8) only."""
+    t._c2m_nc8 = (t._version, tn)
+    t._c2m_nc8_only = True
+    key = t.data_ptr()
+    _nc8_only[key] = (weakref.ref(t), t._version, tn)
+    weakref.finalize(t, _drop_nc8_only, key)
+    return t
+
+
 def _to_nc8(x, keep=None):
     """c2m_nchw_to_nc8: contiguous bf16 [N, C, H, W] -> [N, ceil(C/8), H, W, 8] (the conv input form of conv_nc8.hip).
     The result is remembered ON the source tensor (attribute, with the tensor's `_version`: any in-place change invalidates it),
@@ -350,6 +370,20 @@ def _to_nc8(x, keep=None):
         hit = keep.get(x.data_ptr())
         if hit is not None and hit[0] is x:
             return hit[1]
+    # NC8-only tensors: the NCHW storage of such a tensor was never written.  If the attribute did not travel with the
+    # tensor object (tensor hooks, retain_grad, saved_tensors_hooks hand out another object over the same storage) the NC8 form is
+    # recovered from the registry by storage address + version; a tensor tagged NC8-only without any valid form is an error, never
+    # a layout pass over uninitialised memory.
+    ent = _nc8_only.get(x.data_ptr())
+    if ent is not None:
+        src = ent[0]()
+        if src is not None and src.shape == x.shape and src.dtype == x.dtype and ent[1] == x._version and ent[2].device == x.device:
+            if keep is not None:
+                keep[x.data_ptr()] = (x, ent[2])
+            return ent[2]
+    if getattr(x, "_c2m_nc8_only", False):
+        raise RuntimeError("c2m_amd: a tensor that exists in NC8 form only reached a convolution without a valid NC8 form (it was "
+                           "modified in place, or its single-consumer contract -- feeds= / private_input= -- was broken)")
     N, C = x.shape[0], x.shape[1]
     sp = tuple(x.shape[2:])                 # (H, W), or (T, H, W): the pixel axis of the layout pass is everything behind C
     if _NC8_LOG is not None:                # tools/nc8_producers.py: who produced the tensors that need a layout pass
@@ -735,7 +769,7 @@ class _ConvPlan:
         # ... and the weight gradient of the 3x3 stride-1 pad-1 layers from the NC8 forms of X and dY (transposed LDS reads)
         self.wgrad_nc8 = bool(self.nc8 and _NC8_WGRAD and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and
                               (ph, pw) == (1, 1) and Cout >= 64 and Cin >= 16)      # (Cout = 32: half of a 64-row tile is padding -- 88 vs 145 TF/s on the NCHW kernel)
-        if (kt, kh, kw) == (1, 3, 3) and (_patch_bf16_ok(Cin, stride, Ho, Wo, Cout) if bf16 else
+        if (kt, kh, kw) == (1, 3, 3) and (_patch_bf16_ok(Cin, stride, Ho, Wo, Cout, None, self.nc8) if bf16 else
                                           _patch_ok(Cin, (kt, kh, kw), stride, 1, Ho, Wo, Cout)):
             self.fwd_patch, self.ck = True, 16
             ck = 16
@@ -810,7 +844,8 @@ class _ConvPlan:
                     cck = _choose_ck(Cout, ctaps)
                     cpatch = False
                     if (At, Ay, Ax) == (1, 3, 3) and (st, sh, sw) == (1, 1, 1) and \
-                            (_patch_bf16_ok(Cout, (1, 1, 1), Qy, Qx, dM, _NC8_DGRAD_FILL if (reflect and _G8) else None) if bf16 else
+                            (_patch_bf16_ok(Cout, (1, 1, 1), Qy, Qx, dM, _NC8_DGRAD_FILL if (reflect and _G8) else None,
+                                            not is3d and (Ho * Wo) % 8 == 0) if bf16 else
                              _patch_ok(Cout, (At, Ay, Ax), (1, 1, 1), 1, Qy, Qx, dM)):
                         cpatch, cck = True, 16
                     coffs = _tap_offsets(At, Ay, Ax, qt - np.arange(At), qy - np.arange(Ay), qx - np.arange(Ax))
@@ -951,20 +986,22 @@ def _consumer_reads_only_nc8(like, feeds):
     """`feeds` = conv_consumer(...) and `like` a tensor of the consumer's input shape / dtype: True when that convolution will read
     its input through NC8 kernels only AND in one piece -- `conv()` runs tensors past 2 GiB as batch chunks, i.e. on VIEWS of its
     input, which do not carry the NC8 form."""
-    cw, cstride, cpad, cmode = feeds
+    cw, cstride, cpad, cmode = feeds[:4]
+    cb = feeds[4] if len(feeds) > 4 else None
     nd = like.dim() - 2
     stride3, pad3 = _triple(cstride, nd), _pad3(cpad, nd)
     if _chunks_for_2gib(like.shape, cw.shape, stride3, pad3) > 1:
         return False
     cpl = _plan(like, _f(cw), stride3, pad3, cmode == "reflect" and any(pad3), None)
-    return _fwd_reads_only_nc8(cpl, cw.requires_grad)
+    # (a frozen weight with a trainable bias still runs _ConvFn._wgrad -- the bias gradient comes out of the weight-gradient kernel)
+    return _fwd_reads_only_nc8(cpl, cw.requires_grad or (cb is not None and cb.requires_grad))
 
 
-def conv_consumer(conv_w, stride=1, padding=0, padding_mode="zeros"):
+def conv_consumer(conv_w, stride=1, padding=0, padding_mode="zeros", conv_b=None):
     """`feeds=` argument of batch_norm_act / instance_norm_act / spade_norm_act: the ONE convolution that consumes the op's result
     (the caller guarantees nothing else reads it -- `out = norm(x); out = conv(out)` inside a block).  Where that layer's forward and
     weight gradient run on NC8 kernels the result is produced in NC8 form only."""
-    return (conv_w, stride, padding, padding_mode)
+    return (conv_w, stride, padding, padding_mode, conv_b)
 
 
 def _tag_conv_output(ctx, pl, y, act):
@@ -985,8 +1022,7 @@ def _virtual_grad(like, gn):
     g = torch.empty_like(like)
     if _NC8_POISON:
         g.fill_(float("nan"))
-    g._c2m_nc8 = (g._version, gn)
-    return g
+    return _mark_nc8_only(g, gn)
 
 
 def _plan(x, w, stride, pad, reflect, dgrad_rows=None):
@@ -1788,6 +1824,7 @@ class _NormActFn(torch.autograd.Function):
                                     mode, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
         if only and _NC8_POISON:
             y.fill_(float("nan"))
+        _NormActFn.last_only = only             # read by _norm_act right behind apply(): tags y as NC8-only
         ctx.cfg = (N, C, S, mode, act)
         # x is the output of a convolution whose backward reads its gradient in NC8 only, and this op is x's only consumer (the
         # caller's promise): dx is produced in NC8 form alone
@@ -1817,8 +1854,10 @@ class _NormActFn(torch.autograd.Function):
                    "norm_bwd")
         if only and _NC8_POISON:
             dx.fill_(float("nan"))
-        if dxn is not None:
-            dx._c2m_nc8 = (dx._version, dxn)      # autograd hands this very tensor object to the convolution's backward (see _to_nc8)
+        if dxn is not None and only:
+            _mark_nc8_only(dx, dxn)               # autograd hands this very tensor object to the convolution's backward (see _to_nc8)
+        elif dxn is not None:
+            dx._c2m_nc8 = (dx._version, dxn)
         if ggb is not None and ggb.dtype != ctx.gb_dtype:
             ggb = ggb.to(ctx.gb_dtype)
         return dx, dgamma, dbeta, ggb, None, None, None, None, None, None, None, None
@@ -1826,7 +1865,9 @@ class _NormActFn(torch.autograd.Function):
 
 def _norm_act(*args):
     y, yn = _NormActFn.apply(*args)
-    if yn is not None:
+    if yn is not None and _NormActFn.last_only:
+        _mark_nc8_only(y, yn)                     # y's NCHW storage was never written
+    elif yn is not None:
         y._c2m_nc8 = (y._version, yn)             # the NC8 form travels with the tensor object (ops._to_nc8 picks it up)
     return y
 
@@ -1941,8 +1982,9 @@ class _Upsample2xFn(torch.autograd.Function):
                 _lib.check(_lib.lib().c2m_upsample2x_nc8(_p(xn), _p(yn), N * _cdiv(C, 8), H, W, _stream()), "upsample2x_nc8")
                 if _NC8_POISON:
                     y.fill_(float("nan"))
-                y._c2m_nc8 = (y._version, yn)
+                _Upsample2xFn.last_form = yn      # read by upsample2x() right behind apply(): tags y as NC8-only
                 return y
+        _Upsample2xFn.last_form = None
         _lib.check(_lib.lib().c2m_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _dt(x), _stream()), "upsample2x")
         return y
 
@@ -1958,7 +2000,11 @@ class _Upsample2xFn(torch.autograd.Function):
 def upsample2x(x, feeds=None):
     """nn.Upsample(scale_factor=2, mode='bilinear').  feeds: `conv_consumer(...)` of the ONE convolution that reads the result (the up
     block): where that layer reads NC8 only, the up-sampled map -- the largest tensors of the decoder -- is produced in NC8 alone."""
-    return _Upsample2xFn.apply(x, feeds)
+    y = _Upsample2xFn.apply(x, feeds)
+    if _Upsample2xFn.last_form is not None:
+        _mark_nc8_only(y, _Upsample2xFn.last_form)
+        _Upsample2xFn.last_form = None
+    return y
 
 
 def resize_bilinear(x, size, align_corners=False):

@@ -40,24 +40,44 @@ def _edge_multiplicity(edge_index, dst, src, N, dtype):
         (dst, src), torch.ones_like(dst, dtype=dtype), accumulate=True))
 
 
+def _csr_layout(dst, N, width):
+    """(order, slot) of the padded rows for a KNOWN width, device ops only (no host read-back: capturable).  The in-degrees are an
+    exact integer count (one-hot sum, no atomics); rank within a row = position in the stable order minus the row's start."""
+    E = dst.numel()
+    order = torch.argsort(dst, stable=True)
+    counts = (dst.unsqueeze(1) == torch.arange(N, device=dst.device).unsqueeze(0)).sum(0)
+    start = torch.cumsum(counts, 0) - counts
+    ds = dst[order]
+    slot = ds * width + (torch.arange(E, device=dst.device) - start[ds])
+    return order, slot, counts
+
+
 def _padded_csr(edge_index, dst, src, N):
     """Edges grouped by target node into fixed-width rows: (order, slot, width) with edge order[k] sitting in row dst, column
-    rank-within-row -- slot = dst * width + rank, every slot distinct.  The width (largest in-degree) is read back to the host
-    once per edge_index; inside a capture the eager entry of the warm-up steps is used (its tensors are kept alive here)."""
+    rank-within-row -- slot = dst * width + rank, every slot distinct.  The width (largest in-degree) is the one host-side value:
+    read back once per edge_index in eager mode.  Inside a HIP-graph capture ONLY that integer is taken from the eager warm-up
+    step's entry; argsort / counts / slots are recomputed by captured kernels from the static edge_index, so a replay follows new
+    edges copied into it (the eager entry's tensors used to be baked into the graph -- stale after a copy, freed by the
+    next eager step).  A replay whose largest in-degree exceeds the captured width would write slots of the next row: that is
+    flagged by a captured comparison and raised after the replay (TrainStep._check_deferred_nan), and the slots are clamped so the
+    replay itself stays in bounds."""
     def build(cap):
         if cap:
             hit = _adj_cache.get("csr")
-            if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == edge_index.data_ptr():
-                return hit[5]
-            raise RuntimeError("GATv2Conv (> 64 nodes): run one eager step with this edge_index before capturing a HIP graph "
-                               "(the padded edge layout needs the largest in-degree on the host)")
+            if hit is None or hit[3] != N:
+                raise RuntimeError("GATv2Conv (> 64 nodes): run one eager step with this graph size before capturing a HIP graph "
+                                   "(the padded edge layout needs the largest in-degree on the host)")
+            width = hit[5][2]
+            order, slot, counts = _csr_layout(dst, N, width)
+            from .utils import utils as U
+            U.defer_check((counts.max() > width) if dst.numel() else torch.zeros((), dtype=torch.bool, device=dst.device),
+                          f"GATv2Conv: an in-degree above {width}, the row width this HIP graph was captured with "
+                          "(edge_index changed: capture again)")
+            return order, slot.clamp(max=N * width - 1), width
         E = dst.numel()
-        order = torch.argsort(dst, stable=True)
         counts = torch.bincount(dst, minlength=N)
         width = max(int(counts.max()) if E else 0, 1)
-        start = torch.cumsum(counts, 0) - counts
-        ds = dst[order]
-        slot = ds * width + (torch.arange(E, device=dst.device) - start[ds])
+        order, slot, _ = _csr_layout(dst, N, width)
         return order, slot, width
     return _cached("csr", edge_index, N, torch.int64, build)
 

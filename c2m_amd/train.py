@@ -145,7 +145,7 @@ class TrainStep:
         flags = torch.stack([f.reshape(()) for f, _ in self._deferred_nan])
         if bool(flags.any()):
             bad = [name for (f, name) in self._deferred_nan if bool(f)]
-            raise ValueError(f"nan in {', '.join(bad)}")
+            raise ValueError(f"deferred check failed after a HIP-graph replay (nan / captured-layout guard) in {', '.join(bad)}")
 
     @property
     def graph_stream(self):

@@ -76,6 +76,11 @@ def isnan(x, input_tensor=None):
     return x
 
 
+def defer_check(flag, what):
+    """Record a captured boolean (True = failed) of the capture in progress next to the NaN flags: evaluated after every replay."""
+    _deferred_nan_checks.append((flag, what))
+
+
 def check_deferred_nan():
     """Evaluate NaN checks recorded during a capture that was not made through TrainStep.capture (which keeps its own)."""
     for flag, what in _deferred_nan_checks:

@@ -551,3 +551,54 @@ def test_nan_check_survives_graph_replay():
             step(batch)
         assert torch.equal(model.generator.first.conv.weight.detach(), before), "no optimizer step on a NaN loss"
     torch.cuda.synchronize()
+
+
+def test_gatv2_padded_rows_replay_follows_the_static_edge_index():
+    """above 64 nodes GATv2Conv groups the edges into padded rows.  Inside a HIP-graph capture only the row WIDTH (one
+    host integer) comes from the eager warm-up entry; order / slots are recomputed by captured kernels, so a replay after new
+    edges were copied into the static edge_index equals an eager call on them -- and an in-degree above the captured width is
+    flagged after the replay instead of corrupting the neighbouring row."""
+    from c2m_amd import thirdparty
+    from c2m_amd.utils import utils as U
+    torch.manual_seed(5)
+    n, E = 90, 400
+    m = thirdparty.GATv2Conv(16, 8, heads=4, concat=False, add_self_loops=False).to(DEV)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, 16, generator=g).to(DEV)
+    ei_a = torch.randint(0, n, (2, E), generator=g)
+    ei_b = ei_a.clone()
+    ei_b[:, :200] = torch.randint(0, n, (2, 200), generator=g)
+    width = lambda ei: int(torch.bincount(ei[1], minlength=n).max())
+    if width(ei_b) > width(ei_a):
+        ei_a, ei_b = ei_b, ei_a                                   # the capture sees the wider layout
+    ei_c = ei_a.clone()
+    ei_c[1, :width(ei_a) + 3] = 11                                # node 11: more incoming edges than any captured row holds
+    ei = ei_a.clone().to(DEV)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y_a = m(x, ei).clone()                                # eager entry: the width
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            U.begin_deferred_nan()
+            thirdparty.reset_capture_cache()
+            with torch.cuda.graph(graph, stream=side):
+                y_static = m(x, ei)
+            checks = U.end_deferred_nan()
+            thirdparty.reset_capture_cache()
+            assert len(checks) == 1
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, y_a) and not bool(checks[0][0])
+            ei.copy_(ei_b.to(DEV))                                # new edges INTO the static tensor
+            m(x, torch.zeros(2, 5, dtype=torch.long, device=DEV)) # an eager call on another edge_index replaces the eager cache entry
+            graph.replay()
+            torch.cuda.synchronize()
+            y_b = m(x, ei_b.to(DEV))
+            assert torch.equal(y_static, y_b) and not bool(checks[0][0])
+            ei.copy_(ei_c.to(DEV))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert bool(checks[0][0]), "in-degree above the captured width must be flagged"
+            assert bool(torch.isfinite(y_static).all())

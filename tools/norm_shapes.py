@@ -27,13 +27,13 @@ seen = collections.Counter()
 orig = ops._NormActFn.apply
 
 
-def spy(x, gamma, beta, gb, rm, rv, mode, act, eps, mom):
+def spy(x, gamma, beta, gb, rm, rv, mode, act, eps, mom, *rest):      # *rest: feeds, private_input
     S = 1
     for d in x.shape[2:]:
         S *= d
     kind = "spade" if gb is not None else ("affine" if gamma is not None else "plain")
     seen[(mode, x.shape[0], x.shape[1], S, kind, act, bool(x.requires_grad))] += 1
-    return orig(x, gamma, beta, gb, rm, rv, mode, act, eps, mom)
+    return orig(x, gamma, beta, gb, rm, rv, mode, act, eps, mom, *rest)
 
 
 ops._NormActFn.apply = spy
