@@ -17,7 +17,7 @@ ARCH = "gfx950"
 # the reducer's stream, so they get the same treatment; whole-step time is unchanged (71.18 vs 71.15 ms fp32, 61.9 vs 61.6 bf16).
 # The packed fp32 adds of the Winograd kernels are explicit inline asm (they only ever ran next to their own kind in the tests).
 NOSLP = ["-fno-slp-vectorize"]
-SOURCES = {"conv_igemm.hip": NOSLP, "conv_nc8.hip": NOSLP, "conv_wino.hip": NOSLP, "conv_wino4.hip": NOSLP, "norm.hip": NOSLP, "losses.hip": NOSLP,
+SOURCES = {"conv_igemm.hip": NOSLP, "conv_nc8.hip": NOSLP, "conv_wino.hip": NOSLP, "conv_wino4.hip": NOSLP, "conv_ring.hip": NOSLP, "norm.hip": NOSLP, "losses.hip": NOSLP,
            "optim.hip": ["-ffp-contract=off"] + NOSLP, "data_prep.hip": ["-ffp-contract=off"] + NOSLP,
            "warp.hip": ["-ffp-contract=off"] + NOSLP, "motion_raster.hip": ["-ffp-contract=off"] + NOSLP, "events.hip": [],
            "flownet_ops.hip": ["-ffp-contract=off"] + NOSLP}

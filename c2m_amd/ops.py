@@ -85,6 +85,10 @@ _WINO_DFIT = float(os.environ.get("C2M_WINO_DFIT", "0.5"))
 _WINO_MIN_WGS = int(os.environ.get("C2M_WINO_MIN_WGS", "128"))   # smallest Winograd forward / dgrad grid: 160 workgroups of a 1536-deep layer still beat the gather kernel 1.5x
 _WGRAD_WIDE_S2 = os.environ.get("C2M_WGRAD_WIDE_S2", "1") != "0"      # bf16 stride-2 weight gradient on the 16-byte-load kernel (A/B knob)
 _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect data gradient over unpadded frames (A/B knob)
+# reflect-padded 3x3 data gradients as interior (exact domain, Winograd) + pad ring (conv_ring.hip): "auto" (maps of >= C2M_RING_MIN_PIX
+# pixels) | "off" (padded domain + two-target epilogue + fold, rounds 1-4) | "force" (tests: every eligible layer with H, W >= 4)
+_RING = os.environ.get("C2M_RING", "auto")
+_RING_MIN_PIX = int(os.environ.get("C2M_RING_MIN_PIX", "2048"))
 _WINO4 = os.environ.get("C2M_WINO4", "auto")       # F(4x4,3x3) for the 2-D Winograd layers: "off" | "auto" (rule: _wino4_pays) | "force" (tests: every eligible 2-D Winograd launch)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
@@ -581,6 +585,14 @@ def _wino4_filter(w, Cout, Cin, dgrad):
     return U
 
 
+def _ring_pack(w, Cout, Cin):
+    """c2m_ring_pack: native [Cout][Cin][3][3] -> the A fragments of reflect_ring_dgrad_kernel (four sides x three taps)."""
+    L = _lib.lib()
+    A = torch.empty(L.c2m_ring_pack_floats(Cout, Cin), device=w.device, dtype=torch.float32)
+    _lib.check(L.c2m_ring_pack(_p(w), _p(A), Cout, Cin, _stream()), "ring_pack")
+    return A
+
+
 def _wino_geom(head, To=0, in_st=0, out_st=0, cin=0, nkt=0, toff=0, Ti=0, treflect=0):
     """geom[] of c2m_conv_wino (include/c2m_hip.h): 33 entries; the tail describes the time taps of a 3x3x3 layer."""
     g = np.zeros(34, dtype=np.int64)
@@ -645,7 +657,7 @@ class _ConvPlan:
         in_sc, osp = Ti * Hi * Wi, To * Ho * Wo
         # ---- Winograd F(2x2,3x3) for the 3x3 stride-1 2-D layers (fp32 mode): forward, and the data gradient when the
         # padding is zeros (the reflect data gradient runs over the padded domain with the two-target epilogue)
-        self.wino_fwd = self.wino_dgrad = self.wino_wgrad = False
+        self.wino_fwd = self.wino_dgrad = self.wino_wgrad = self.ring_dgrad = False
         self.wino4_fwd = self.wino4_dgrad = False         # F(4x4,3x3) instead of F(2x2,3x3) for that launch (2-D layers)
         if not bf16 and (kt, kh, kw) == (1, 3, 3) and tuple(stride) == (1, 1, 1) and (ph, pw) == (1, 1) and nd == 2:
             wrows = 32 if Cout <= 32 else 64                      # workgroup tile: 64 (32 for Cout <= 32) output x 32 input channels
@@ -670,13 +682,26 @@ class _ConvPlan:
                 self.wino_fwd_geom = _wino_geom([Cout, Cin, N, Hi, Wi, Ho, Wo, -1, -1, int(reflect), Cin * in_sc, in_sc, Wi,
                                                  Cout * osp, osp, Wo, 0, 4 * N * Cin * in_sc])
                 self.wino4_fwd = _wino4_pays(L, Cout, Cin, N, Ho, Wo)
-            # data gradient: zero padding -> the unpadded domain; reflect padding -> the padded (H+2)x(W+2) domain with
-            # the two-target epilogue (interior straight into dX, pad ring into a scratch tensor that is then folded)
+            # data gradient: zero padding -> the unpadded domain; reflect padding -> EITHER the exact H x W domain (the interior
+            # of the padded gradient = the zero-padded "same" data gradient, full Winograd regions) + the pad ring folded into dX
+            # by c2m_reflect_ring_dgrad (conv_ring.hip: four thin GEMMs, 3/9 (2H+2W)/(HW) of the layer's FLOPs -- maps of
+            # >= _RING_MIN_PIX pixels), OR the padded (H+2)x(W+2) domain with the two-target epilogue (interior straight into dX,
+            # pad ring into a scratch tensor that is then folded)
+            self.ring_dgrad = False
+            if reflect and dM == Cin and _RING != "off" and Hi >= 4 and Wi >= 4 and (_RING == "force" or Hi * Wi >= _RING_MIN_PIX):
+                eregions = N * L.c2m_wino_regions(Hi, Wi)
+                efit = N * Hi * Wi >= 0.8 * eregions * 128
+                if _WINO == "force" or (_WINO == "auto" and efit and Cout >= 32 and rows_ok(Cin) and
+                                        eregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS):
+                    self.wino_dgrad = self.ring_dgrad = True
+                    self.wino_dgrad_geom = _wino_geom(
+                        [Cin, Cout, N, Ho, Wo, Hi, Wi, -1, -1, 0, Cout * osp, osp, Wo, Cin * in_sc, in_sc, Wi, 0, 4 * N * Cout * osp])
+                    self.wino4_dgrad = _wino4_pays(L, Cin, Cout, N, Hi, Wi)
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
             dregions = N * L.c2m_wino_regions(Hd, Wd)
             dfit = N * Hd * Wd >= _WINO_DFIT * dregions * 128
-            if dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
-                                                   dregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS)):
+            if not self.ring_dgrad and dM == Cin and (_WINO == "force" or (_WINO == "auto" and dfit and Cout >= 32 and rows_ok(Cin) and
+                                                                         dregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS)):
                 self.wino_dgrad = True
                 o = -2 if reflect else -1
                 self.wino_dgrad_geom = _wino_geom(
@@ -1224,6 +1249,18 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
         npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
         tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
+        if pl.ring_dgrad:
+            # reflect, exact domain: the interior term straight into gx, then the pad ring added in place (conv_ring.hip) -- both
+            # launches inside the timed region of this layer's data gradient
+            Ar = _packed(w, frozen_w, ("ring-dgrad",), lambda: _ring_pack(w, Cout, Cin))
+            Hi_, Wi_ = pl.dims[4:6]
+
+            def run_ring():
+                rc = conv_wino(_p(U), _p(gy), _p(gx), None, None, _gp(pl.wino_dgrad_geom), 0, 0.0, _stream())
+                return rc or L.c2m_reflect_ring_dgrad(_p(Ar), _p(w), _p(gy), _p(gx), N, Cout, Cin, Hi_, Wi_, _stream())
+            _lib.check(_timed("wino4" if w4 else "wino", pl.fwd_flops, run_ring, tag + ("ring",),
+                              4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad + reflect ring")
+            return gx if gx.dtype == out_dtype else gx.to(out_dtype)
         # reflect: ring of the padded domain -> tgt (only the ring is ever written or read), interior -> gx
         tgt = torch.empty(pl.dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
         _lib.check(_timed("wino4" if w4 else "wino", pl.fwd_flops,

@@ -200,6 +200,20 @@ int c2m_conv_wino_wgrad(const float* dY, const float* X, float* slab, float* dbs
 int c2m_conv_wino_wgrad3d(const float* dY, const float* X, float* slab, float* dbslab, float* dW, float* db,
                           int M, int Cin, int N, int T, int H, int W, int reflect, void* stream);
 
+/* Pad-ring part of the data gradient of a reflect-padded (pad 1) 3x3 stride-1 convolution, folded straight into dX
+ * (conv_ring.hip).  Replaces, together with a c2m_conv_wino / c2m_conv_wino4 launch over the EXACT H x W domain, the ATen chain
+ * reflection_pad2d_backward(conv2d_backward_input(..)) of the `nn.Conv2d(.., padding=1, padding_mode='reflect')` call sites
+ * (layers/residual_block.py:13-31,42-71, same_block.py:50-68, spade_block.py:47-49): dX [N][M][H][W] must already hold the
+ * zero-padded "same" data gradient (the interior of the padded gradient); this launch adds what rows 0, H+1 and columns 0, W+1 of
+ * the padded gradient mirror onto rows 1, H-2 and columns 1, W-2 -- four three-tap GEMMs M x 3C x (N * line) on the exact fp32
+ * MFMA + one thread per (image, row, corner) for the four targets that receive three ring terms.  Every element of dX has one
+ * writer: no atomics, bit-repeatable.  w: native [C][M][3][3] (C = the layer's output channels, M = its input channels);
+ * apack: c2m_ring_pack_floats(C, M) floats written by c2m_ring_pack; dY [N][C][H][W]; H, W >= 4; tensors < 2 GiB.            */
+long c2m_ring_pack_floats(int C, int M);
+int c2m_ring_pack(const float* w, float* apack, int C, int M, void* stream);
+int c2m_reflect_ring_dgrad(const float* apack, const float* w, const float* dY, float* dX, int N, int C, int M, int H, int W,
+                           void* stream);
+
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */
 int c2m_reflect_border_add(const void* dXpad, void* dX, long NC, int T, int H, int W, int pt, int ph, int pw,

@@ -153,6 +153,7 @@ def test_conv_winograd_forced(case, monkeypatch):
     pick: forward, zero-pad data gradient, reflect data gradient over the padded domain (two-target epilogue)."""
     monkeypatch.setattr(ops, "_WINO", "force")
     monkeypatch.setattr(ops, "_WINO_WGRAD", "force")
+    monkeypatch.setattr(ops, "_RING", "off")         # (the interior + ring route: test_conv_reflect_ring_dgrad)
     ops._geom_cache.clear()
     try:
         xs, cout, k, stride, pad, mode = case
@@ -197,6 +198,7 @@ def test_conv_winograd_f4x4_forced(case, monkeypatch):
     (measured on the GPU: 2e-6 ... 4e-6 of the tensor scale, tools/bench_wino4.py)."""
     monkeypatch.setattr(ops, "_WINO", "force")
     monkeypatch.setattr(ops, "_WINO4", "force")
+    monkeypatch.setattr(ops, "_RING", "off")
     ops._geom_cache.clear()
     try:
         xs, cout, k, stride, pad, mode = case
@@ -231,6 +233,54 @@ def test_conv_winograd_f4x4_forced(case, monkeypatch):
 
 def _bf(t):
     return t.bfloat16().float()
+
+
+RING_CASES = [c for c in WINO4_CASES if c[5] == "reflect"] + [
+    ((3, 33, 4, 4), 50, (3, 3), 1, 1, "reflect"),        # smallest map: rows 1 / H-2 adjacent, every row target but x = 0, 3 is a corner
+    ((2, 40, 6, 10), 24, (3, 3), 1, 1, "reflect"),       # 24 reduction channels: the second chunk half empty; 40 rows: partial 64-row tile
+    ((5, 96, 32, 64), 128, (3, 3), 1, 1, "reflect"),     # line tiles that span images (5 x 64 = 2.5 pixel tiles), 8 chunks
+    ((2, 64, 64, 128), 64, (3, 3), 1, 1, "reflect"),     # the 64 x 128 maps the auto rule moves to F(4x4) on the exact domain
+    ((1, 130, 8, 130), 72, (3, 3), 1, 1, "reflect"),     # W > 128: a row spans two pixel tiles; M = 130: three 64-row tiles
+]
+
+
+@pytest.mark.parametrize("w4", ["F(2x2)", "F(4x4)"])
+@pytest.mark.parametrize("case", RING_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}")
+def test_conv_reflect_ring_dgrad(case, w4, monkeypatch):
+    """Reflect-pad data gradient as interior + ring (round 5): the Winograd kernels run the zero-padded "same" data gradient over
+    the EXACT H x W domain and c2m_reflect_ring_dgrad (conv_ring.hip) adds what the pad ring of the padded gradient mirrors onto
+    rows 1, H-2 / columns 1, W-2 -- against torch's reflection_pad2d + conv2d autograd on the CPU at the data-gradient gate, the
+    weight gradient beside it, and twice the same bits (every element of dX has one writer)."""
+    monkeypatch.setattr(ops, "_WINO", "force")
+    monkeypatch.setattr(ops, "_WINO4", "force" if w4 == "F(4x4)" else "off")
+    monkeypatch.setattr(ops, "_RING", "force")
+    ops._geom_cache.clear()
+    try:
+        xs, cout, k, stride, pad, mode = case
+        seed = zlib.crc32(("ring" + str(case)).encode()) % 10000
+        x = rnd(seed, *xs)
+        w = rnd(seed + 1, cout, xs[1], *k, scale=(1.0 / (xs[1] * 9) ** 0.5))
+        xr, wr = (t.clone().requires_grad_(True) for t in (x, w))
+        yr = _ref_conv(xr, wr, None, stride, pad, mode, None)
+        go = rnd(seed + 3, *yr.shape)
+        (yr * go).sum().backward()
+        grads = []
+        for _ in range(2):
+            xg, wg = (g(t).requires_grad_(True) for t in (x, w))
+            y = ops.conv(xg, wg, None, stride=stride, padding=pad, padding_mode=mode)
+            pl = ops._plan(xg, wg, (1, 1, 1), (0, 1, 1), True)
+            assert pl.wino_dgrad and pl.ring_dgrad and pl.wino4_dgrad == (w4 == "F(4x4)")
+            (y * g(go)).sum().backward()
+            grads.append(xg.grad.clone())
+        rel_close(grads[0], xr.grad, 5e-5, f"reflect dgrad: {w4} interior + ring")
+        # the ring rows / columns alone (the interior dominates the tensor scale): rows 1, H-2 and columns 1, W-2
+        H, W = xs[2], xs[3]
+        for sl in ((slice(None), slice(None), [1, H - 2], slice(None)), (slice(None), slice(None), slice(None), [1, W - 2])):
+            rel_close(grads[0][sl], xr.grad[sl], 5e-5, f"reflect dgrad, ring targets: {w4}")
+        rel_close(wg.grad, wr.grad, 1e-4, "wgrad beside the ring route")
+        assert torch.equal(grads[0], grads[1]), "interior + ring must be bit-repeatable"
+    finally:
+        ops._geom_cache.clear()
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}_k{c[2]}_s{c[3]}_{c[5]}")
