@@ -16,27 +16,34 @@
 //   right   dX[m][i][W-2] += sum_c sum_ky w[c][m][ky][2] dY[c][i+1-ky][W-1]
 // i.e. four small GEMMs  M x 3C x (N * line length)  on v_mfma_f32_32x32x2_f32 (exact fp32), 3/9 * (2W + 2H) / (H W) of the
 // layer's direct FLOPs (1.6 % at 64x128).  The four targets (1 | H-2, 1 | W-2) of a plane receive THREE ring terms each (row
-// side, column side and the true corner of dXp): the GEMM part skips them and one thread per (image, channel, corner) sums its
-// seven (tap, dY element) products over the channels -- so every element of dX has exactly one writer in this launch, the
-// read-modify-write needs no atomics and the result is bit-repeatable.  No padded scratch tensor, no separate fold pass.
+// side, column side and the true corner of dXp): the GEMM part skips them and the corner part -- one workgroup per (image,
+// corner), one thread per row -- sums their seven (tap, dY element) products over the channels.  So every element of dX has
+// exactly one writer in this launch: the read-modify-write needs no atomics and the result is bit-repeatable.  No padded scratch
+// tensor, no separate fold pass.
+//
+// GEMM part: one workgroup = one side x 64 line positions (pixels: images x positions, tiles may span images) x up to 256 rows.
+// The column sides read ONE useful float per 128-byte line of dY (elements W floats apart), and a fully divergent load costs the
+// texture path ~4 cycles per lane: the first version (three shifted copies of the line loaded per tap, re-gathered by every
+// 64-row tile) spent ~12 us PER 16-channel chunk in those gathers.  Now the 66 elements a tile needs (64 + one neighbour either
+// side) are loaded once per chunk into LDS -- every tap is the same slice read at another offset, the line ends are per-lane masks
+// -- and serve all the rows of the workgroup: 6-12x fewer line requests per CU.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RING_OOB 0x80000000u
 
 constexpr int RG_CK = 16;            // channels per chunk
-constexpr int RG_PX = 128;           // pixels (line positions x images) per workgroup
-constexpr int RG_MR = 64;            // rows (input channels of the layer = output rows of the GEMM) per workgroup
+constexpr int RG_PX = 64;            // pixels (line positions x images) per workgroup
 
 struct RingP {
     const float* A;                  // c2m_ring_pack: [side 4][chunk][tap 3][m-tile of 32][lane 64][8]
-    const float* w;                  // native [C][M][3][3] (corner part)
     const float* dY;                 // [N][C][H][W]
     float* dX;                       // [N][M][H][W], already holds the interior term
     int N, C, M, H, W;
-    int nchunks, mt32, mt64;
-    int pt[4];                       // pixel tiles of 128 per side
+    int nchunks, mt32, mgroups;      // 16-channel chunks, 32-row tiles, row groups of 128 * MTW rows
+    int pt[4];                       // pixel tiles of 64 per side
     int gemm_blocks, corner_blocks;
     unsigned dy_bytes;
 };
@@ -70,167 +77,220 @@ C2M_API int c2m_ring_pack(const float* w, float* apack, int C, int M, void* stre
     return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256, 2) void reflect_ring_dgrad_kernel(const RingP p) {
-    __shared__ float sB[3][RG_CK][RG_PX];            // the three shifted copies of a 16-channel slice of the line: 24 KB
+constexpr int RG_SP = 72;            // LDS pitch of a channel's 66-element slice
+
+// MTW = 32-row tiles per wave: the workgroup's four waves cover 128 * MTW rows of ALL 64 pixels
+template <int MTW>
+__global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kernel(const RingP p) {
+    __shared__ float sS[RG_CK][RG_SP];               // 16 channels x (pixel p0 - 1 .. p0 + 64) of the side's line(s)
+    __shared__ float sD[7][RG_CK];                   // corner part: the seven dY elements of 16 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W, HW = H * W;
-    if ((int)blockIdx.x < p.corner_blocks) {
-        // ---- corner targets: item = (image, corner, row m), m fastest
-        const long item = (long)blockIdx.x * 256 + tid;
-        const long total = (long)p.N * 4 * p.M;
-        if (item >= total) return;
-        const int m = (int)(item % p.M); const int r = (int)(item / p.M);
+    if ((int)blockIdx.x >= p.gemm_blocks) {
+        // ---- corner targets: block = (image, corner), thread = row m (looped over M in steps of 256).  Per 16-channel chunk the
+        // seven dY elements of every channel go through LDS (112 loads per block, not per row) and the weights come from the
+        // packed A fragments: 8 channels per 32-byte load, rows contiguous.
+        const int r = (int)blockIdx.x - p.gemm_blocks;
         const int corner = r & 3, n = r >> 2;
         const int ty = (corner & 1) ? H - 2 : 1, ey = (corner & 1) ? H + 1 : 0, kyr = (corner & 1) ? 2 : 0;
         const int tx = (corner & 2) ? W - 2 : 1, ex = (corner & 2) ? W + 1 : 0, kxr = (corner & 2) ? 2 : 0;
-        int tap[7], off[7];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {                // (ey, tx + 1): the ring ROW above / below the target, taps (kyr, k)
-            tap[k] = kyr * 3 + k; off[k] = (ey - kyr) * W + (tx + 1 - k);
+        const int side_row = (corner & 1) ? 1 : 0, side_col = (corner & 2) ? 3 : 2;
+        // term k = tid >> 4 of the loader threads (tid < 112): its dY element inside a channel plane
+        int my_off = 0;
+        {
+            const int k = tid >> 4;
+            if (k < 3) my_off = (ey - kyr) * W + (tx + 1 - k);                 // ring ROW above / below the target, taps (kyr, k)
+            else if (k < 6) my_off = (ty + 1 - (k - 3)) * W + (ex - kxr);      // ring COLUMN beside it, taps (k - 3, kxr)
+            else my_off = (ey - kyr) * W + (ex - kxr);                         // the corner of dXp, tap (kyr, kxr)
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {                // (ty + 1, ex): the ring COLUMN beside it, taps (k, kxr)
-            tap[3 + k] = k * 3 + kxr; off[3 + k] = (ty + 1 - k) * W + (ex - kxr);
-        }
-        tap[6] = kyr * 3 + kxr; off[6] = (ey - kyr) * W + (ex - kxr);        // (ey, ex): the corner of dXp
         const float* __restrict__ dy = p.dY + (long)n * p.C * HW;
-        const float* __restrict__ wm = p.w + (long)m * 9;
-        float acc = 0.f;
-        for (int c = 0; c < p.C; ++c) {
-            const float* __restrict__ wc = wm + (long)c * p.M * 9;
-            const float* __restrict__ dc = dy + (long)c * HW;
-            float s = 0.f;
+        const long a_tap = (long)p.mt32 * 512, a_chunk = 3 * a_tap, a_side = (long)p.nchunks * a_chunk;
+        for (int mbase = 0; mbase < p.M; mbase += 256) {
+            const int m = mbase + tid;
+            const int mc = m < p.M ? m : p.M - 1;
+            const float* __restrict__ am = p.A + (long)(mc >> 5) * 512 + (mc & 31) * 8;
+            float acc = 0.f;
+            for (int q = 0; q < p.nchunks; ++q) {
+                __syncthreads();
+                if (tid < 112) {
+                    const int c = q * RG_CK + (tid & 15);
+                    sD[tid >> 4][tid & 15] = c < p.C ? dy[(long)c * HW + my_off] : 0.f;
+                }
+                __syncthreads();
+                float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) s += wc[tap[k]] * dc[off[k]];
-            acc += s;
+                for (int k = 0; k < 7; ++k) {
+                    const int sd = k < 3 ? side_row : (k < 6 ? side_col : side_row);
+                    const int j = k < 3 ? k : (k < 6 ? k - 3 : kxr);
+                    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(am + sd * a_side + q * a_chunk + j * a_tap);
+                    const f32x4 e0 = a[0], e1 = a[1], o0 = a[64], o1 = a[65];      // even channels (kk = 0) / odd channels (lane + 32)
+                    const float* __restrict__ d = sD[k];
+                    s += e0[0] * d[0] + o0[0] * d[1] + e0[1] * d[2] + o0[1] * d[3] + e0[2] * d[4] + o0[2] * d[5] + e0[3] * d[6] + o0[3] * d[7]
+                       + e1[0] * d[8] + o1[0] * d[9] + e1[1] * d[10] + o1[1] * d[11] + e1[2] * d[12] + o1[2] * d[13] + e1[3] * d[14] + o1[3] * d[15];
+                }
+                acc += s;
+            }
+            if (m < p.M) {
+                float* __restrict__ d = p.dX + ((long)n * p.M + m) * HW + (long)ty * W + tx;
+                *d += acc;
+            }
         }
-        float* __restrict__ d = p.dX + ((long)n * p.M + m) * HW + (long)ty * W + tx;
-        *d += acc;
         return;
     }
-    // ---- GEMM part: blocks ordered side-major, then pixel tile, then 64-row tile (neighbours share the B lines in L2)
-    int b = (int)blockIdx.x - p.corner_blocks;
+    // ---- GEMM part (the first blocks of the grid: they are the long ones): side-major, then pixel tile, then row group
+    int b = (int)blockIdx.x;
     int side = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const int nb = p.pt[s] * p.mt64;
+        const int nb = p.pt[s] * p.mgroups;
         if (side == s && b >= nb) { b -= nb; side = s + 1; }
     }
-    const int mt = b % p.mt64, ptile = b / p.mt64;
+    const int mg = b % p.mgroups, ptile = b / p.mgroups;
     const bool rowside = side < 2;
     const int L = rowside ? W : H;                            // line length = targets per image on this side
     const long npix = (long)p.N * L;
     const int lbase = side == 1 ? (H - 1) * W : (side == 3 ? W - 1 : 0);      // first element of the dY line inside a plane
     const int es = rowside ? 1 : W;                           // element stride along the line
-    // loader role: pixel px = tid & 127, channel half hf = tid >> 7 (wave-uniform): 8 channels x 3 taps per chunk
-    const int lpx = tid & 127, hf = __builtin_amdgcn_readfirstlane(tid >> 7);
-    unsigned voff[3];
-    {
-        const long pp = (long)ptile * RG_PX + lpx;
-        const int n = (int)(pp / L), i = (int)(pp - (long)n * L);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int u = i + 1 - j;
-            const bool ok = pp < npix && u >= 0 && u < L;
-            voff[j] = ok ? (unsigned)(((long)n * p.C * HW + lbase + (long)u * es) * 4) : RING_OOB;
-        }
-    }
+    const long p0 = (long)ptile * RG_PX;
+    // loader roles: slice index x = 1 + (tid & 63) (pixel p0 + (tid & 63)) for the four channels 4 (tid >> 6) + e (wave-uniform);
+    // the two neighbour elements x = 0 / 65 of channel tid & 15 by the first 32 threads
+    auto slice_off = [&](long g) -> unsigned {
+        if (g < 0 || g >= npix) return RING_OOB;
+        const int n = (int)(g / L), u = (int)(g - (long)n * L);
+        return (unsigned)(((long)n * p.C * HW + lbase + (long)u * es) * 4);
+    };
+    const unsigned voff_main = slice_off(p0 + (tid & 63));
+    const unsigned voff_halo = tid < 32 ? slice_off(tid < 16 ? p0 - 1 : p0 + RG_PX) : RING_OOB;
+    const int cg = wave;                                      // = tid >> 6
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
-    // MFMA role: wave (wm = wave & 1: 32-row half, wn = wave >> 1: 64-pixel half), two 32x32 tiles side by side
-    const int wm = wave & 1, wn = wave >> 1;
-    const int t32 = mt * 2 + wm;
-    const bool rows_live = t32 < p.mt32;
-    const float* __restrict__ abase = p.A + ((((long)side * p.nchunks) * 3) * p.mt32 + t32) * 512 + lane * 8;
+    // MFMA roles: wave w owns the 32-row tiles t32 = (mg * 4 + w) * MTW + k, k < MTW, over both 32-pixel halves of the tile
+    const int t32_0 = (mg * 4 + wave) * MTW;
     const long a_tap = (long)p.mt32 * 512, a_chunk = 3 * a_tap;
+    const float* __restrict__ abase = p.A + ((long)side * p.nchunks) * a_chunk + lane * 8;
+    // line-end masks of this lane's two pixels: tap 0 reads the NEXT line position, tap 2 the previous one
+    bool m_next[2], m_prev[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long g = p0 + t * 32 + (lane & 31);
+        const int i = (int)(g % L);
+        m_next[t] = i != L - 1; m_prev[t] = i != 0;
+    }
 
-    float braw[3][8];
-    f32x4 araw[3][2];
+    float sraw[4], hraw = 0.f;
+    f32x4 araw[MTW][3][2];
     auto fetch = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = q * RG_CK + hf * 8 + e;             // wave-uniform
-            const int soff = c * HW * 4;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                braw[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, c < p.C ? voff[j] : RING_OOB, soff, 0));
+        for (int e = 0; e < 4; ++e) {
+            const int c = q * RG_CK + cg * 4 + e;             // wave-uniform
+            sraw[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, c < p.C ? voff_main : RING_OOB, c * HW * 4, 0));
         }
-        if (rows_live) {
+        if (wave == 0) {
+            const int c = q * RG_CK + (tid & 15);
+            hraw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rsy, (c < p.C && voff_halo != RING_OOB) ? voff_halo + (unsigned)(c * HW * 4) : RING_OOB, 0, 0));
+        }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(abase + q * a_chunk + j * a_tap);
-                araw[j][0] = a[0]; araw[j][1] = a[1];
+        for (int k = 0; k < MTW; ++k)
+            if (t32_0 + k < p.mt32) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(abase + q * a_chunk + j * a_tap + (long)(t32_0 + k) * 512);
+                    araw[k][j][0] = a[0]; araw[k][j][1] = a[1];
+                }
             }
-        }
     };
-    f32x16 acc[2];
+    f32x16 acc[MTW][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int k = 0; k < MTW; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][t][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MTW; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { araw[k][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; araw[k][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     fetch(0);
     for (int q = 0; q < p.nchunks; ++q) {
         __syncthreads();                                       // the previous chunk's fragment reads are done
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int e = 0; e < 4; ++e) sS[cg * 4 + e][1 + (tid & 63)] = sraw[e];
+        if (tid < 32) sS[tid & 15][tid < 16 ? 0 : 65] = hraw;
+        f32x4 a[MTW][3][2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sB[j][hf * 8 + e][lpx] = braw[j][e];
-        f32x4 a[3][2];
+        for (int k = 0; k < MTW; ++k)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { a[j][0] = araw[j][0]; a[j][1] = araw[j][1]; }
+            for (int j = 0; j < 3; ++j) { a[k][j][0] = araw[k][j][0]; a[k][j][1] = araw[k][j][1]; }
         __syncthreads();
         if (q + 1 < p.nchunks) fetch(q + 1);                   // in flight during this chunk's MFMAs
-        if (rows_live) {
-            const float* __restrict__ bb = &sB[0][lane >> 5][wn * 64 + (lane & 31)];
+        const float* __restrict__ bb = &sS[lane >> 5][(lane & 31) + 2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float av = e < 4 ? a[j][0][e & 3] : a[j][1][e & 3];
-                    const float b0 = bb[(j * RG_CK + 2 * e) * RG_PX], b1 = bb[(j * RG_CK + 2 * e) * RG_PX + 32];
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+            for (int e = 0; e < 8; ++e) {
+                float b0 = bb[2 * e * RG_SP - j], b1 = bb[2 * e * RG_SP - j + 32];
+                if (j == 0) { b0 = m_next[0] ? b0 : 0.f; b1 = m_next[1] ? b1 : 0.f; }
+                if (j == 2) { b0 = m_prev[0] ? b0 : 0.f; b1 = m_prev[1] ? b1 : 0.f; }
+#pragma unroll
+                for (int k = 0; k < MTW; ++k) {
+                    const float av = e < 4 ? a[k][j][0][e & 3] : a[k][j][1][e & 3];
+                    acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[k][0], 0, 0, 0);
+                    acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[k][1], 0, 0, 0);
                 }
-        }
+            }
     }
-    if (!rows_live) return;
-    // ---- dX[target] += acc: lane owns pixel column (lane & 31) of each tile, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
+    // ---- dX[target] += acc: lane owns pixel column (lane & 31) of each half, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const long pp = (long)ptile * RG_PX + wn * 64 + t * 32 + (lane & 31);
+        const long pp = p0 + t * 32 + (lane & 31);
         if (pp >= npix) continue;
         const int n = (int)(pp / L), i = (int)(pp - (long)n * L);
-        if (i == 1 || i == L - 2) continue;                    // the corner targets of the plane: one thread of the corner part each
+        if (i == 1 || i == L - 2) continue;                    // the corner targets of the plane: the corner part's
         const int ty = side == 0 ? 1 : (side == 1 ? H - 2 : i), tx = side == 2 ? 1 : (side == 3 ? W - 2 : i);
         float* __restrict__ d = p.dX + (long)n * p.M * HW + (long)ty * W + tx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = t32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < p.M) d[(long)m * HW] += acc[t][r];
+        for (int k = 0; k < MTW; ++k) {
+            if (t32_0 + k >= p.mt32) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (t32_0 + k) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) d[(long)m * HW] += acc[k][t][r];
+            }
         }
     }
 }
 
 // dX [N][M][H][W] += the ring terms of the reflect-pad-1 data gradient (see the head of this file); dX must already hold the
-// zero-padded "same" data gradient.  apack = c2m_ring_pack(w); dY [N][C][H][W]; w native [C][M][3][3].  H, W >= 4.
+// zero-padded "same" data gradient.  apack = c2m_ring_pack(w); dY [N][C][H][W]; w native [C][M][3][3] (unused since the corner
+// part reads the packed fragments too; kept in the signature for the reference-side binding).  H, W >= 4.
 C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const float* dY, float* dX, int N, int C, int M, int H,
                                    int W, void* stream) {
     C2M_ENTER();
+    (void)w;
     if (N <= 0 || C <= 0 || M <= 0) return 0;
     if (H < 4 || W < 4) return (int)hipErrorInvalidValue;
     const long dy_bytes = 4L * N * C * H * W, dx_bytes = 4L * N * M * H * W;
     if (dy_bytes >= 0x80000000L || dx_bytes >= 0x80000000L) return (int)hipErrorInvalidValue;
     if ((((uintptr_t)apack) & 15) != 0) return (int)hipErrorInvalidValue;
     RingP p;
-    p.A = apack; p.w = w; p.dY = dY; p.dX = dX;
+    p.A = apack; p.dY = dY; p.dX = dX;
     p.N = N; p.C = C; p.M = M; p.H = H; p.W = W;
-    p.nchunks = c2m_cdiv(C, RG_CK); p.mt32 = c2m_cdiv(M, 32); p.mt64 = c2m_cdiv(M, RG_MR);
+    p.nchunks = c2m_cdiv(C, RG_CK); p.mt32 = c2m_cdiv(M, 32);
+    const int mtw = M <= 128 ? 1 : 2;
+    p.mgroups = c2m_cdiv(p.mt32, 4 * mtw);
     p.pt[0] = p.pt[1] = c2m_cdiv((long)N * W, RG_PX);
     p.pt[2] = p.pt[3] = c2m_cdiv((long)N * H, RG_PX);
-    p.gemm_blocks = (p.pt[0] + p.pt[1] + p.pt[2] + p.pt[3]) * p.mt64;
-    p.corner_blocks = c2m_cdiv((long)N * 4 * M, 256);
+    p.gemm_blocks = (p.pt[0] + p.pt[1] + p.pt[2] + p.pt[3]) * p.mgroups;
+    p.corner_blocks = N * 4;
     p.dy_bytes = (unsigned)dy_bytes;
-    hipLaunchKernelGGL(reflect_ring_dgrad_kernel, dim3((unsigned)(p.corner_blocks + p.gemm_blocks)), dim3(256), 0, (hipStream_t)stream, p);
+    static const int part = [] { const char* e = getenv("C2M_RING_PART"); return e ? atoi(e) : 0; }();      // timing diagnostics only
+    if (part == 1) p.corner_blocks = 0;                         // GEMM part only (wrong corner targets)
+    if (part == 2) { p.gemm_blocks = 0; p.pt[0] = p.pt[1] = p.pt[2] = p.pt[3] = 0; }      // corner part only
+    if (p.corner_blocks + p.gemm_blocks == 0) return 0;
+    const dim3 grid((unsigned)(p.corner_blocks + p.gemm_blocks));
+    if (mtw == 1) hipLaunchKernelGGL(reflect_ring_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else          hipLaunchKernelGGL(reflect_ring_dgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

@@ -35,8 +35,18 @@ def run(mode, shape, min_pix=None):
         gx = ops._conv_dgrad(pl, w, gy, True)
     e1.record()
     torch.cuda.synchronize()
+    total_us = e0.elapsed_time(e1) / reps * 1000.0
+    if pl.ring_dgrad:                       # the ring launch alone
+        L = ops._lib.lib()
+        Ar = ops._ring_pack(w, Cout, Cin)
+        e0.record()
+        for _ in range(reps):
+            L.c2m_reflect_ring_dgrad(ops._p(Ar), ops._p(w), ops._p(gy), ops._p(gx), N, Cout, Cin, H, W, ops._stream())
+        e1.record()
+        torch.cuda.synchronize()
+        run.ring_us = e0.elapsed_time(e1) / reps * 1000.0
     route = ("ring+" if pl.ring_dgrad else "padded+") + ("F4" if pl.wino4_dgrad else ("F2" if pl.wino_dgrad else "direct"))
-    return e0.elapsed_time(e1) / reps * 1000.0, route, gx
+    return total_us, route, gx
 
 
 print(f"{'shape (N,Cin,H,W,Cout)':32s} {'padded us':>10s} {'route':>12s} {'ring us':>10s} {'route':>10s} {'speedup':>8s} max|diff|/scale")
@@ -44,4 +54,4 @@ for sh in SHAPES:
     ta, ra, ga = run("off", sh)
     tb, rb, gb = run("auto", sh, 1)
     d = float((ga - gb).abs().max() / ga.abs().max())
-    print(f"{str(sh):32s} {ta:10.1f} {ra:>12s} {tb:10.1f} {rb:>10s} {ta / tb:8.2f} {d:.2e}")
+    print(f"{str(sh):32s} {ta:10.1f} {ra:>12s} {tb:10.1f} {rb:>10s} {ta / tb:8.2f} {d:.2e}   ring launch alone {getattr(run, 'ring_us', 0):.1f} us")
