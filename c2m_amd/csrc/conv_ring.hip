@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RING_OOB 0x80000000u
 
 constexpr int RG_CK = 16;            // channels per chunk
-constexpr int RG_PX = 64;            // pixels (line positions x images) per workgroup
+constexpr int RG_PX = 64;            // pixels (line positions x images) per workgroup of a row side; column sides: 32
 
 struct RingP {
     const float* A;                  // c2m_ring_pack: [side 4][chunk][tap 3][m-tile of 32][lane 64][8]
@@ -45,6 +45,7 @@ struct RingP {
     int nchunks, mt32, mgroups;      // 16-channel chunks, 32-row tiles, row groups of 128 * MTW rows
     int pt[4];                       // pixel tiles of 64 per side
     int gemm_blocks, corner_blocks;
+    int diag;                        // timing diagnostics (C2M_RING_DIAG): 1 no epilogue, 2 no MFMAs, 4 no dY gathers, 8 no A loads
     unsigned dy_bytes;
 };
 
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
     const long npix = (long)p.N * L;
     const int lbase = side == 1 ? (H - 1) * W : (side == 3 ? W - 1 : 0);      // first element of the dY line inside a plane
     const int es = rowside ? 1 : W;                           // element stride along the line
-    const long p0 = (long)ptile * RG_PX;
+    const int nhalf = rowside ? 2 : 1;                        // 32-pixel halves per tile: rows 64 pixels, columns 32 (see RG_PX)
+    const int tpx = 32 * nhalf;
+    const long p0 = (long)ptile * tpx;
     // loader roles: slice index x = 1 + (tid & 63) (pixel p0 + (tid & 63)) for the four channels 4 (tid >> 6) + e (wave-uniform);
     // the two neighbour elements x = 0 / 65 of channel tid & 15 by the first 32 threads
     auto slice_off = [&](long g) -> unsigned {
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         const int n = (int)(g / L), u = (int)(g - (long)n * L);
         return (unsigned)(((long)n * p.C * HW + lbase + (long)u * es) * 4);
     };
-    const unsigned voff_main = slice_off(p0 + (tid & 63));
-    const unsigned voff_halo = tid < 32 ? slice_off(tid < 16 ? p0 - 1 : p0 + RG_PX) : RING_OOB;
+    const unsigned voff_main = (tid & 63) < tpx ? slice_off(p0 + (tid & 63)) : RING_OOB;
+    const unsigned voff_halo = tid < 32 ? slice_off(tid < 16 ? p0 - 1 : p0 + tpx) : RING_OOB;
     const int cg = wave;                                      // = tid >> 6
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dY), 0, p.dy_bytes, 0x00020000);
     // MFMA roles: wave w owns the 32-row tiles t32 = (mg * 4 + w) * MTW + k, k < MTW, over both 32-pixel halves of the tile
@@ -182,17 +185,18 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
     auto fetch = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            if (p.diag & 4) break;
             const int c = q * RG_CK + cg * 4 + e;             // wave-uniform
             sraw[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, c < p.C ? voff_main : RING_OOB, c * HW * 4, 0));
         }
-        if (wave == 0) {
+        if (wave == 0 && !(p.diag & 4)) {
             const int c = q * RG_CK + (tid & 15);
             hraw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 rsy, (c < p.C && voff_halo != RING_OOB) ? voff_halo + (unsigned)(c * HW * 4) : RING_OOB, 0, 0));
         }
 #pragma unroll
         for (int k = 0; k < MTW; ++k)
-            if (t32_0 + k < p.mt32) {
+            if (t32_0 + k < p.mt32 && !(p.diag & 8)) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(abase + q * a_chunk + j * a_tap + (long)(t32_0 + k) * 512);
@@ -216,8 +220,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
     for (int q = 0; q < p.nchunks; ++q) {
         __syncthreads();                                       // the previous chunk's fragment reads are done
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sS[cg * 4 + e][1 + (tid & 63)] = sraw[e];
-        if (tid < 32) sS[tid & 15][tid < 16 ? 0 : 65] = hraw;
+        for (int e = 0; e < 4; ++e)
+            if ((tid & 63) < tpx) sS[cg * 4 + e][1 + (tid & 63)] = sraw[e];      // (column sides: 32 live lanes; index tpx + 1 is the neighbour element's)
+        if (tid < 32) sS[tid & 15][tid < 16 ? 0 : tpx + 1] = hraw;
         f32x4 a[MTW][3][2];
 #pragma unroll
         for (int k = 0; k < MTW; ++k)
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         __syncthreads();
         if (q + 1 < p.nchunks) fetch(q + 1);                   // in flight during this chunk's MFMAs
         const float* __restrict__ bb = &sS[lane >> 5][(lane & 31) + 2];
+        if (p.diag & 2) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -237,15 +243,16 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
                 for (int k = 0; k < MTW; ++k) {
                     const float av = e < 4 ? a[k][j][0][e & 3] : a[k][j][1][e & 3];
                     acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[k][0], 0, 0, 0);
-                    acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[k][1], 0, 0, 0);
+                    if (rowside) acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[k][1], 0, 0, 0);
                 }
             }
     }
+    if (p.diag & 1) return;
     // ---- dX[target] += acc: lane owns pixel column (lane & 31) of each half, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const long pp = p0 + t * 32 + (lane & 31);
-        if (pp >= npix) continue;
+        if (t >= nhalf || pp >= npix) continue;
         const int n = (int)(pp / L), i = (int)(pp - (long)n * L);
         if (i == 1 || i == L - 2) continue;                    // the corner targets of the plane: the corner part's
         const int ty = side == 0 ? 1 : (side == 1 ? H - 2 : i), tx = side == 2 ? 1 : (side == 3 ? W - 2 : i);
@@ -278,13 +285,17 @@ C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const flo
     p.A = apack; p.dY = dY; p.dX = dX;
     p.N = N; p.C = C; p.M = M; p.H = H; p.W = W;
     p.nchunks = c2m_cdiv(C, RG_CK); p.mt32 = c2m_cdiv(M, 32);
-    const int mtw = M <= 128 ? 1 : 2;
+    // 128 rows per workgroup (MTW = 1): the column sides are bound by their divergent gathers and read-modify-writes (one 128-byte
+    // line per element), which only more workgroups spread -- 256-row groups (MTW = 2) halved them and measured slower
+    const int mtw = 1;
     p.mgroups = c2m_cdiv(p.mt32, 4 * mtw);
-    p.pt[0] = p.pt[1] = c2m_cdiv((long)N * W, RG_PX);
-    p.pt[2] = p.pt[3] = c2m_cdiv((long)N * H, RG_PX);
+    p.pt[0] = p.pt[1] = c2m_cdiv((long)N * W, 64);
+    p.pt[2] = p.pt[3] = c2m_cdiv((long)N * H, 32);
     p.gemm_blocks = (p.pt[0] + p.pt[1] + p.pt[2] + p.pt[3]) * p.mgroups;
     p.corner_blocks = N * 4;
     p.dy_bytes = (unsigned)dy_bytes;
+    static const int diag = [] { const char* e = getenv("C2M_RING_DIAG"); return e ? atoi(e) : 0; }();
+    p.diag = diag;
     static const int part = [] { const char* e = getenv("C2M_RING_PART"); return e ? atoi(e) : 0; }();      // timing diagnostics only
     if (part == 1) p.corner_blocks = 0;                         // GEMM part only (wrong corner targets)
     if (part == 2) { p.gemm_blocks = 0; p.pt[0] = p.pt[1] = p.pt[2] = p.pt[3] = 0; }      // corner part only

@@ -88,7 +88,7 @@ _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect 
 # reflect-padded 3x3 data gradients as interior (exact domain, Winograd) + pad ring (conv_ring.hip): "auto" (maps of >= C2M_RING_MIN_PIX
 # pixels) | "off" (padded domain + two-target epilogue + fold, rounds 1-4) | "force" (tests: every eligible layer with H, W >= 4)
 _RING = os.environ.get("C2M_RING", "auto")
-_RING_MIN_PIX = int(os.environ.get("C2M_RING_MIN_PIX", "2048"))
+_RING_MIN_PIX = int(os.environ.get("C2M_RING_MIN_PIX", "1024"))
 _WINO4 = os.environ.get("C2M_WINO4", "auto")       # F(4x4,3x3) for the 2-D Winograd layers: "off" | "auto" (rule: _wino4_pays) | "force" (tests: every eligible 2-D Winograd launch)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
