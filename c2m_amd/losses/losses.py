@@ -14,39 +14,54 @@ from ..utils.utils import isnan
 _TAPS = ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1")
 
 
+_STYLE_TAPS = ("relu2_2", "relu3_4", "relu4_4", "relu5_2")
+
+
 class PerceptualLoss(nn.Module):
     def __init__(self, train_params):
         super().__init__()
         self.train_params = train_params
         style = train_params["loss_weights"].get("style", 0) > 0
-        # without the style term only relu{1..5}_1 are consumed: stop there
-        self.vgg19 = Vgg19(stop_after="relu5_4" if style else "relu5_1")
+        # without the style term only relu{1..5}_1 are consumed: stop there; with it the deepest slice read is
+        # relu5_2 (losses.py:48-56) -- the module keeps all 16 slices either way (state_dict surface), evaluation stops early
+        self.vgg19 = Vgg19(stop_after="relu5_2" if style else "relu5_1")
         self.criterion = nn.L1Loss()
 
     @staticmethod
     def compute_gram(x):
         b, ch, h, w = x.size()
-        f = x.view(b, ch, w * h)
+        f = x.float().view(b, ch, w * h)
         return f.bmm(f.transpose(1, 2)) / (h * w * ch)
 
     def forward(self, gt, fake):
         T = self.train_params["num_predicted_frames"]
         w = self.train_params["loss_weights"]
         out = {}
-        if w.get("style", 0) > 0:
-            raise NotImplementedError("style loss (weight 0 in every shipped config) is not on the C2M-AMD path")
-        if w.get("perceptual", 0) > 0:
-            B = gt.shape[0]
-            # frame-major fold: rows [t*B:(t+1)*B] are frame t -> per-frame means are recovered from one VGG pass
-            with torch.no_grad():
-                x_feats = self.vgg19(fold_time(gt))
-            # the feature L1 of every tap comes out of the VGG pass itself (fused tap backward, ops.conv_relu_tap)
-            y_feats = self.vgg19(fold_time(fake), tap_targets={k: x_feats[k] for k in _TAPS})
-            content = 0.0
+        style = w.get("style", 0) > 0
+        content = w.get("perceptual", 0) > 0
+        if not (style or content):
+            return out
+        B = gt.shape[0]
+        # frame-major fold: rows [t*B:(t+1)*B] are frame t -> per-frame means are recovered from one VGG pass
+        with torch.no_grad():
+            x_feats = self.vgg19(fold_time(gt))
+        # the feature L1 of every tap comes out of the VGG pass itself (fused tap backward, ops.conv_relu_tap)
+        y_feats = self.vgg19(fold_time(fake), tap_targets={k: x_feats[k] for k in _TAPS} if content else None,
+                             need=_STYLE_TAPS if style else ())
+        if content:
+            total = 0.0
             for k in _TAPS:
                 # sum_t mean_frame|x - y| = T * mean_all|x - y| because every frame contributes equally many elements
-                content = content + y_feats["l1"][k] * T
-            out["perceptual"] = content / T
+                total = total + y_feats["l1"][k] * T
+            out["perceptual"] = total / T
+        if style:
+            # Gram branch (losses.py:32-59): per frame L1 between the [B, ch, ch] Gram matrices of four slices, summed over frames
+            # and divided by T.  Every frame contributes B*ch*ch elements, so sum_t mean_t = T * mean over all T*B matrices.
+            # Small batched GEMMs on PyTorch device ops (weight 0 in every shipped config: plumbing, not a hot path).
+            total = 0.0
+            for k in _STYLE_TAPS:
+                total = total + self.criterion(self.compute_gram(y_feats[k]), self.compute_gram(x_feats[k]).detach()) * T
+            out["style"] = total / T
         return out
 
 

@@ -53,7 +53,7 @@ class Vgg19(torch.nn.Module):
             for param in self.parameters():
                 param.requires_grad = False
 
-    def forward(self, x, tap_targets=None):
+    def forward(self, x, tap_targets=None, need=()):
         """tap_targets (optional): {slice name: target feature map without gradient}; those slices also return mean|y - target|
         (the perceptual loss's feature L1, losses/losses.py:60-65) under out["l1"][name], with the L1 gradient, the sum with the
         next conv's data gradient and the ReLU mask fused into one backward pass (ops.conv_relu_tap)."""
@@ -73,7 +73,8 @@ class Vgg19(torch.nn.Module):
                 x = ops.maxpool2x2(x)
             else:
                 c = getattr(self, name)._modules[str(i)]
-                fuse_pool = tap_targets is not None and name not in tap_targets and j + 1 < len(flat) and flat[j + 1][0] == "pool"
+                fuse_pool = tap_targets is not None and name not in tap_targets and name not in need and j + 1 < len(flat) and \
+                    flat[j + 1][0] == "pool"
                 if tap_targets is not None and name in tap_targets:
                     x, l1[name] = ops.conv_relu_tap(x, c.weight, c.bias, tap_targets[name])
                 elif fuse_pool:

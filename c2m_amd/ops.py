@@ -89,6 +89,7 @@ _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect 
 # pixels) | "off" (padded domain + two-target epilogue + fold, rounds 1-4) | "force" (tests: every eligible layer with H, W >= 4)
 _RING = os.environ.get("C2M_RING", "auto")
 _RING_MIN_PIX = int(os.environ.get("C2M_RING_MIN_PIX", "1024"))
+_RING_F2_MAX_PIX = int(os.environ.get("C2M_RING_F2_MAX_PIX", "4096"))      # largest map on which an F(2x2) interior + ring beats the padded domain
 _WINO4 = os.environ.get("C2M_WINO4", "auto")       # F(4x4,3x3) for the 2-D Winograd layers: "off" | "auto" (rule: _wino4_pays) | "force" (tests: every eligible 2-D Winograd launch)
 _WINO = os.environ.get("C2M_WINOGRAD", "auto")      # "auto" | "off" | "force" (tests: every eligible shape)
 # Winograd WEIGHT gradient (round 2: fragments built in registers from raw LDS patches): "auto" = the layers where it beats
@@ -691,12 +692,17 @@ class _ConvPlan:
             if reflect and dM == Cin and _RING != "off" and Hi >= 4 and Wi >= 4 and (_RING == "force" or Hi * Wi >= _RING_MIN_PIX):
                 eregions = N * L.c2m_wino_regions(Hi, Wi)
                 efit = N * Hi * Wi >= 0.8 * eregions * 128
-                if _WINO == "force" or (_WINO == "auto" and efit and Cout >= 32 and rows_ok(Cin) and
-                                        eregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS):
+                w4e = _wino4_pays(L, Cin, Cout, N, Hi, Wi)
+                # measured per shape in the step (profiles/r05_ab_ring_*): the route pays where the exact domain moves the layer to
+                # F(4x4) (1.3-1.65x) and on the <= 32 x 64 maps whose padded domain wastes a third of the F(2x2) regions (1.14-1.26x);
+                # F(2x2) layers on >= 64 x 128 maps (padded fill 0.8-0.9) gain less than the ring launch costs
+                pays = _RING == "force" or w4e or Hi * Wi <= _RING_F2_MAX_PIX
+                if pays and (_WINO == "force" or (_WINO == "auto" and efit and Cout >= 32 and rows_ok(Cin) and
+                                                  eregions * _cdiv(Cin, 64) >= _WINO_MIN_WGS)):
                     self.wino_dgrad = self.ring_dgrad = True
                     self.wino_dgrad_geom = _wino_geom(
                         [Cin, Cout, N, Ho, Wo, Hi, Wi, -1, -1, 0, Cout * osp, osp, Wo, Cin * in_sc, in_sc, Wi, 0, 4 * N * Cout * osp])
-                    self.wino4_dgrad = _wino4_pays(L, Cin, Cout, N, Hi, Wi)
+                    self.wino4_dgrad = w4e
             Hd, Wd = (Hi + 2, Wi + 2) if reflect else (Hi, Wi)
             dregions = N * L.c2m_wino_regions(Hd, Wd)
             dfit = N * Hd * Wd >= _WINO_DFIT * dregions * 128

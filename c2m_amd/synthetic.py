@@ -48,7 +48,7 @@ class GraphBatch:
 
 
 def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_predicted_frames=5,
-               num_objects=3, seed=0, device="cpu"):
+               num_objects=3, seed=0, device="cpu", use_fw_of=False):
     g = torch.Generator(device="cpu").manual_seed(seed)
     B, H, W = batch_size, height, width
     T = num_input_frames + num_predicted_frames
@@ -114,11 +114,17 @@ def make_batch(batch_size=1, height=128, width=256, num_input_frames=2, num_pred
     if num_input_frames > 1:
         batch["input_of"] = 2.0 * torch.randn(B, 2, num_input_frames - 1, H, W, generator=g)
         batch["input_occ"] = (torch.rand(B, 1, num_input_frames - 1, H, W, generator=g) > 0.2).float()
+    if use_fw_of:
+        # forward flow / occlusion targets of the `use_fw_of: True` branch (dense_motion.py:71-87, losses.py:211-216): drawn from
+        # their OWN generator so that the tensors above keep the values every older fixture was captured with
+        g2 = torch.Generator(device="cpu").manual_seed(seed + 7919)
+        batch["target_fw_of"] = 2.0 * torch.randn(B, 2, num_predicted_frames, H, W, generator=g2)
+        batch["target_fw_occ"] = (torch.rand(B, 1, num_predicted_frames, H, W, generator=g2) > 0.2).float()
     return batch_to(batch, device)
 
 
 def make_stream_batch(streams=1, windows=2, height=128, width=256, num_input_frames=2, num_predicted_frames=5,
-                      num_objects=3, seed=0, device="cpu"):
+                      num_objects=3, seed=0, device="cpu", use_fw_of=False):
     """BASELINE configs[4] ("14-frame clips"): t_out is fixed at 5 by the model (UpBlock2d chunk(5, 0)),
     so a 14-frame stream sample is cut into `windows` consecutive 7-frame windows that are stacked along the batch axis
      -- window w of stream s is clip s * windows + w.  Every synthetic field is drawn i.i.d. per frame (and
@@ -126,7 +132,7 @@ def make_stream_batch(streams=1, windows=2, height=128, width=256, num_input_fra
     same distribution; the windows are drawn directly."""
     if windows < 1 or streams < 1:
         raise ValueError("streams and windows must be >= 1")
-    return make_batch(streams * windows, height, width, num_input_frames, num_predicted_frames, num_objects, seed, device)
+    return make_batch(streams * windows, height, width, num_input_frames, num_predicted_frames, num_objects, seed, device, use_fw_of)
 
 
 def batch_to(batch, device):

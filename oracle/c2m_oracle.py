@@ -342,7 +342,10 @@ def generate_sparse_motion(cfg, gnn, thetas, source_instance, use_gt):
             bw[bi, :, t] = torch.where(warped == 1, flow, bw[bi, :, t])
             fw[bi, :, t] = torch.where(mask == 1, flow * -1, fw[bi, :, t])
             binm[bi, :, t] = torch.where(warped == 1, warped, binm[bi, :, t])
-    out = {"sparse_motion_bw": bw.detach(), "sparse_motion_bin": binm, "_sparse_motion_fw": fw.detach()}
+    out = {"sparse_motion_bw": bw.detach()}
+    if cfg["train_params"].get("use_fw_of", False):                                  # :144-145 (key order of the reference's dict)
+        out["sparse_motion_fw"] = fw.detach()
+    out.update({"sparse_motion_bin": binm, "_sparse_motion_fw": fw.detach()})
     out["sparse_occ_bw"] = torch.stack([clip_mask(occlusion_map(fw[:, :, i])) for i in range(T)], 2)
     out["sparse_occ_fw"] = torch.stack([clip_mask(occlusion_map(bw[:, :, i])) for i in range(T)], 2)
     return out
@@ -404,7 +407,7 @@ def dense_motion_decoder(S, p, cfg, app, sparse_feats, sparse_motion, sparse_occ
 
 
 def dense_motion_network(S, cfg, app, mi, rng, training=True, p="motion_encoder"):
-    """motion_estimator/dense_motion.py:170-235 (forward, use_fw_of False)."""
+    """motion_estimator/dense_motion.py:170-235 (forward; the use_fw_of branch :216-219,226-234 since round 5)."""
     tp, cp = cfg["train_params"], cfg["model_params"]["common_params"]
     t_in, T = tp["num_input_frames"], tp["num_predicted_frames"]
     ap = cfg["model_params"]["appearance_encoder"]
@@ -434,10 +437,16 @@ def dense_motion_network(S, cfg, app, mi, rng, training=True, p="motion_encoder"
     codex = app["app_encoded"].unsqueeze(2).repeat(1, 1, T, 1, 1)
     code = torch.cat(torch.chunk(code.unsqueeze(2), T, 1), 2)
     z = torch.cat([codex, code], 1)
+    if tp.get("use_fw_of", False):                                                   # :216-219, 226-228: the SAME sparse encoder
+        sparse_feats_fw = sparse_feature_encoder(S, cfg, sparse["sparse_motion_fw"], training)
+        flow_fw, occ_fw = dense_motion_decoder(S, p + ".dense_generator_fw", cfg, app, sparse_feats_fw,
+                                               sparse["sparse_motion_fw"], sparse["sparse_occ_fw"], z, training)
     flow, occ = dense_motion_decoder(S, p + ".dense_generator_bw", cfg, app, sparse_feats,
                                      sparse["sparse_motion_bw"], sparse["sparse_occ_bw"], z, training)
     out.update({k: v for k, v in sparse.items() if not k.startswith("_")})
     out["dense_motion_bw"], out["occlusion_bw"] = flow, occ
+    if tp.get("use_fw_of", False):
+        out["dense_motion_fw"], out["occlusion_fw"] = flow_fw, occ_fw
     return out
 
 
@@ -489,7 +498,7 @@ def flow_embedder(S, p, cfg, x, training=True):
     return outs[nd:][::-1]
 
 
-def generator(S, cfg, first_frame, flow, occ, training=True, p="generator"):
+def generator(S, cfg, first_frame, flow, occ, training=True, p="generator", dataset="cityscapes"):
     """generator/generator.py:126-158 (cityscapes branch; both use_spade values)."""
     gp = cfg["model_params"]["generator"]
     nd, pm = gp["num_down_blocks"], gp["padding_mode"]
@@ -510,6 +519,14 @@ def generator(S, cfg, first_frame, flow, occ, training=True, p="generator"):
         x = warped * o
     for i in range(gp["num_bottleneck_blocks"]):
         x = residual_block(S, f"{p}.middle.{i}", x, training)
+    if "kitti" in dataset:                                                          # generator.py:139-145
+        xw = same_block2d(S, p + ".first_warped", resample(first_frame, flow), 7, pm)
+        for i in range(nd):
+            xw = down_block2d(S, f"{p}.down_blocks_warped.{i}", xw, pm, training)
+        o = occ
+        if xw.shape[2:] != o.shape[2:]:
+            o = F.interpolate(o, size=xw.shape[2:], mode="bilinear")
+        x = same_block2d(S, p + ".pre_decode.0", torch.cat([x, xw * o], dim=1), 3, pm)
     for i in range(nd):
         if gp["use_spade"]:
             cond = feats[nd - i]
@@ -569,35 +586,88 @@ def kl_loss(mu, lv):
     return (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())) / mu.numel()
 
 
-def perceptual_loss(S, p, gt, fake, T):
-    """losses/losses.py:23-70 (style weight 0): sum_t sum_l L1(vgg(gt)_l.detach, vgg(fake)_l) / T; None if not > 0."""
-    content = 0.0
+def compute_gram(x):
+    """losses/losses.py:32-38."""
+    b, ch, h, w = x.size()
+    f = x.view(b, ch, w * h)
+    return f.bmm(f.transpose(1, 2)) / (h * w * ch)
+
+
+def perceptual_loss(S, p, gt, fake, T, weights=None):
+    """losses/losses.py:23-70: {"perceptual": sum_t sum_l L1(vgg(gt)_l.detach, vgg(fake)_l) / T, "style": the same over the Gram
+    matrices of relu2_2 / relu3_4 / relu4_4 / relu5_2} -- each only when its weight is > 0 and the sum is > 0 (:66-69)."""
+    weights = weights or {"perceptual": 1, "style": 0}
+    content, style = 0.0, 0.0
     for i in range(T):
         a = vgg19_taps(S, p + ".vgg19", gt[:, :, i])
         b = vgg19_taps(S, p + ".vgg19", fake[:, :, i])
-        for k in ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1"):
-            content = content + F.l1_loss(b[k], a[k].detach())
-    return content / T if float(content.detach()) > 0 else None
+        if weights.get("style", 0) > 0:
+            for k in ("relu2_2", "relu3_4", "relu4_4", "relu5_2"):
+                style = style + F.l1_loss(compute_gram(b[k]), compute_gram(a[k].detach()))
+        if weights.get("perceptual", 0) > 0:
+            for k in ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1"):
+                content = content + F.l1_loss(b[k], a[k].detach())
+    out = {}
+    if torch.is_tensor(content) and float(content.detach()) > 0:
+        out["perceptual"] = content / T
+    if torch.is_tensor(style) and float(style.detach()) > 0:
+        out["style"] = style / T
+    return out
 
 
-def training_losses(S, cfg, frames, bw_of, bw_occ, gen, gnn, p="objective_func"):
-    """losses/losses.py:205-255 (use_fw_of False, flow_smooth weight 0)."""
+def smooth_loss(flow, image):
+    """losses/losses.py:73-112 SmoothLoss: edge-aware first differences of each flow component, time folded into the batch.
+    (The reference's `gradient_x` differences along H and `gradient_y` along W; kept.)"""
+    f, im = fold_time(flow), fold_time(image)
+
+    def gx(t): return t[:, :, :-1, :] - t[:, :, 1:, :]
+
+    def gy(t): return t[:, :, :, :-1] - t[:, :, :, 1:]
+    wx = torch.exp(-torch.mean(torch.abs(gx(im)), 1, True))
+    wy = torch.exp(-torch.mean(torch.abs(gy(im)), 1, True))
+    total = 0
+    for c in range(2):
+        fc = f[:, c:c + 1]
+        total = total + torch.mean(torch.abs(gx(fc) * wx)) + torch.mean(torch.abs(gy(fc) * wy))
+    return total / 2
+
+
+def flow_consist_loss(flow, flowback, mask_fw, mask_bw, T):
+    """losses/losses.py:115-140 FlowConsistLoss (masked form; called with the fw / bw occlusion maps at :215-216)."""
+    f, fb = fold_time(flow), fold_time(flowback)
+    nxt = torch.abs(resample(fb, f) + f)
+    prv = torch.abs(resample(f, fb) + fb)
+    if mask_bw is not None:
+        nxt, prv = fold_time(mask_fw) * nxt, fold_time(mask_bw) * prv
+    return (prv.mean() + nxt.mean()) * T
+
+
+def training_losses(S, cfg, frames, bw_of, bw_occ, gen, gnn, p="objective_func", fw_of=None, fw_occ=None):
+    """losses/losses.py:205-255 (the use_fw_of / flow_smooth / style branches since round 5)."""
     tp = cfg["train_params"]
     t_in, T = tp["num_input_frames"], tp["num_predicted_frames"]
     src, tgt = frames[:, :, t_in - 1], frames[:, :, t_in:]
     L = {}
     L["flow_reconstruction"] = masked_l1(gen["dense_motion_bw"], bw_of, bw_occ)
+    if fw_of is not None:                                                            # :211-216
+        L["flow_reconstruction"] = L["flow_reconstruction"] + masked_l1(gen["dense_motion_fw"], fw_of, fw_occ)
+        L["flowcon"] = flow_consist_loss(gen["dense_motion_fw"], gen["dense_motion_bw"], gen["occlusion_fw"],
+                                         gen["occlusion_bw"], T)
     warped = torch.stack([resample(src, gen["dense_motion_bw"][:, :, i]) for i in range(T)], 2)
     L["warped"] = masked_l1(warped, tgt)
+    if tp["loss_weights"]["flow_smooth"] > 0:                                       # :221-226
+        L["flow_smooth"] = smooth_loss(gen["dense_motion_bw"], tgt)
+        if fw_of is not None:
+            L["flow_smooth"] = L["flow_smooth"] + smooth_loss(gen["dense_motion_fw"], src.unsqueeze(2).repeat(1, 1, T, 1, 1))
     mu, lv = gen["mu"], gen["logvar"]
     L["kl"] = kl_loss(mu, lv)
     L["ssim"] = ssim_loss(fold_time(gen["generated"]), fold_time(tgt))
     L["reconstruction"] = masked_l1(gen["generated"], tgt)
     if tp["loss_weights"]["perceptual"] > 0:
-        pl = perceptual_loss(S, p + ".perceptual_loss", tgt, gen["generated"], T)
-        if pl is not None:
-            L["perceptual"] = pl
+        L.update(perceptual_loss(S, p + ".perceptual_loss", tgt, gen["generated"], T, tp["loss_weights"]))
     L["occlusion_bw"] = masked_l1(bw_occ, gen["occlusion_bw"])
+    if fw_of is not None:
+        L["occlusion_fw"] = masked_l1(fw_occ, gen["occlusion_fw"])
     tr = sc = ro = 0
     for t in range(T):                                                               # :244-250
         th, gt = gen[f"theta_{t}"], gnn.targets_theta[:, t]
@@ -675,6 +745,7 @@ def forward(S, cfg, batch, rng, training=True):
         enc_in = torch.cat([enc_in, stack_time_into_channels(input_of[:, :, :t_in]),
                             stack_time_into_channels(input_occ[:, :, :t_in])], 1)
     app = appearance_encoder(S, cfg, enc_in, gnn, training)
+    fw_of, fw_occ = batch.get("target_fw_of"), batch.get("target_fw_occ")           # model.py:148-153 (None unless the data has them)
     mi = dict(frames=frames, bg_mask=bg, fg_mask=fg, instance=instance, target_bw_of=bw_of, target_bw_occ=bw_occ,
               tracking_gnn=gnn, latent=rng["latent_traj"])
     out = dense_motion_network(S, cfg, app, mi, rng, training)
@@ -686,7 +757,7 @@ def forward(S, cfg, batch, rng, training=True):
         [resample(last, out["sparse_motion_bw"][:, :, i].detach()) for i in range(T)], 2).detach()
     out["generated_sparse_occ"] = torch.stack(
         [resample(last, out["sparse_motion_bw"][:, :, i].detach()) * out["sparse_occ_bw"][:, :, i] for i in range(T)], 2)
-    loss_g = training_losses(S, cfg, frames, bw_of, bw_occ, out, gnn)
+    loss_g = training_losses(S, cfg, frames, bw_of, bw_occ, out, gnn, fw_of=fw_of, fw_occ=fw_occ)
     loss_d_img, loss_d_vid = {}, {}
     if tp["use_image_discriminator"]:
         dr, df, gg, fm = d_losses(S, "netD_image", cfg, fold_time(batch["video"][:, :, t_in:]),

@@ -233,12 +233,14 @@ def capture_blocks():
     save("blk_perceptual", dict(block="perceptual", spec=spec, seed=2003), arrays)
 
 
-def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed):
+def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed, use_fw_of=False, loss_weights=None):
     from modules.model import GeneratorFullModel
     cfg = normalize_config(default_config(num_input_frames=t_in, block_expansion=4, max_expansion=32, h_dim=32,
                                           z_dim=16, out_channel=16, ndf=4, use_spade=use_spade,
                                           use_image_discriminator=use_d, use_video_discriminator=use_d))
     cfg["train_params"]["use_gt_training"] = use_gt_training
+    cfg["train_params"]["use_fw_of"] = use_fw_of
+    cfg["train_params"]["loss_weights"].update(loss_weights or {})
     ref_cfg = copy.deepcopy(cfg)
     model = GeneratorFullModel(train_params=ref_cfg["train_params"], model_params=ref_cfg["model_params"],
                                dataset="cityscapes")
@@ -251,7 +253,7 @@ def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed)
     del fresh
     model.load_state_dict(synth_state(spec, seed))
     model.train()
-    batch = make_batch(batch_size, 128, 256, t_in, seed=seed)
+    batch = make_batch(batch_size, 128, 256, t_in, seed=seed, use_fw_of=use_fw_of)
     gnn = batch["tracking_gnn"]
     N, B = gnn.x.shape[0], batch_size
     # replicate the reference's three random draws so the oracle/product can be fed the same values
@@ -304,7 +306,7 @@ def capture_e2e(name, t_in, use_spade, batch_size, use_gt_training, use_d, seed)
         if k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
             arrays["sum.buf." + k] = summarize(b)
     meta = dict(t_in=t_in, use_spade=use_spade, batch_size=batch_size, use_gt_training=use_gt_training,
-                use_d=use_d, seed=seed, spec=spec, cfg=cfg)
+                use_d=use_d, seed=seed, spec=spec, cfg=cfg, use_fw_of=use_fw_of)
     save(name, meta, arrays)
 
 
@@ -428,6 +430,95 @@ def capture_modules_round2():
     grad_in = tuple(k for k in din if k not in ("sparse_motion", "sparse_occlusion"))
     spec, arrays = run_module_compact(mod, 2200, din, call_dec, grad_in)
     save("mod_dense_decoder", dict(module="dense_decoder", spec=spec, seed=2200, decoder=dp, inputs=din), arrays)
+
+
+def capture_round5():
+    """Round 5: the branches that existed in the mirror but had never been compared with the reference --
+    the Gram style branch of PerceptualLoss (losses.py:32-59), SmoothLoss (:73-112) and FlowConsistLoss (:115-140) as stand-alone
+    modules, the "kitti" generator branch (generator.py:37-48,139-145), the stand-alone AppearanceEncoder
+    (appearance_encoder.py:54-78) and one whole training step with `use_fw_of: True` + flow_smooth / flowcon / style weights
+    (dense_motion.py:71-87,216-234; losses.py:211-226,241-242)."""
+    import losses.losses as L
+    from modules.generator.generator import OcclusionAwareGenerator
+    from modules.appearance_encoder.appearance_encoder import AppearanceEncoder
+
+    # ---- PerceptualLoss with the style branch on (both terms; VGG-19 weights synthesised, as in blk_perceptual)
+    tp = {"num_predicted_frames": 5, "loss_weights": {"perceptual": 10, "style": 250}}
+    mod = L.PerceptualLoss(tp)
+    gt = torch.rand(2, 3, 5, 32, 64, generator=torch.Generator().manual_seed(62))
+    fk = torch.rand(2, 3, 5, 32, 64, generator=torch.Generator().manual_seed(63))
+    spec, arrays = run_module(mod, 2004, {"gt": gt, "fake": fk}, grad_inputs=("fake",))
+    arrays = {k: v for k, v in arrays.items() if not k.startswith("buf.")}
+    save("blk_perceptual_style", dict(block="perceptual_style", spec=spec, seed=2004, train_params=tp), arrays)
+
+    # ---- SmoothLoss + FlowConsistLoss (masked and unmasked) on seeded flows
+    g = lambda s_, *sh: torch.randn(*sh, generator=torch.Generator().manual_seed(s_))
+    flow = (2.0 * g(70, 2, 2, 5, 24, 40)).requires_grad_(True)
+    flowback = (2.0 * g(71, 2, 2, 5, 24, 40)).requires_grad_(True)
+    img = torch.rand(2, 3, 5, 24, 40, generator=torch.Generator().manual_seed(72))
+    mfw = torch.rand(2, 1, 5, 24, 40, generator=torch.Generator().manual_seed(73)).requires_grad_(True)
+    mbw = torch.rand(2, 1, 5, 24, 40, generator=torch.Generator().manual_seed(74)).requires_grad_(True)
+    fc = L.FlowConsistLoss({"num_predicted_frames": 5})
+    sm = L.SmoothLoss()(flow, img)
+    c_masked = fc(flow, flowback, mfw, mbw)
+    c_plain = fc(flow, flowback)
+    (sm * 1.3 + c_masked * 0.7 + c_plain * 0.4).backward()
+    save("op_losses_flow", {"op": "losses_flow", "weights": [1.3, 0.7, 0.4]},
+         {"in.flow": flow, "in.flowback": flowback, "in.image": img, "in.mask_fw": mfw, "in.mask_bw": mbw,
+          "out.smooth": sm, "out.flowcon_masked": c_masked, "out.flowcon": c_plain,
+          "gin.flow": flow.grad, "gin.flowback": flowback.grad, "gin.mask_fw": mfw.grad, "gin.mask_bw": mbw.grad})
+
+    # ---- OcclusionAwareGenerator, dataset "kitti" (second encoder over the warped frame + pre_decode), both use_spade values
+    fp = dict(input_channel=6, block_expansion=4, num_down_blocks=3, max_expansion=32, padding_mode="reflect", use_decoder=True)
+    gin = {"first_frame": dict(seed=75, shape=[5, 3, 32, 64], kind="rand"),
+           "flow": dict(seed=76, shape=[5, 2, 32, 64], kind="randn", scale=2.0),
+           "occlusion_map": dict(seed=77, shape=[5, 1, 32, 64], kind="rand")}
+    for use_spade in (True, False):
+        gp = dict(block_expansion=4, num_down_blocks=3, max_expansion=32, num_bottleneck_blocks=2, padding_mode="reflect",
+                  use_skip=False, use_spade=use_spade)
+        mod = OcclusionAwareGenerator(copy.deepcopy(gp), copy.deepcopy(fp), input_channel=3, dataset="kitti")
+        seed = 2110 + int(use_spade)
+        spec, arrays = run_module_compact(mod, seed, gin, lambda m, **kw: m(kw["first_frame"], kw["flow"], kw["occlusion_map"]),
+                                          ("first_frame", "flow", "occlusion_map"))
+        save("mod_generator_kitti_" + ("spade" if use_spade else "nospade"),
+             dict(module="generator", dataset="kitti", spec=spec, seed=seed, generator=gp, flow_embedder=fp, inputs=gin), arrays)
+
+    # ---- stand-alone AppearanceEncoder (two input frames: the chunk / repeat_interleave quirks of :57-62, :72-76 with t_in = 2)
+    for t_in, bsz in ((2, 2), (1, 3)):
+        cfg = normalize_config(default_config(num_input_frames=t_in, block_expansion=4, max_expansion=32, h_dim=32, z_dim=16,
+                                              out_channel=16, ndf=4))
+        ref_cfg = copy.deepcopy(cfg)
+        mod = AppearanceEncoder(ref_cfg["train_params"], **ref_cfg["model_params"]["appearance_encoder"],
+                                **ref_cfg["model_params"]["common_params"])
+        seed = 2300 + t_in
+        spec = state_spec(mod.state_dict())
+        mod.load_state_dict(synth_state(spec, seed))
+        mod.train()
+        batch = make_batch(bsz, 128, 256, t_in, seed=seed)
+        cin = mod.down_blocks[0].conv.weight.shape[1]
+        fspec = dict(seed=seed + 1, shape=[bsz, cin, 128, 256], kind="rand")
+        first = synth_input(fspec).requires_grad_(True)
+        out = mod({"first_frame": first, "tracking_gnn": batch["tracking_gnn"].clone()})
+        total = 0
+        for i, (k, v) in enumerate(sorted(out.items())):
+            total = total + (v * rnd(seed + 100 + i, *v.shape)).sum()
+        total.backward()
+        arrays = {}
+        for k, v in out.items():
+            arrays.update(compact("out", k, v))
+        arrays.update(compact("gin", "first_frame", first.grad))
+        for k, p_ in mod.named_parameters():
+            if p_.grad is not None:
+                arrays.update(compact("grad", k, p_.grad))
+        for k, b in mod.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                arrays.update(compact("buf", k, b))
+        save(f"mod_appearance_encoder_tin{t_in}", dict(module="appearance_encoder", spec=spec, seed=seed, t_in=t_in,
+                                                        batch_size=bsz, cfg=cfg, inputs={"first_frame": fspec}), arrays)
+
+    # ---- one whole training step with the forward-flow branch and every optional loss term switched on
+    capture_e2e("e2e_tin1_spade_fwof", 1, True, 1, True, False, 17, use_fw_of=True,
+                loss_weights={"flow_smooth": 2.0, "flowcon": 1.5, "style": 250.0})
 
 
 TRACKS = os.path.join(OUT, "scene_tracks")
@@ -596,6 +687,9 @@ def main():
         capture_e2e("e2e_tin1_nospade_gt", 1, False, 1, True, False, 7)
         capture_modules_round2()
         return
+    if "--round5-only" in sys.argv:         # likewise (round 5: VERDICT r04 item 6, the never-compared branches)
+        capture_round5()
+        return
     print("ops");      capture_ops(ref_utils)
     print("blocks");   capture_blocks()
     print("e2e")
@@ -612,6 +706,8 @@ def main():
     capture_dataset(ref_utils)
     print("flownet")
     capture_flownet(ref_utils)
+    print("round 5 branches")
+    capture_round5()
 
 
 if __name__ == "__main__":

@@ -70,7 +70,7 @@ def _run_block(name, mod, inputs):
     return {"y": mod(x)}
 
 
-@pytest.mark.parametrize("name", [n[4:] for n in names("blk_") if n != "blk_perceptual"])
+@pytest.mark.parametrize("name", [n[4:] for n in names("blk_") if not n.startswith("blk_perceptual")])
 def test_block_vs_golden(name):
     c = Case("blk_" + name)
     seed = c.meta["seed"]
@@ -106,9 +106,16 @@ def _product_module(c):
     m = c.meta
     if m["module"] == "generator":
         mod = OcclusionAwareGenerator(_copy.deepcopy(m["generator"]), _copy.deepcopy(m["flow_embedder"]), input_channel=3,
-                                      dataset="cityscapes")
+                                      dataset=m.get("dataset", "cityscapes"))      # "kitti": generator.py:37-48,139-145 (round 5)
         call = lambda i: {"y": mod(i["first_frame"], i["flow"], i["occlusion_map"])}
         gin = ("first_frame", "flow", "occlusion_map")
+    elif m["module"] == "appearance_encoder":
+        from c2m_amd.modules.appearance_encoder.appearance_encoder import AppearanceEncoder
+        cfg = normalize_config(_copy.deepcopy(m["cfg"]))
+        mod = AppearanceEncoder(cfg["train_params"], **cfg["model_params"]["appearance_encoder"], **cfg["model_params"]["common_params"])
+        gnn = make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"])["tracking_gnn"].to(DEV)
+        call = lambda i: mod({"first_frame": i["first_frame"], "tracking_gnn": gnn})
+        gin = ("first_frame",)
     else:
         mod = DenseMotionDecoder(_copy.deepcopy(m["decoder"]))
 
@@ -174,13 +181,60 @@ def test_perceptual_vs_golden():
     assert "relu5_2" not in mod.vgg19(i["fake"][:, :, 0].to(DEV)), "VGG must stop at relu5_1 when style is off"
 
 
+def test_perceptual_style_vs_golden():
+    """Round 5: PerceptualLoss with the Gram style branch on (losses.py:32-59) against the live reference's values and d/d fake."""
+    c = Case("blk_perceptual_style")
+    mod = PerceptualLoss(c.meta["train_params"])
+    mod.load_state_dict(synth_state(c.meta["spec"], c.meta["seed"]), strict=True)
+    mod.to(DEV)
+    i = c.group("in")
+    fake = i["fake"].to(DEV).requires_grad_(True)
+    out = mod(i["gt"].to(DEV), fake)
+    ref = c.group("out")
+    assert list(out) == ["perceptual", "style"]
+    total = 0
+    for j, k in enumerate(sorted(out)):
+        close(out[k], ref[k], 2e-4, 1e-7, k)
+        total = total + (out[k] * rnd(c.meta["seed"] + 100 + j).to(DEV)).sum()
+    total.backward()
+    refg = c.group("gin")["fake"].double()
+    err = (fake.grad.cpu().double() - refg).norm() / refg.norm()
+    assert err < 5e-3, f"d fake: relative L2 error {err:.2e}"
+    feats = mod.vgg19(i["fake"][:, :, 0].to(DEV))
+    assert "relu5_2" in feats and "relu5_3" not in feats, "with the style term the VGG pass stops behind relu5_2"
+
+
+def test_flow_losses_vs_golden():
+    """Round 5: SmoothLoss (losses.py:73-112) and FlowConsistLoss (:115-140; two flow_warp launches per call) against the live
+    reference: values and the gradients of both flows and both masks."""
+    from c2m_amd.losses.losses import SmoothLoss, FlowConsistLoss
+    c = Case("op_losses_flow")
+    i = c.group("in")
+    t = {k: i[k].to(DEV).requires_grad_(True) for k in ("flow", "flowback", "mask_fw", "mask_bw")}
+    fc = FlowConsistLoss({"num_predicted_frames": 5})
+    sm = SmoothLoss()(t["flow"], i["image"].to(DEV))
+    cm = fc(t["flow"], t["flowback"], t["mask_fw"], t["mask_bw"])
+    cp = fc(t["flow"], t["flowback"])
+    ref = c.group("out")
+    close(sm, ref["smooth"], 1e-4, 1e-7, "smooth")
+    close(cm, ref["flowcon_masked"], 1e-4, 1e-7, "flowcon masked")
+    close(cp, ref["flowcon"], 1e-4, 1e-7, "flowcon")
+    w = c.meta["weights"]
+    (sm * w[0] + cm * w[1] + cp * w[2]).backward()
+    g = c.group("gin")
+    for k in t:
+        refg = g[k].double()
+        err = (t[k].grad.cpu().double() - refg).norm() / refg.norm()
+        assert err < 1e-3, f"d{k}: relative L2 error {err:.2e}"
+
+
 def _model_and_batch(c, device=DEV):
     m = c.meta
     cfg = normalize_config(m["cfg"])
     model = GeneratorFullModel(train_params=cfg["train_params"], model_params=cfg["model_params"], dataset="cityscapes")
     model.load_state_dict(synth_state(m["spec"], m["seed"]), strict=True)
     model.to(device).train()
-    batch = batch_to(make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"]), device)
+    batch = batch_to(make_batch(m["batch_size"], 128, 256, m["t_in"], seed=m["seed"], use_fw_of=m.get("use_fw_of", False)), device)
     rng = c.group("rng")
     batch["rng"] = dict(latent_traj=rng["latent_traj"].to(device), eps=rng["eps"].to(device),
                         click_index=rng["click_index"].long().to(device))
