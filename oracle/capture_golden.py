@@ -513,6 +513,8 @@ def capture_round5():
         for k, b in mod.named_buffers():
             if not k.endswith("num_batches_tracked"):
                 arrays.update(compact("buf", k, b))
+        arrays["nograd"] = np.frombuffer(json.dumps(
+            [k for k, p_ in mod.named_parameters() if p_.requires_grad and p_.grad is None]).encode(), dtype=np.uint8)
         save(f"mod_appearance_encoder_tin{t_in}", dict(module="appearance_encoder", spec=spec, seed=seed, t_in=t_in,
                                                         batch_size=bsz, cfg=cfg, inputs={"first_frame": fspec}), arrays)
 

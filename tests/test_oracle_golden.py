@@ -227,8 +227,7 @@ def test_standalone_module(name):
     for k in ref_keys:
         check_compact(c.arr, "grad", k, grads[k], 1e-4, f"{name} grad.{k}", floor=1e-6)
     nograd = [k for k, v in S.t.items() if v.requires_grad and v.grad is None]
-    if "nograd" in c.arr:
-        assert sorted(nograd) == sorted(c.json("nograd"))
+    assert sorted(nograd) == sorted(c.json("nograd"))
 
 
 def test_perceptual_style_branch():

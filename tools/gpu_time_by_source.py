@@ -34,7 +34,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
         step(batch)
     torch.cuda.synchronize()
 
-CONV = re.compile(r"conv_patch_nc8|conv_gather_nc8|conv_wgrad_nc8|conv_s2_dgrad_nc8|conv_wino_kernel|conv_wino4_kernel|conv_wino_wgrad_kernel|conv_igemm_kernel|conv_wgrad_kernel|conv_patch3x3|conv_wgrad_wide")
+CONV = re.compile(r"reflect_ring_dgrad|conv_patch_nc8|conv_gather_nc8|conv_wgrad_nc8|conv_s2_dgrad_nc8|conv_wino_kernel|conv_wino4_kernel|conv_wino_wgrad_kernel|conv_igemm_kernel|conv_wgrad_kernel|conv_patch3x3|conv_wgrad_wide")
 by = collections.defaultdict(lambda: [0.0, 0])
 tot_conv = tot_other = 0.0
 n_other = 0
