@@ -64,6 +64,8 @@ _SIGS = {
     "c2m_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_double] * 5 + [c_void_p]),
     "c2m_norm_workspace_floats": (c_long, [c_int, c_int, c_long]),
     "c2m_norm_stats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_float, c_float, c_int, c_void_p]),
+    "c2m_norm_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_long, c_int, c_float, c_float, c_int, c_float, c_int, c_void_p]),
+    "c2m_norm_set_fused": (c_int, [c_int]),
     "c2m_norm_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_norm_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "c2m_act_bwd": (c_int, [c_void_p] * 3 + [c_long, c_int, c_float, c_int, c_void_p]),

@@ -15,6 +15,7 @@
 // Backward: one reduction pass (sum g', sum g'*xhat, and the SPADE gamma/beta map gradients) + one apply pass.
 #include "common.h"
 #include "dtype.h"
+#include <stdlib.h>
 
 #define NORM_CHUNK 8192
 
@@ -346,6 +347,96 @@ C2M_API int c2m_norm_apply(const void* x, const float* mean, const float* invstd
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------- instance norm in ONE launch (round 5)
+// mode 0 (per-plane statistics: InstanceNorm2d / SPADE, same_block.py:19-22, spade_block.py:68-77) with planes of <= 32768
+// elements: one workgroup owns a whole plane, keeps it in registers (<= 32 float4 per thread), computes mean and centred sum
+// of squares exactly like norm_partial_kernel (same two passes, same block sums -- bit-identical statistics for planes of one
+// chunk) and applies scale / shift / activation straight from the registers.  Replaces partial + finalize + apply: one read of
+// x instead of two, one launch instead of three (65 launches and ~0.5 ms of a BASELINE configs[1] step).
+template <class T, int NV>
+__global__ __launch_bounds__(256) void norm_inst_fused_kernel(const ApplyP<T> p, float* __restrict__ mean_out,
+                                                              float* __restrict__ invstd_out, float eps) {
+    __shared__ float sm[4];
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % p.C);
+    const int n = (int)(plane / p.C);
+    const T* __restrict__ x = p.x + plane * p.S;
+    const int S = (int)p.S;
+    float4 keep[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x * 4 + k * 1024;
+        if (i < S) {
+            keep[k] = c2m_ld4(x + i);
+            s += (keep[k].x + keep[k].y) + (keep[k].z + keep[k].w);
+        }
+    }
+    s = block_sum_256(s, sm);
+    const float mean = s / (float)S;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x * 4 + k * 1024;
+        if (i < S) {
+            const float a = keep[k].x - mean, b = keep[k].y - mean, cc = keep[k].z - mean, d = keep[k].w - mean;
+            m2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    m2 = block_sum_256(m2, sm);
+    const double var = (double)m2 / (double)S;                       // norm_finalize_kernel with one chunk
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { mean_out[plane] = mean; invstd_out[plane] = invstd; }
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    T* __restrict__ y = p.y + plane * p.S;
+    const T* __restrict__ g0 = p.gb ? p.gb + ((long)n * 2 * p.C + c) * p.S : nullptr;
+    const T* __restrict__ g1 = p.gb ? g0 + (long)p.C * p.S : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x * 4 + k * 1024;
+        if (i < S) {
+            const float4 v = keep[k];
+            float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
+            if (p.gb) {
+                const float4 a = c2m_ld4(g0 + i);
+                sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+                sh = c2m_ld4(g1 + i);
+            }
+            float4 o;
+            o.x = c2m_act((v.x - mean) * invstd * sc.x + sh.x, p.act, p.slope);
+            o.y = c2m_act((v.y - mean) * invstd * sc.y + sh.y, p.act, p.slope);
+            o.z = c2m_act((v.z - mean) * invstd * sc.z + sh.z, p.act, p.slope);
+            o.w = c2m_act((v.w - mean) * invstd * sc.w + sh.w, p.act, p.slope);
+            c2m_st4(y + i, o);
+        }
+    }
+}
+
+static int norm_fused_on = [] { const char* e = getenv("C2M_NORM_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();      // A/B knob
+// tests / A/B runs: 0 = every norm on the three-launch path, 1 = the one-launch instance-norm kernels where eligible; returns the old value
+C2M_API int c2m_norm_set_fused(int on) { const int old = norm_fused_on; norm_fused_on = on ? 1 : 0; return old; }
+
+// Statistics + apply in one call (c2m_norm_stats followed by c2m_norm_apply, without the NC8 side output): instance-norm planes of
+// 1024 ... 32768 elements take the one-launch kernel above, everything else the three launches.
+C2M_API int c2m_norm_fwd(const void* x, float* mean, float* invstd, float* running_mean, float* running_var, float* workspace,
+                         const float* gamma, const float* beta, const void* gb, void* y, int N, int C, long S, int mode,
+                         float eps, float momentum, int act, float slope, int dt, void* stream) {
+    C2M_ENTER();
+    if ((long)N * C * S <= 0) return 0;
+    if (norm_fused_on && mode == 0 && S <= 32768 && norm_vec_ok(S, x, y, gb, nullptr, dt)) {
+        C2M_DISPATCH_DT(dt,
+            ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, (const T*)gb, (T*)y, N, C, S, mode, act, slope};
+            if (S <= 8192)
+                hipLaunchKernelGGL((norm_inst_fused_kernel<T, 8>), dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, eps);
+            else
+                hipLaunchKernelGGL((norm_inst_fused_kernel<T, 32>), dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, eps););
+        return (int)hipGetLastError();
+    }
+    const int rc = c2m_norm_stats(x, mean, invstd, running_mean, running_var, workspace, N, C, S, mode, eps, momentum, dt, stream);
+    if (rc) return rc;
+    return c2m_norm_apply(x, mean, invstd, gamma, beta, gb, y, nullptr, N, C, S, mode, act, slope, dt, stream);
+}
+
 // ------------------------------------------------------------------------------------------- backward
 template <class T>
 struct BwdP {
@@ -621,6 +712,71 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_nc8_kernel(const BwdP<bf16
     }
 }
 
+// Instance-norm backward in ONE launch (round 5): mode 0, no affine-parameter gradient (SPADE / plain instance norm), planes of
+// <= 8192 elements.  The workgroup keeps x, gy and the SPADE scale / shift of its plane in registers between the reduction
+// (norm_bwd_reduce_kernel's arithmetic and summation order, one chunk) and the apply pass (norm_bwd_apply_vec_kernel's):
+// reduce + finalize + apply = three launches and two reads of three tensors become one launch and one read.
+template <class T>
+__global__ __launch_bounds__(256) void norm_inst_bwd_fused_kernel(const BwdP<T> p) {
+    constexpr int NV = NORM_CHUNK / 1024;
+    __shared__ float sm[4];
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % p.C);
+    const int n = (int)(plane / p.C);
+    const int S = (int)p.S;
+    const float mean = p.mean[plane], invstd = p.invstd[plane];
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    const T* __restrict__ xp = p.x + plane * p.S;
+    const T* __restrict__ gp = p.gy + plane * p.S;
+    T* __restrict__ dp = p.dx + plane * p.S;
+    const long gplane = ((long)n * 2 * p.C + c) * p.S, goff = (long)p.C * p.S;
+    float xh[NV][4], gsc[NV][4], scv[NV][4];          // xhat, g' * scale (the dx term), scale
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int s = threadIdx.x * 4 + k * 1024;
+        if (s < S) {
+            const float4 xv = c2m_ld4(xp + s);
+            const float4 gv = c2m_ld4(gp + s);
+            float4 sc = make_float4(ga, ga, ga, ga), sh = make_float4(be, be, be, be);
+            if (p.gb) {
+                const float4 a = c2m_ld4(p.gb + gplane + s);
+                sc = make_float4(1.0f + a.x, 1.0f + a.y, 1.0f + a.z, 1.0f + a.w);
+                sh = c2m_ld4(p.gb + gplane + goff + s);
+            }
+            const float xq[4] = {(xv.x - mean) * invstd, (xv.y - mean) * invstd, (xv.z - mean) * invstd, (xv.w - mean) * invstd};
+            const float sq[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, gyv[4] = {gv.x, gv.y, gv.z, gv.w};
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[e] = gyv[e] * act_grad(xq[e] * sq[e] + shv[e], p.act, p.slope);
+                if (p.gb) { s1 += g[e] * sq[e]; s2 += g[e] * sq[e] * xq[e]; }
+                else { s1 += g[e]; s2 += g[e] * xq[e]; }
+                xh[k][e] = xq[e]; gsc[k][e] = g[e] * sq[e]; scv[k][e] = sq[e];
+            }
+            if (p.gb) {
+                c2m_st4(p.ggb + gplane + s, make_float4(g[0] * xq[0], g[1] * xq[1], g[2] * xq[2], g[3] * xq[3]));
+                c2m_st4(p.ggb + gplane + goff + s, make_float4(g[0], g[1], g[2], g[3]));
+            }
+        }
+    }
+    (void)scv;
+    s1 = block_sum_256(s1, sm);
+    s2 = block_sum_256(s2, sm);
+    const float c1 = (float)((double)ga * (double)s1 / (double)p.S), c2 = (float)((double)ga * (double)s2 / (double)p.S);
+    if (threadIdx.x == 0) { p.coef[plane * 2 + 0] = c1; p.coef[plane * 2 + 1] = c2; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int s = threadIdx.x * 4 + k * 1024;
+        if (s < S) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = invstd * (gsc[k][e] - c1 - xh[k][e] * c2);
+            c2m_st4(dp + s, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
 // workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
 // dx_nc8 (optional, bf16 tensors with S % 8 == 0 only): dx in the channel-blocked layout as well (see c2m_norm_apply).
 C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
@@ -640,6 +796,11 @@ C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const
         p.coef = workspace + (long)N * C * p.chunks * 2;
         p.dgamma = dgamma; p.dbeta = dbeta; p.dx = (T*)dx;
         p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
+        if (norm_fused_on && mode == 0 && !dgamma && !dx_nc8 && dx && vec && p.chunks == 1 &&
+            (!gb || ((((uintptr_t)gb) | ((uintptr_t)ggb)) & C2mVec4<T>::mask) == 0)) {
+            hipLaunchKernelGGL(norm_inst_bwd_fused_kernel<T>, dim3((unsigned)((long)N * C)), dim3(256), 0, s, p);
+            return (int)hipGetLastError();
+        }
         hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);
         const int nthreads = mode == 0 ? N * C : C;
         if (N * p.chunks >= 16 && (mode == 1 || dgamma))

@@ -1852,8 +1852,6 @@ class _NormActFn(torch.autograd.Function):
         mean = torch.empty(nstat, device=x.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         ws = torch.empty(L.c2m_norm_workspace_floats(N, C, S), device=x.device, dtype=torch.float32)
-        _lib.check(L.c2m_norm_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), N, C, S, mode,
-                                    eps, momentum, dt, _stream()), "norm_stats")
         y = torch.empty_like(x)
         # bf16 data path: activations of conv-sized maps are ALSO written in the NC8 layout of the convolution they feed (and, in
         # backward, the gradient they hand to the convolution in front): conv_nc8.hip then needs no layout pass of its own
@@ -1863,8 +1861,15 @@ class _NormActFn(torch.autograd.Function):
         if feeds is not None and dt == 1 and S % 8 == 0:
             only = _consumer_reads_only_nc8(x, feeds)
         yn = torch.empty((N, _cdiv(C, 8)) + tuple(x.shape[2:]) + (8,), device=x.device, dtype=BF16) if (ctx.nc8 or only) else None
-        _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), None if only else _p(y), _p(yn), N, C, S,
-                                    mode, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
+        if yn is None:
+            # statistics + apply in one call: instance-norm planes of <= 32768 elements run as ONE launch (norm_inst_fused_kernel)
+            _lib.check(L.c2m_norm_fwd(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), _p(gamma), _p(beta), _p(gb),
+                                      _p(y), N, C, S, mode, eps, momentum, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_fwd")
+        else:
+            _lib.check(L.c2m_norm_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), N, C, S, mode,
+                                        eps, momentum, dt, _stream()), "norm_stats")
+            _lib.check(L.c2m_norm_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gb), None if only else _p(y), _p(yn), N, C, S,
+                                        mode, ACT[act], LRELU_SLOPE, dt, _stream()), "norm_apply")
         if only and _NC8_POISON:
             y.fill_(float("nan"))
         _NormActFn.last_only = only             # read by _norm_act right behind apply(): tags y as NC8-only

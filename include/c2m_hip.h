@@ -230,6 +230,14 @@ int c2m_reflect_fold(const void* dXpad, void* dX, long NC, int T, int H, int W, 
 long c2m_norm_workspace_floats(int N, int C, long S);
 int c2m_norm_stats(const void* x, float* mean, float* invstd, float* running_mean, float* running_var,
                    float* workspace, int N, int C, long S, int mode, float eps, float momentum, int dt, void* stream);
+/* c2m_norm_stats followed by c2m_norm_apply (without the NC8 side output) as ONE call: instance-norm planes (mode 0) of 1024 ...
+ * 32768 elements run as one launch that keeps the plane in registers between the statistics and the apply pass (same arithmetic and
+ * summation order as the three-launch path; bit-identical for planes of <= 8192 elements); everything else runs the three launches.
+ * c2m_norm_bwd makes the same choice by itself for mode 0 without affine-parameter gradients and planes of <= 8192 elements.      */
+int c2m_norm_set_fused(int on);       /* tests / A/B: 0 = always the three-launch path; returns the previous setting */
+int c2m_norm_fwd(const void* x, float* mean, float* invstd, float* running_mean, float* running_var, float* workspace,
+                 const float* gamma, const float* beta, const void* gb, void* y, int N, int C, long S, int mode, float eps,
+                 float momentum, int act, float slope, int dt, void* stream);
 /* y_nc8 / dx_nc8 (optional; bf16 tensors with S % 8 == 0): the result ALSO in the channel-blocked layout [N][ceil(C/8)][S][8] the
  * NC8 convolutions consume (c2m_nchw_to_nc8's), written by the same pass -- the activation feeds a convolution, the gradient is the
  * dY of the convolution in front.                                                                                              */

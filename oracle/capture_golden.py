@@ -477,7 +477,7 @@ def capture_round5():
         gp = dict(block_expansion=4, num_down_blocks=3, max_expansion=32, num_bottleneck_blocks=2, padding_mode="reflect",
                   use_skip=False, use_spade=use_spade)
         mod = OcclusionAwareGenerator(copy.deepcopy(gp), copy.deepcopy(fp), input_channel=3, dataset="kitti")
-        seed = 2110 + int(use_spade)
+        seed = 2120 + int(use_spade)      # (2111: one LeakyReLU pre-activation of image 1 within rounding of 0 -- the product and the reference take different slopes there, 585 input-gradient elements move by 1-2 %)
         spec, arrays = run_module_compact(mod, seed, gin, lambda m, **kw: m(kw["first_frame"], kw["flow"], kw["occlusion_map"]),
                                           ("first_frame", "flow", "occlusion_map"))
         save("mod_generator_kitti_" + ("spade" if use_spade else "nospade"),

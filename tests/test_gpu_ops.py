@@ -487,6 +487,56 @@ def test_spade_norm_act():
     close(gbg.grad, gbr.grad, 1e-4, 1e-5, "spade d(gamma,beta)")
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 32, 64), (2, 6, 64, 128), (2, 3, 128, 256), (2, 4, 36, 40), (5, 2, 16, 64)])
+@pytest.mark.parametrize("kind", ["plain", "affine", "spade"])
+def test_instance_norm_one_launch_kernels(shape, kind):
+    """Round 5: instance-norm planes of 1024 ... 32768 elements run statistics + apply as ONE launch (norm_inst_fused_kernel) and,
+    without affine-parameter gradients and up to 8192 elements, the backward as one launch too (norm_inst_bwd_fused_kernel).
+    Against torch on the CPU, and against the three-launch path of the same library (c2m_norm_set_fused(0)): bit-identical for
+    planes of one 8192-element chunk (same arithmetic, same summation order), within rounding above."""
+    from c2m_amd import _lib
+    N, C, H, W = shape
+    x = rnd(11, *shape) * 1.7 + 0.8
+    gam, bet = (1 + 0.1 * rnd(12, C), 0.1 * rnd(13, C)) if kind == "affine" else (None, None)
+    gb = 0.3 * rnd(14, N, 2 * C, H, W) if kind == "spade" else None
+    go = rnd(15, *shape)
+    xr = x.clone().requires_grad_(True)
+    gr, br = (gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)) if kind == "affine" else (None, None)
+    gbr = gb.clone().requires_grad_(True) if gb is not None else None
+    yn = F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if gbr is not None:
+        ga_, be_ = gbr.chunk(2, 1)
+        yn = yn * (1 + ga_) + be_
+    yr = F.leaky_relu(yn, 0.2)
+    (yr * go).sum().backward()
+
+    def run():
+        xg = g(x).requires_grad_(True)
+        gg, bg = (g(gam).requires_grad_(True), g(bet).requires_grad_(True)) if kind == "affine" else (None, None)
+        gbg = g(gb).requires_grad_(True) if gb is not None else None
+        y = ops.spade_norm_act(xg, gbg, "lrelu") if kind == "spade" else ops.instance_norm_act(xg, gg, bg, "lrelu")
+        (y * g(go)).sum().backward()
+        return [y.detach(), xg.grad] + ([gg.grad, bg.grad] if kind == "affine" else []) + ([gbg.grad] if gbg is not None else [])
+    fused = run()
+    old = _lib.lib().c2m_norm_set_fused(0)
+    try:
+        three = run()
+    finally:
+        _lib.lib().c2m_norm_set_fused(old)
+    close(fused[0], yr, 1e-4, 1e-5, "one-launch instance norm fwd")
+    close(fused[1], xr.grad, 1e-3, 1e-5, "one-launch instance norm dx")
+    if kind == "affine":
+        close(fused[2], gr.grad, 1e-4, 1e-4)
+        close(fused[3], br.grad, 1e-4, 1e-4)
+    if kind == "spade":
+        close(fused[2], gbr.grad, 1e-4, 1e-5, "spade d(gamma, beta)")
+    for a, b in zip(fused, three):
+        if H * W <= 8192:
+            assert torch.equal(a, b), "one chunk per plane: the one-launch kernels must reproduce the three-launch path bit for bit"
+        else:
+            close(a, b.cpu(), 1e-4, 1e-5, "one-launch vs three-launch path")
+
+
 # ----------------------------------------------------------------------------------------------- warping / resampling
 @pytest.mark.parametrize("name", names("op_resample"))
 def test_flow_warp_golden(name):
