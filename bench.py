@@ -326,6 +326,9 @@ def main():
     ap.add_argument("--no-graph-side", dest="graph_side", action="store_false")
     ap.add_argument("--fp32-allreduce", action="store_true",
                     help="keep fp32 gradient buckets on the wire in the bf16 configurations (default there: bf16 copies)")
+    ap.add_argument("--measure-comm", action="store_true",
+                    help="also record one HIP event per gradient bucket and step (allreduce_exposed_ms_per_bucket); off by default: "
+                         "the timed region then carries only the two events of allreduce_exposed_ms_per_step")
     ap.add_argument("--force-reducer", action="store_true",
                     help="run the bucketed RCCL all-reduce path even with one rank (plumbing check on a single GPU)")
     ap.add_argument("--side-configs", default=None,
@@ -367,7 +370,8 @@ def main():
     # bf16 configurations all-reduce bf16 copies of the fp32 gradient buckets (212 MB instead of 424 MB)
     comm_dtype = torch.bfloat16 if (args.dtype == "bf16" and not args.fp32_allreduce) else torch.float32
     step = TrainStep(model, run_optimizers=args.full_step, distributed=distributed,
-                     force_collectives=args.force_reducer, measure_comm=True, comm_dtype=comm_dtype)
+                     force_collectives=args.force_reducer, measure_comm=True, comm_dtype=comm_dtype,
+                     measure_comm_buckets=args.measure_comm)
     clips = args.batch * args.windows
     batch = batch_to(make_stream_batch(args.batch, args.windows, args.height, args.width, 2, seed=rank), dev)
     rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=rank)

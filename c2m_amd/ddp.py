@@ -45,7 +45,7 @@ class _Bucket:
 
 class GradientReducer:
     def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False, buffers=(),
-                 measure=False, comm_dtype=torch.float32):
+                 measure=False, comm_dtype=torch.float32, measure_buckets=False):
         """params: ALL parameters of the model.  The trainable ones are bucketed; every parameter -- frozen ones (the
         VGG-19 of the perceptual loss, a flow net) included -- and every tensor of `buffers` (BatchNorm running
         statistics, spectral-norm u/v) is broadcast from rank 0 at construction, which is what DistributedDataParallel's
@@ -100,6 +100,9 @@ class GradientReducer:
         self.next_slot = 0            # position in self.order of the next bucket to launch
         self.use_avg = self.on_gpu and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         self.measure = measure and self.on_gpu
+        # per-bucket exposure (one stream-side wait + one event record per bucket and step): only on request -- the aggregate figure
+        # above costs two event records per step (keep the bookkeeping out of the timed region by default)
+        self.measure_buckets = bool(measure_buckets) and self.measure
         self._exposed = []            # (event at end of backward compute, event after the side stream was joined)
         self._exposed_buckets = []    # (event at arm(), event at end of backward, [(bucket, event: its reduced gradients final)])
         self._launched_now, self._base_ev = [], None
@@ -206,7 +209,7 @@ class GradientReducer:
                     b.work.wait()
                     b.work = None
                     self._expand(b)
-                if self.measure:                 # when this bucket's reduced gradients are final (per-bucket exposure)
+                if self.measure_buckets:         # when this bucket's reduced gradients are final (per-bucket exposure)
                     if b.work is not None:
                         b.work.wait()            # (stream-side wait only: orders the event behind the collective)
                         b.work = None

@@ -65,7 +65,7 @@ def compute_flow(flownet, train_batch, train_params):
 
 class TrainStep:
     def __init__(self, c2m, loss_weights=None, run_optimizers=True, distributed=None, bucket_mb=25.0,
-                 force_collectives=False, measure_comm=False, comm_dtype=torch.float32):
+                 force_collectives=False, measure_comm=False, comm_dtype=torch.float32, measure_comm_buckets=False):
         self.c2m = c2m
         self.tp = c2m.train_params
         self.loss_weights = loss_weights or self.tp["loss_weights"]
@@ -77,7 +77,7 @@ class TrainStep:
             self.optimizers.append(c2m.d_optimizer_video)
         distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb, buffers=list(c2m.buffers()),
-                                       force_collectives=force_collectives, measure=measure_comm,
+                                       force_collectives=force_collectives, measure=measure_comm, measure_buckets=measure_comm_buckets,
                                        comm_dtype=comm_dtype) if distributed else None
         self._deferred_nan = []       # NaN checks recorded while capturing (utils.isnan), evaluated after every replay
 

@@ -49,7 +49,7 @@ def test_bench_under_torchrun_with_rccl_reducer():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch",
-           "1", "--no-cpu-baseline", "--no-roofline", "--force-reducer"]
+           "1", "--no-cpu-baseline", "--no-roofline", "--force-reducer", "--measure-comm"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     r = _json_line(out.stdout)
@@ -137,3 +137,19 @@ def test_bench_graph_replay_with_the_reducer():
     r = _json_line(out.stdout)
     assert r["hip_graph"] is True and r["rccl_ranks"] == 1 and r["value"] > 0 and r["allreduce_buckets"] >= 10
     assert r["allreduce_op"] == "avg"
+
+
+def test_bench_side_configs_object():
+    """Round 5: the default one-GPU line carries `side_configs` -- the bf16 BASELINE configurations as HIP-graph replays measured in
+    the same process after (and outside) the headline timed region.  Here: configs[3] only, two replays, on a short headline run."""
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline",
+                          "--no-roofline", "--side-configs", "3", "--side-steps", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    sc = r["side_configs"]["configs[3]"]
+    assert "error" not in sc, sc
+    assert sc["steps"] == 2 and sc["ms_per_step"] > 0 and sc["unit"] == "frames/s" and "BASELINE configs[3]" in sc["workload"]
+    assert abs(sc["value"] - 8 * 7 * 1000.0 / sc["ms_per_step"]) < 0.02 * sc["value"]
+    assert 0 < sc["conv_frac_of_peak"] < 1 and sc["peak_tflops"] == 2500.0 and sc["conv_launches_per_step"] > 100
+    assert r["config"]["workload"].startswith("BASELINE configs[1]") and r["dtype"] == "f32"      # the headline is untouched
