@@ -12,6 +12,9 @@ _lib = None
 c_void_p, c_int, c_long, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
 _SIGS = {
+    "c2m_abi_version": (c_int, []),
+    "c2m_geom_len": (c_int, []),
+    "c2m_wino_geom_len": (c_int, []),
     "c2m_conv_igemm": (c_int, [c_void_p] * 7 + [c_int, c_float, c_void_p]),
     "c2m_nchw_to_nc8": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_void_p]),
     "c2m_conv_patch_nc8": (c_int, [c_void_p] * 6 + [c_int, c_float, c_void_p]),
@@ -98,6 +101,32 @@ _SIGS = {
 }
 
 
+GEOM_HEADER = os.path.join(os.path.dirname(_HERE), "include", "c2m_geom.h")
+
+
+class _Index(dict):
+    """Enum of include/c2m_geom.h as attributes: G.M, G.PATCH_TY, ... (unknown names raise -- a typo is not index 0)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(f"c2m_geom.h defines no geom entry {k!r}") from None
+
+
+def _parse_geom_header():
+    with open(GEOM_HEADER) as f:
+        text = f.read()
+    version = int(re.search(r"#define\s+C2M_ABI_VERSION\s+(\d+)", text).group(1))
+    conv = _Index((m.group(1), int(m.group(2))) for m in re.finditer(r"\bC2M_G_([A-Z0-9_]+)\s*=\s*(\d+)", text))
+    wino = _Index((m.group(1), int(m.group(2))) for m in re.finditer(r"\bC2M_WG_([A-Z0-9_]+)\s*=\s*(\d+)", text))
+    for tab in (conv, wino):          # every index once
+        assert len(set(tab.values())) == len(tab), "c2m_geom.h: two names share an index"
+    return version, conv, wino
+
+
+ABI_VERSION, GEOM, WINO_GEOM = _parse_geom_header()
+
+
 def declared_symbols():
     """Every function name declared in include/c2m_hip.h."""
     with open(HEADER) as f:
@@ -121,6 +150,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if (L.c2m_abi_version(), L.c2m_geom_len(), L.c2m_wino_geom_len()) != (ABI_VERSION, GEOM.LEN, WINO_GEOM.LEN):
+            raise RuntimeError(f"c2m_amd: {LIB_PATH} was built from another include/c2m_geom.h (library ABI "
+                               f"{L.c2m_abi_version()}, geom {L.c2m_geom_len()} / {L.c2m_wino_geom_len()} entries; header ABI "
+                               f"{ABI_VERSION}, {GEOM.LEN} / {WINO_GEOM.LEN}): rebuild with `python -m c2m_amd.build --force`")
         _lib = L
     return _lib
 

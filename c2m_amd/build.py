@@ -35,7 +35,8 @@ def build(force=False, verbose=False, variant=None, defines=()):
     the environment variable C2M_AMD_LIB; the default build takes neither."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    common = [os.path.join(CSRC, h) for h in ("common.h", "dtype.h", "conv_store.h")]
+    common = [os.path.join(CSRC, h) for h in ("common.h", "dtype.h", "conv_store.h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "c2m_geom.h")]
     suffix = f"_{variant}" if variant else ""
     lib = LIB.replace(".so", suffix + ".so")
     objs = []

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/c2m_geom.h"      // names of the geom[] entries (one definition for the library and the ctypes host)
 
 #define C2M_API extern "C" __attribute__((visibility("default")))
 

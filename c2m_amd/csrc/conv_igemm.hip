@@ -1322,47 +1322,47 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
     ConvP p;
     p.A = A; p.X = (const float*)X; p.Y = (float*)Y; p.bias = bias; p.ktab = reinterpret_cast<const int4*>(ktab);
     p.Y2 = (float*)Y_interior;
-    p.ps_t = (int)g[36]; p.ps_y = (int)g[37]; p.ps_x = (int)g[38]; p.po_t = (int)g[39]; p.po_y = (int)g[40];
-    p.po_x = (int)g[41]; p.lo_t = (int)g[42]; p.lo_y = (int)g[43]; p.lo_x = (int)g[44]; p.ext_t = (int)g[45];
-    p.ext_y = (int)g[46]; p.ext_x = (int)g[47]; p.y2_sn = g[48]; p.y2_sc = g[49]; p.y2_st = g[50]; p.y2_sh = g[51];
-    p.M = (int)g[0]; p.nk = (int)g[1]; p.lda = (int)g[2];
-    p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
-    p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
-    p.st = (int)g[10]; p.sh = (int)g[11]; p.sw = (int)g[12];
-    p.in_sn = g[13]; p.in_st = g[14]; p.in_sh = g[15];
-    p.out_sn = g[16]; p.out_sc = g[17]; p.out_st = g[18]; p.out_sh = g[19]; p.out_sw = g[20]; p.out_off = g[21];
-    p.reflect = (int)g[22]; p.is3d = (int)g[23];
-    const int ns = (int)g[24];
-    p.in_sc = (int)g[25];
-    const int splits = (int)g[26];           // 1, or the value returned by c2m_conv_igemm_splits
-    p.slab_stride = g[27];
-    if (g[32] <= 0 || g[32] >= 0x80000000LL) return (int)hipErrorInvalidValue;   // X must be < 2 GiB
-    p.x_bytes = (unsigned)g[32];
+    p.ps_t = (int)g[C2M_G_PS_T]; p.ps_y = (int)g[C2M_G_PS_Y]; p.ps_x = (int)g[C2M_G_PS_X]; p.po_t = (int)g[C2M_G_PO_T]; p.po_y = (int)g[C2M_G_PO_Y];
+    p.po_x = (int)g[C2M_G_PO_X]; p.lo_t = (int)g[C2M_G_LO_T]; p.lo_y = (int)g[C2M_G_LO_Y]; p.lo_x = (int)g[C2M_G_LO_X]; p.ext_t = (int)g[C2M_G_EXT_T];
+    p.ext_y = (int)g[C2M_G_EXT_Y]; p.ext_x = (int)g[C2M_G_EXT_X]; p.y2_sn = g[C2M_G_Y2_SN]; p.y2_sc = g[C2M_G_Y2_SC]; p.y2_st = g[C2M_G_Y2_ST]; p.y2_sh = g[C2M_G_Y2_SH];
+    p.M = (int)g[C2M_G_M]; p.nk = (int)g[C2M_G_NK]; p.lda = (int)g[C2M_G_LDA];
+    p.Npix = (int)g[C2M_G_NPIX]; p.To = (int)g[C2M_G_TO]; p.Ho = (int)g[C2M_G_HO]; p.Wo = (int)g[C2M_G_WO];
+    p.Ti = (int)g[C2M_G_TI]; p.Hi = (int)g[C2M_G_HI]; p.Wi = (int)g[C2M_G_WI];
+    p.st = (int)g[C2M_G_ST]; p.sh = (int)g[C2M_G_SH]; p.sw = (int)g[C2M_G_SW];
+    p.in_sn = g[C2M_G_IN_SN]; p.in_st = g[C2M_G_IN_ST]; p.in_sh = g[C2M_G_IN_SH];
+    p.out_sn = g[C2M_G_OUT_SN]; p.out_sc = g[C2M_G_OUT_SC]; p.out_st = g[C2M_G_OUT_ST]; p.out_sh = g[C2M_G_OUT_SH]; p.out_sw = g[C2M_G_OUT_SW]; p.out_off = g[C2M_G_OUT_OFF];
+    p.reflect = (int)g[C2M_G_REFLECT]; p.is3d = (int)g[C2M_G_IS3D];
+    const int ns = (int)g[C2M_G_NS];
+    p.in_sc = (int)g[C2M_G_IN_SC];
+    const int splits = (int)g[C2M_G_SPLITS];           // 1, or the value returned by c2m_conv_igemm_splits
+    p.slab_stride = g[C2M_G_SLAB_STRIDE];
+    if (g[C2M_G_X_BYTES] <= 0 || g[C2M_G_X_BYTES] >= 0x80000000LL) return (int)hipErrorInvalidValue;   // X must be < 2 GiB
+    p.x_bytes = (unsigned)g[C2M_G_X_BYTES];
     p.act = act; p.slope = slope;
-    p.xh = (int)g[90]; p.yh = (int)g[91];       // element types of X and of Y / Y_interior: 0 fp32, 1 bf16 (dtype.h)
+    p.xh = (int)g[C2M_G_X_TYPE]; p.yh = (int)g[C2M_G_Y_TYPE];       // element types of X and of Y / Y_interior: 0 fp32, 1 bf16 (dtype.h)
     if ((p.xh | p.yh) & ~1) return (int)hipErrorInvalidValue;
     if (p.M <= 0 || p.Npix <= 0) return 0;
     if (p.nk <= 0 || (p.lda & 3) || (((uintptr_t)A) & 15) || splits < 1) return (int)hipErrorInvalidValue;
     if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;   // the two-target epilogue is a direct-store feature
     p.ksteps_per_split = c2m_cdiv(p.nk, splits);
-    if (!g[52] && c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // empty split
+    if (!g[C2M_G_PATCH] && c2m_cdiv(p.nk, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;   // empty split
     p.splits = splits;
-    p.ncls = g[61] > 1 ? (int)g[61] : 1;
+    p.ncls = g[C2M_G_NCLS] > 1 ? (int)g[C2M_G_NCLS] : 1;
     if (p.ncls > 8) return (int)hipErrorInvalidValue;
-    p.a_cls = g[62]; p.ktab_cls = (int)g[63];
+    p.a_cls = g[C2M_G_A_CLS]; p.ktab_cls = (int)g[C2M_G_KTAB_CLS];
     p.out_off_c[0] = p.out_off; p.po_c[0][0] = p.po_t; p.po_c[0][1] = p.po_y; p.po_c[0][2] = p.po_x;
     for (int c = 0; c < p.ncls && p.ncls > 1; ++c) {
-        p.out_off_c[c] = g[64 + c];
-        for (int d = 0; d < 3; ++d) p.po_c[c][d] = (int)g[96 + 3 * c + d];     // 96 .. 119 (geom[90..92] are the type / form flags)
+        p.out_off_c[c] = g[C2M_G_CLS_OUT_OFF + c];
+        for (int d = 0; d < 3; ++d) p.po_c[c][d] = (int)g[C2M_G_CLS_PO + 3 * c + d];     // 96 .. 119 (geom[90..92] are the type / form flags)
     }
-    if (p.ncls > 1 && (g[52] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
+    if (p.ncls > 1 && (g[C2M_G_PATCH] || (p.a_cls & 3))) return (int)hipErrorInvalidValue;   // gather kernel only
     hipStream_t s = (hipStream_t)stream;
-    if (g[94] == 1) {
+    if (g[C2M_G_G8] == 1) {
         // NC8 gather form (conv_gather_nc8_kernel): X = NC8 of the gathered bf16 tensor ([N][ceil(C/8)][Ti*Hi*Wi][8], geom[32] its bytes),
         // A = c2m_pack_weights_bf16_gather image(s) of this launch's first class, ktab = [ncls][taps] {dt, dy, dx, 1}, nk = taps *
         // ceil(C/16) K-steps in (tap, chunk) order; C = geom[28], taps = geom[29]; geom[95] = tile variant (0 = rule)
-        const int C = (int)g[28], taps = (int)g[29];
-        if (g[34] != 1 || !p.xh || g[52] || C <= 0 || taps <= 0 || taps > 64 || (((uintptr_t)A | (uintptr_t)X) & 15))
+        const int C = (int)g[C2M_G_CIN], taps = (int)g[C2M_G_TAPS];
+        if (g[C2M_G_PRECISION] != 1 || !p.xh || g[C2M_G_PATCH] || C <= 0 || taps <= 0 || taps > 64 || (((uintptr_t)A | (uintptr_t)X) & 15))
             return (int)hipErrorInvalidValue;
         p.g8_nch = c2m_cdiv(C, 16); p.g8_ntaps = taps; p.g8_CB = c2m_cdiv(C, 8); p.g8_Mpad = c2m_cdiv(p.M, 128) * 128;
         if (p.nk != taps * p.g8_nch || p.in_st != (long)p.Hi * p.Wi || p.in_sh != p.Wi) return (int)hipErrorInvalidValue;
@@ -1371,8 +1371,8 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
             return (int)hipErrorInvalidValue;
         p.g8_plane_bytes = (unsigned)plane; p.g8_a_bytes = (unsigned)ab;
         const unsigned ptiles = (unsigned)c2m_cdiv(p.Npix, 256);
-        int v = (int)g[95] & 255;
-        p.g8_dbg = (int)(g[95] >> 8);
+        int v = (int)g[C2M_G_G8_VARIANT] & 255;
+        p.g8_dbg = (int)(g[C2M_G_G8_VARIANT] >> 8);
         // (kernel trace of tools/ab_g8.py on one box, all variants per shape: 64-row tiles 2 stages x 3 workgroups per CU >= 3 stages x 2
         // everywhere (45-row (4,4,4) data gradient 160 vs 209 us); 128-row tiles: variants 3 / 6 within 3 %; <= 32 rows: 4 K-steps per stage)
         if (v == 0) v = p.M <= 32 ? 1 : ((p.M <= 64 || (p.M % 128 >= 1 && p.M % 128 <= 64)) ? 5 : 3);
@@ -1392,16 +1392,16 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
 #undef G8_LAUNCH
         return (int)hipGetLastError();
     }
-    if (g[52]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
+    if (g[C2M_G_PATCH]) {                                           // LDS-patch path (3x3 stride 1, chosen by the host plan)
         if (ns != 1 || p.st != 1 || p.sh != 1 || p.sw != 1) return (int)hipErrorInvalidValue;
-        p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
-        for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
+        p.iy0 = (int)g[C2M_G_PATCH_IY0]; p.ix0 = (int)g[C2M_G_PATCH_IX0];
+        for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[C2M_G_PATCH_TY + i]; p.ptx[i] = (int)g[C2M_G_PATCH_TX + i]; }
         p.nchunks = p.nk / 9;
-        p.cin = (int)g[28];
+        p.cin = (int)g[C2M_G_CIN];
         if (p.nchunks * 9 != p.nk || p.cin <= 0 || p.cin > p.nchunks * 16) return (int)hipErrorInvalidValue;
         p.ksteps_per_split = c2m_cdiv(p.nchunks, splits);           // chunks per split
         if (c2m_cdiv(p.nchunks, p.ksteps_per_split) != splits) return (int)hipErrorInvalidValue;
-        if (g[34] == 1) {
+        if (g[C2M_G_PRECISION] == 1) {
             // bf16: A = c2m_pack_weights_bf16_patch output, lda = its padded row count (a multiple of 128); X is bf16
             if (p.lda % 128 != 0 || p.lda < p.M || !p.xh) return (int)hipErrorInvalidValue;
             if (p.M <= 32)      return launch_patch_bf16<32>(p, splits, s);
@@ -1418,18 +1418,18 @@ C2M_API int c2m_conv_igemm(const float* A, const void* X, void* Y, void* Y_inter
     }
     if (p.M <= 4 && splits == 1 && p.Npix >= 16384 && !p.Y2 && p.ncls == 1) {      // thin output: vector-ALU kernel
         if (p.xh || p.yh) return (int)hipErrorInvalidValue;        // fp32 in, fp32 out (the host casts bf16 activations)
-        // g[35] = +-KW: 2-D stride-1 square KW x KW tap set in row-major order (dx ascending / descending)
-        const int kw = (int)(g[35] < 0 ? -g[35] : g[35]);
+        // g[C2M_G_SQUARE_KW] = +-KW: 2-D stride-1 square KW x KW tap set in row-major order (dx ascending / descending)
+        const int kw = (int)(g[C2M_G_SQUARE_KW] < 0 ? -g[C2M_G_SQUARE_KW] : g[C2M_G_SQUARE_KW]);
         if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
-            g[29] == kw * kw && g[28] > 0 && g[28] * kw * kw * 16 <= 48 * 1024) {
-            if (kw == 3) return launch_thin_rows<3>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
-            return launch_thin_rows<7>(p, ns, (int)g[30], (int)g[28], g[35] < 0, s);
+            g[C2M_G_TAPS] == kw * kw && g[C2M_G_CIN] > 0 && g[C2M_G_CIN] * kw * kw * 16 <= 48 * 1024) {
+            if (kw == 3) return launch_thin_rows<3>(p, ns, (int)g[C2M_G_NTG], (int)g[C2M_G_CIN], g[C2M_G_SQUARE_KW] < 0, s);
+            return launch_thin_rows<7>(p, ns, (int)g[C2M_G_NTG], (int)g[C2M_G_CIN], g[C2M_G_SQUARE_KW] < 0, s);
         }
         if (ns == 1) return launch_thin_fwd<1>(p, s);
         if (ns == 2) return launch_thin_fwd<2>(p, s);
         return launch_thin_fwd<4>(p, s);
     }
-    const bool bf16 = g[34] == 1;                          // operand precision: 0 fp32 (exact), 1 bf16 (fp32 accumulate)
+    const bool bf16 = g[C2M_G_PRECISION] == 1;                          // operand precision: 0 fp32 (exact), 1 bf16 (fp32 accumulate)
     if (bf16 ? !p.xh : (p.xh || p.yh)) return (int)hipErrorInvalidValue;   // bf16 kernels gather bf16 X; fp32 kernels are fp32 only
     if (p.M <= 32)      return launch_igemm<32, 256, 1, 4>(p, ns, splits, s, bf16);
     else if (p.M <= 64) return launch_igemm<64, 128, 2, 2>(p, ns, splits, s, bf16);
@@ -2535,17 +2535,17 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
     C2M_ENTER();
     WgradP p;
     p.dY = (const float*)dY; p.X = (const float*)X; p.slab = slab; p.jtab = reinterpret_cast<const int4*>(jtab);
-    p.M = (int)g[0]; p.J = (int)g[1];
-    p.Npix = (int)g[3]; p.To = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
-    p.Ti = (int)g[7]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
-    p.st = (int)g[10]; p.sh = (int)g[11]; p.sw = (int)g[12];
-    p.in_sn = g[13]; p.in_st = g[14]; p.in_sh = g[15];
-    p.dy_sn = g[16]; p.dy_sc = g[17];
-    p.reflect = (int)g[22]; p.is3d = (int)g[23];
-    p.in_sc = (int)g[25];
-    const int NS = (int)g[24], Cin = (int)g[28], taps = (int)g[29], ntg = (int)g[30], ngroups = (int)g[31];
-    if (g[32] <= 0 || g[32] >= 0x80000000LL || g[33] <= 0 || g[33] >= 0x80000000LL) return (int)hipErrorInvalidValue;
-    p.x_bytes = (unsigned)g[32]; p.dy_bytes = (unsigned)g[33];
+    p.M = (int)g[C2M_G_M]; p.J = (int)g[C2M_G_NK];
+    p.Npix = (int)g[C2M_G_NPIX]; p.To = (int)g[C2M_G_TO]; p.Ho = (int)g[C2M_G_HO]; p.Wo = (int)g[C2M_G_WO];
+    p.Ti = (int)g[C2M_G_TI]; p.Hi = (int)g[C2M_G_HI]; p.Wi = (int)g[C2M_G_WI];
+    p.st = (int)g[C2M_G_ST]; p.sh = (int)g[C2M_G_SH]; p.sw = (int)g[C2M_G_SW];
+    p.in_sn = g[C2M_G_IN_SN]; p.in_st = g[C2M_G_IN_ST]; p.in_sh = g[C2M_G_IN_SH];
+    p.dy_sn = g[C2M_G_OUT_SN]; p.dy_sc = g[C2M_G_OUT_SC];
+    p.reflect = (int)g[C2M_G_REFLECT]; p.is3d = (int)g[C2M_G_IS3D];
+    p.in_sc = (int)g[C2M_G_IN_SC];
+    const int NS = (int)g[C2M_G_NS], Cin = (int)g[C2M_G_CIN], taps = (int)g[C2M_G_TAPS], ntg = (int)g[C2M_G_NTG], ngroups = (int)g[C2M_G_NGROUPS];
+    if (g[C2M_G_X_BYTES] <= 0 || g[C2M_G_X_BYTES] >= 0x80000000LL || g[C2M_G_DY_BYTES] <= 0 || g[C2M_G_DY_BYTES] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[C2M_G_X_BYTES]; p.dy_bytes = (unsigned)g[C2M_G_DY_BYTES];
     if (p.M <= 0 || p.J <= 0 || p.Npix <= 0) return 0;
     int BM, BN;
     wgrad_tile(p.M, BM, BN);
@@ -2557,11 +2557,11 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
     const int Seff = c2m_cdiv(p.Npix, per);   // <= S; unused slabs are never read
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.J / BN, c2m_cdiv(p.M, BM), Seff);
-    const bool xh = g[90] == 1;                           // dY and X are bf16 tensors (bf16 kernels only)
+    const bool xh = g[C2M_G_X_TYPE] == 1;                           // dY and X are bf16 tensors (bf16 kernels only)
     if (p.M <= 4 && p.Npix >= 16384) {                    // thin output: vector-ALU kernels, same slab layout
         if (xh) return (int)hipErrorInvalidValue;         // fp32 operands (the host casts bf16 activations)
-        // g[35] = KW: 2-D stride-1 square KW x KW tap set in row-major order -> row-blocked kernel
-        const int kw = (int)g[35];
+        // g[C2M_G_SQUARE_KW] = KW: 2-D stride-1 square KW x KW tap set in row-major order -> row-blocked kernel
+        const int kw = (int)g[C2M_G_SQUARE_KW];
         if (p.M <= 3 && (kw == 3 || kw == 7) && !p.is3d && p.To == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Wo % 4 == 0 &&
             taps == kw * kw && Cin > 0 && (p.dy_sn % 4) == 0 && (p.dy_sc % 4) == 0 && ((uintptr_t)dY & 15) == 0) {
             const int lns = NS == 1 ? 0 : (NS == 2 ? 1 : 2);
@@ -2608,11 +2608,11 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
         const long total2 = (long)p.M * (ngroups + 1) * 16;
         return launch_wgrad_reduce(total2, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Sthin);
     }
-    const bool bf16 = g[34] == 1;
+    const bool bf16 = g[C2M_G_PRECISION] == 1;
     if (bf16 != xh) return (int)hipErrorInvalidValue;  // the bf16 kernel gathers bf16 tensors, the fp32 kernel fp32 ones
     const dim3 grid1(grid.x * grid.y * grid.z);       // 1-D launch, decoded XCD-aware in the kernel (common.h)
-    // g[92] = 1: the layer qualifies for the 16-byte-load form (host: unit x stride, Wi == Wo, Wo % 8 == 0, |tap dx| <= 1)
-    if (bf16 && g[92] == 2 && !getenv("C2M_WGRAD_NARROW")) {      // the stride-2 form (host: sw == 2, Wi == 2 Wo, Wo % 8 == 0, dx in -1 .. 2)
+    // g[C2M_G_WGRAD_WIDE] = 1: the layer qualifies for the 16-byte-load form (host: unit x stride, Wi == Wo, Wo % 8 == 0, |tap dx| <= 1)
+    if (bf16 && g[C2M_G_WGRAD_WIDE] == 2 && !getenv("C2M_WGRAD_NARROW")) {      // the stride-2 form (host: sw == 2, Wi == 2 Wo, Wo % 8 == 0, dx in -1 .. 2)
         if (p.sw != 2 || p.Wi != 2 * p.Wo || (p.Wo & 7) || (p.dy_sc & 7) || (p.pix_per_split & 63)) return (int)hipErrorInvalidValue;
         if (p.M <= 32)      hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<32, 128, 1, 4, 2>), grid1, dim3(256), 0, s, p, NS);
         else if (p.M > 64)  hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<128, 128, 2, 2, 2>), grid1, dim3(256), 0, s, p, NS);
@@ -2622,7 +2622,7 @@ C2M_API int c2m_conv_wgrad(const void* dY, const void* X, float* slab, float* dW
         const long totalw = (long)p.M * (ngroups + 1) * 16;
         return launch_wgrad_reduce(totalw, s, slab, dW, db, p.M, p.J, Cin, taps, NS, ntg, ngroups, Seff);
     }
-    if (bf16 && g[92] == 1 && !getenv("C2M_WGRAD_NARROW")) {
+    if (bf16 && g[C2M_G_WGRAD_WIDE] == 1 && !getenv("C2M_WGRAD_NARROW")) {
         if (p.sw != 1 || p.Wi != p.Wo || (p.Wo & 7) || p.Wi < 8 || (p.dy_sc & 7) || (p.pix_per_split & 63)) return (int)hipErrorInvalidValue;
         if (p.M <= 32)      hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<32, 128, 1, 4>), grid1, dim3(256), 0, s, p, NS);
         else if (p.M > 64)  hipLaunchKernelGGL((conv_wgrad_wide_bf16_kernel<128, 128, 2, 2>), grid1, dim3(256), 0, s, p, NS);

@@ -444,34 +444,34 @@ C2M_API int c2m_conv_patch_nc8(const void* A, const void* X, void* Y, void* Y_in
     C2M_ENTER();
     Nc8P p;
     p.A = A; p.X = X; p.Y = (float*)Y; p.Y2 = (float*)Y_interior; p.bias = bias;
-    p.M = (int)g[0]; p.Mpad = (int)g[2];
-    p.Ho = (int)g[5]; p.Wo = (int)g[6]; p.Hi = (int)g[8]; p.Wi = (int)g[9];
-    const int nk = (int)g[1], cin = (int)g[28], splits = (int)g[26];
-    if (p.M <= 0 || g[3] <= 0) return 0;
-    if (g[4] != 1 || g[7] != 1 || g[23] != 0 || g[10] != 1 || g[11] != 1 || g[12] != 1 || !g[52] || g[20] != 1)
+    p.M = (int)g[C2M_G_M]; p.Mpad = (int)g[C2M_G_LDA];
+    p.Ho = (int)g[C2M_G_HO]; p.Wo = (int)g[C2M_G_WO]; p.Hi = (int)g[C2M_G_HI]; p.Wi = (int)g[C2M_G_WI];
+    const int nk = (int)g[C2M_G_NK], cin = (int)g[C2M_G_CIN], splits = (int)g[C2M_G_SPLITS];
+    if (p.M <= 0 || g[C2M_G_NPIX] <= 0) return 0;
+    if (g[C2M_G_TO] != 1 || g[C2M_G_TI] != 1 || g[C2M_G_IS3D] != 0 || g[C2M_G_ST] != 1 || g[C2M_G_SH] != 1 || g[C2M_G_SW] != 1 || !g[C2M_G_PATCH] || g[C2M_G_OUT_SW] != 1)
         return (int)hipErrorInvalidValue;                  // 2-D, stride 1, unit pixel stride of the output
     p.nchunks = nk / 9;
     p.CB = (cin + 7) / 8;
     if (p.nchunks * 9 != nk || cin <= 0 || cin > p.nchunks * 16 || p.Mpad % 128 != 0 || p.Mpad < p.M || splits < 1 ||
         (((uintptr_t)A | (uintptr_t)X) & 15))
         return (int)hipErrorInvalidValue;
-    p.Nimg = (int)(g[3] / ((long)p.Ho * p.Wo));
-    if ((long)p.Nimg * p.Ho * p.Wo != g[3]) return (int)hipErrorInvalidValue;
+    p.Nimg = (int)(g[C2M_G_NPIX] / ((long)p.Ho * p.Wo));
+    if ((long)p.Nimg * p.Ho * p.Wo != g[C2M_G_NPIX]) return (int)hipErrorInvalidValue;
     const long xb = (long)p.Nimg * p.CB * p.Hi * p.Wi * 16, ab = (long)p.nchunks * 9 * p.Mpad * 32;
     if (xb >= 0x80000000LL || ab >= 0x80000000LL) return (int)hipErrorInvalidValue;
     p.x_bytes = (unsigned)xb; p.a_bytes = (unsigned)ab;
-    p.out_sn = g[16]; p.out_sc = g[17]; p.out_sh = g[19]; p.out_off = g[21];
-    p.reflect = (int)g[22]; p.slab_stride = g[27];
-    p.act = act; p.slope = slope; p.yh = (int)g[91];
+    p.out_sn = g[C2M_G_OUT_SN]; p.out_sc = g[C2M_G_OUT_SC]; p.out_sh = g[C2M_G_OUT_SH]; p.out_off = g[C2M_G_OUT_OFF];
+    p.reflect = (int)g[C2M_G_REFLECT]; p.slab_stride = g[C2M_G_SLAB_STRIDE];
+    p.act = act; p.slope = slope; p.yh = (int)g[C2M_G_Y_TYPE];
     if (p.Y2 && splits != 1) return (int)hipErrorInvalidValue;
-    p.ps_y = (int)g[37]; p.ps_x = (int)g[38]; p.po_y = (int)g[40]; p.po_x = (int)g[41]; p.lo_y = (int)g[43]; p.lo_x = (int)g[44];
-    p.ext_y = (int)g[46]; p.ext_x = (int)g[47]; p.y2_sn = g[48]; p.y2_sc = g[49]; p.y2_sh = g[51];
-    p.iy0 = (int)g[53]; p.ix0 = (int)g[54];
-    for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[55 + i]; p.ptx[i] = (int)g[58 + i]; }
+    p.ps_y = (int)g[C2M_G_PS_Y]; p.ps_x = (int)g[C2M_G_PS_X]; p.po_y = (int)g[C2M_G_PO_Y]; p.po_x = (int)g[C2M_G_PO_X]; p.lo_y = (int)g[C2M_G_LO_Y]; p.lo_x = (int)g[C2M_G_LO_X];
+    p.ext_y = (int)g[C2M_G_EXT_Y]; p.ext_x = (int)g[C2M_G_EXT_X]; p.y2_sn = g[C2M_G_Y2_SN]; p.y2_sc = g[C2M_G_Y2_SC]; p.y2_sh = g[C2M_G_Y2_SH];
+    p.iy0 = (int)g[C2M_G_PATCH_IY0]; p.ix0 = (int)g[C2M_G_PATCH_IX0];
+    for (int i = 0; i < 3; ++i) { p.pty[i] = (int)g[C2M_G_PATCH_TY + i]; p.ptx[i] = (int)g[C2M_G_PATCH_TX + i]; }
     p.chunks_per_split = c2m_cdiv(p.nchunks, splits);
     if (c2m_cdiv(p.nchunks, p.chunks_per_split) != splits) return (int)hipErrorInvalidValue;
     p.T = 1; p.nch2d = p.nchunks; p.t0 = 0; p.treflect = 0; p.out_st = 0; p.ptab = nullptr;
-    return nc8_launch_patch(p, splits, (int)g[93], (hipStream_t)stream);
+    return nc8_launch_patch(p, splits, (int)g[C2M_G_NC8_VARIANT], (hipStream_t)stream);
 }
 
 static int nc8_launch_patch(Nc8P& p, int splits, int v, hipStream_t s) {

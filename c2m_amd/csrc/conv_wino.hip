@@ -648,19 +648,19 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
     p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = p.y2_st = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
     if (Y_interior) {
-        p.y2_sn = g[18]; p.y2_sc = g[19]; p.y2_sh = g[20];
-        p.lo_y = (int)g[21]; p.lo_x = (int)g[22]; p.ext_y = (int)g[23]; p.ext_x = (int)g[24];
+        p.y2_sn = g[C2M_WG_Y2_SN]; p.y2_sc = g[C2M_WG_Y2_SC]; p.y2_sh = g[C2M_WG_Y2_SH];
+        p.lo_y = (int)g[C2M_WG_LO_Y]; p.lo_x = (int)g[C2M_WG_LO_X]; p.ext_y = (int)g[C2M_WG_EXT_Y]; p.ext_x = (int)g[C2M_WG_EXT_X];
     }
-    p.M = (int)g[0]; p.K = (int)g[1]; p.nimg = (int)g[2];
-    p.Hi = (int)g[3]; p.Wi = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
-    p.iy0 = (int)g[7]; p.ix0 = (int)g[8]; p.reflect = (int)g[9];
-    p.in_sn = g[10]; p.in_sc = (int)g[11]; p.in_sh = (int)g[12];
-    p.out_sn = g[13]; p.out_sc = g[14]; p.out_sh = g[15]; p.out_off = g[16];
-    if (g[17] <= 0 || g[17] >= 0x80000000LL) return (int)hipErrorInvalidValue;
-    p.x_bytes = (unsigned)g[17];
-    p.To = (int)g[25]; p.in_st = g[26]; p.out_st = g[27]; p.cin = (int)g[28]; p.nkt = (int)g[29]; p.toff = (int)g[30];
-    p.Ti = (int)g[31]; p.treflect = (int)g[32];
-    p.ptab = (const int*)(uintptr_t)g[33]; p.cpk = 0;
+    p.M = (int)g[C2M_WG_M]; p.K = (int)g[C2M_WG_K]; p.nimg = (int)g[C2M_WG_NIMG];
+    p.Hi = (int)g[C2M_WG_HI]; p.Wi = (int)g[C2M_WG_WI]; p.Ho = (int)g[C2M_WG_HO]; p.Wo = (int)g[C2M_WG_WO];
+    p.iy0 = (int)g[C2M_WG_IY0]; p.ix0 = (int)g[C2M_WG_IX0]; p.reflect = (int)g[C2M_WG_REFLECT];
+    p.in_sn = g[C2M_WG_IN_SN]; p.in_sc = (int)g[C2M_WG_IN_SC]; p.in_sh = (int)g[C2M_WG_IN_SH];
+    p.out_sn = g[C2M_WG_OUT_SN]; p.out_sc = g[C2M_WG_OUT_SC]; p.out_sh = g[C2M_WG_OUT_SH]; p.out_off = g[C2M_WG_OUT_OFF];
+    if (g[C2M_WG_X_BYTES] <= 0 || g[C2M_WG_X_BYTES] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[C2M_WG_X_BYTES];
+    p.To = (int)g[C2M_WG_TO]; p.in_st = g[C2M_WG_IN_ST]; p.out_st = g[C2M_WG_OUT_ST]; p.cin = (int)g[C2M_WG_CIN]; p.nkt = (int)g[C2M_WG_NKT]; p.toff = (int)g[C2M_WG_TOFF];
+    p.Ti = (int)g[C2M_WG_TI]; p.treflect = (int)g[C2M_WG_TREFLECT];
+    p.ptab = (const int*)(uintptr_t)g[C2M_WG_PTAB]; p.cpk = 0;
     if (p.nkt) {
         if (p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
         if (Y_interior) p.y2_st = (long)p.ext_y * p.y2_sh;      // frames of the interior target are dense [ext_y][y2_sh] planes

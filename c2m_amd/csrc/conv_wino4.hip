@@ -601,17 +601,17 @@ C2M_API int c2m_conv_wino4(const float* upack, const float* X, float* Y, float* 
     p.U = upack; p.X = X; p.Y = Y; p.bias = bias;
     p.Y2 = Y_interior; p.y2_sn = p.y2_sc = p.y2_sh = 0; p.lo_y = p.lo_x = p.ext_y = p.ext_x = 0;
     if (Y_interior) {
-        p.y2_sn = g[18]; p.y2_sc = g[19]; p.y2_sh = g[20];
-        p.lo_y = (int)g[21]; p.lo_x = (int)g[22]; p.ext_y = (int)g[23]; p.ext_x = (int)g[24];
+        p.y2_sn = g[C2M_WG_Y2_SN]; p.y2_sc = g[C2M_WG_Y2_SC]; p.y2_sh = g[C2M_WG_Y2_SH];
+        p.lo_y = (int)g[C2M_WG_LO_Y]; p.lo_x = (int)g[C2M_WG_LO_X]; p.ext_y = (int)g[C2M_WG_EXT_Y]; p.ext_x = (int)g[C2M_WG_EXT_X];
     }
-    p.M = (int)g[0]; p.K = (int)g[1]; p.nimg = (int)g[2];
-    p.Hi = (int)g[3]; p.Wi = (int)g[4]; p.Ho = (int)g[5]; p.Wo = (int)g[6];
-    p.iy0 = (int)g[7]; p.ix0 = (int)g[8]; p.reflect = (int)g[9];
-    p.in_sn = g[10]; p.in_sc = (int)g[11]; p.in_sh = (int)g[12];
-    p.out_sn = g[13]; p.out_sc = g[14]; p.out_sh = g[15]; p.out_off = g[16];
-    if (g[17] <= 0 || g[17] >= 0x80000000LL) return (int)hipErrorInvalidValue;
-    p.x_bytes = (unsigned)g[17];
-    if (g[29] != 0 || g[33] != 0) return (int)hipErrorInvalidValue;
+    p.M = (int)g[C2M_WG_M]; p.K = (int)g[C2M_WG_K]; p.nimg = (int)g[C2M_WG_NIMG];
+    p.Hi = (int)g[C2M_WG_HI]; p.Wi = (int)g[C2M_WG_WI]; p.Ho = (int)g[C2M_WG_HO]; p.Wo = (int)g[C2M_WG_WO];
+    p.iy0 = (int)g[C2M_WG_IY0]; p.ix0 = (int)g[C2M_WG_IX0]; p.reflect = (int)g[C2M_WG_REFLECT];
+    p.in_sn = g[C2M_WG_IN_SN]; p.in_sc = (int)g[C2M_WG_IN_SC]; p.in_sh = (int)g[C2M_WG_IN_SH];
+    p.out_sn = g[C2M_WG_OUT_SN]; p.out_sc = g[C2M_WG_OUT_SC]; p.out_sh = g[C2M_WG_OUT_SH]; p.out_off = g[C2M_WG_OUT_OFF];
+    if (g[C2M_WG_X_BYTES] <= 0 || g[C2M_WG_X_BYTES] >= 0x80000000LL) return (int)hipErrorInvalidValue;
+    p.x_bytes = (unsigned)g[C2M_WG_X_BYTES];
+    if (g[C2M_WG_NKT] != 0 || g[C2M_WG_PTAB] != 0) return (int)hipErrorInvalidValue;
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.K <= 0 || p.nimg <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
     if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;

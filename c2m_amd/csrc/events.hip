@@ -24,3 +24,9 @@ C2M_API int c2m_event_elapsed_ms(void* start, void* stop, float* ms) {
 C2M_API int c2m_event_destroy(void* ev) {
     return (int)hipEventDestroy((hipEvent_t)ev);
 }
+
+// ---- ABI self-description (include/c2m_geom.h): the ctypes host parses the header it ships with and refuses a library that was
+// built from another one (c2m_amd/_lib.py)
+C2M_API int c2m_abi_version(void) { return C2M_ABI_VERSION; }
+C2M_API int c2m_geom_len(void) { return C2M_G_LEN; }
+C2M_API int c2m_wino_geom_len(void) { return C2M_WG_LEN; }

@@ -14,6 +14,8 @@ import torch
 
 from . import _lib
 
+G, WG = _lib.GEOM, _lib.WINO_GEOM      # names of the geom[] entries (include/c2m_geom.h: one definition for kernels and host)
+
 ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
 LRELU_SLOPE = 0.2
 
@@ -439,7 +441,7 @@ def _pack_bf16_k333(w, M, C, dgrad=False, cin_total=None):
 def _nc8_launch(L, A, x, dst, y2, b, geom, act, slope, keep=None):
     """One 3x3 stride-1 launch on channel-blocked input: the layout pass + c2m_conv_patch_nc8 (timed together)."""
     xn = _to_nc8(x, keep)
-    geom[93] = _NC8_VARIANT
+    geom[G.NC8_VARIANT] = _NC8_VARIANT
     return L.c2m_conv_patch_nc8(_p(A), _p(xn), _p(dst), _p(y2), _p(b), _gp(geom), act, slope, _stream())
 
 
@@ -484,7 +486,7 @@ def _g8_geom(geom, C, taps, S):
     """geom of the same launch on the NC8 gather form: nk = taps * ceil(C/16) K-steps in (tap, chunk) order."""
     g = geom.copy()
     nk = taps * _cdiv(C, 16)
-    g[[1, 2, 24, 26, 28, 29, 34, 52, 94, 95]] = (nk, nk * 16, 1, S, C, taps, 1, 0, 1, _G8_VARIANT)
+    g[[G.NK, G.LDA, G.NS, G.SPLITS, G.CIN, G.TAPS, G.PRECISION, G.PATCH, G.G8, G.G8_VARIANT]] = (nk, nk * 16, 1, S, C, taps, 1, 0, 1, _G8_VARIANT)
     return g
 
 
@@ -496,10 +498,10 @@ def _g8_taps(offs, device):
 
 
 def _set_patch(geom, iy0, ix0, pty, ptx):
-    geom[52] = 1
-    geom[53], geom[54] = iy0, ix0
-    geom[55:58] = pty
-    geom[58:61] = ptx
+    geom[G.PATCH] = 1
+    geom[G.PATCH_IY0], geom[G.PATCH_IX0] = iy0, ix0
+    geom[G.PATCH_TY:G.PATCH_TY + 3] = pty
+    geom[G.PATCH_TX:G.PATCH_TX + 3] = ptx
 
 
 def _tap_offsets(kt, kh, kw, off_t, off_y, off_x):
@@ -541,10 +543,11 @@ def _pack_rows(wm, ck):
 
 
 def _geom(**kw):
-    g = np.zeros(120, dtype=np.int64)      # 96 .. 119: per-class (po_t, po_y, po_x) of a class-batched launch
-    idx = dict(M=0, nk=1, lda=2, Npix=3, To=4, Ho=5, Wo=6, Ti=7, Hi=8, Wi=9, st=10, sh=11, sw=12, in_sn=13, in_st=14,
-               in_sh=15, out_sn=16, out_sc=17, out_st=18, out_sh=19, out_sw=20, out_off=21, reflect=22, is3d=23, ns=24,
-               in_sc=25, splits=26, slab_stride=27, Cin=28, taps=29, ntg=30, ngroups=31, x_bytes=32, dy_bytes=33)
+    g = np.zeros(G.LEN, dtype=np.int64)      # CLS_PO .. LEN - 1: per-class (po_t, po_y, po_x) of a class-batched launch
+    idx = dict(M=G.M, nk=G.NK, lda=G.LDA, Npix=G.NPIX, To=G.TO, Ho=G.HO, Wo=G.WO, Ti=G.TI, Hi=G.HI, Wi=G.WI, st=G.ST, sh=G.SH, sw=G.SW,
+               in_sn=G.IN_SN, in_st=G.IN_ST, in_sh=G.IN_SH, out_sn=G.OUT_SN, out_sc=G.OUT_SC, out_st=G.OUT_ST, out_sh=G.OUT_SH,
+               out_sw=G.OUT_SW, out_off=G.OUT_OFF, reflect=G.REFLECT, is3d=G.IS3D, ns=G.NS, in_sc=G.IN_SC, splits=G.SPLITS,
+               slab_stride=G.SLAB_STRIDE, Cin=G.CIN, taps=G.TAPS, ntg=G.NTG, ngroups=G.NGROUPS, x_bytes=G.X_BYTES, dy_bytes=G.DY_BYTES)
     for k, v in kw.items():
         g[idx[k]] = v
     return g
@@ -596,9 +599,10 @@ def _ring_pack(w, Cout, Cin):
 
 def _wino_geom(head, To=0, in_st=0, out_st=0, cin=0, nkt=0, toff=0, Ti=0, treflect=0):
     """geom[] of c2m_conv_wino (include/c2m_hip.h): 33 entries; the tail describes the time taps of a 3x3x3 layer."""
-    g = np.zeros(34, dtype=np.int64)
+    g = np.zeros(WG.LEN, dtype=np.int64)
+    assert len(head) in (WG.X_BYTES + 1, WG.EXT_X + 1)       # M .. X_BYTES in enum order (+ the Y_interior block Y2_SN .. EXT_X)
     g[:len(head)] = head
-    g[25:33] = (To, in_st, out_st, cin, nkt, toff, Ti, treflect)
+    g[WG.TO:WG.TREFLECT + 1] = (To, in_st, out_st, cin, nkt, toff, Ti, treflect)
     return g
 
 
@@ -749,10 +753,10 @@ class _ConvPlan:
                      0, 4 * N * Cout * osp], To=Tl, in_st=hw_o, out_st=Hd * Wd, cin=Cout, nkt=3, toff=o, Ti=To, treflect=0)
                 if self.wino3d_pairs:
                     self.wino_pair_tab = torch.from_numpy(_time_pair_table(Ti).reshape(-1)).to(device)
-                    self.wino_dgrad_geom[33] = self.wino_pair_tab.data_ptr()
+                    self.wino_dgrad_geom[WG.PTAB] = self.wino_pair_tab.data_ptr()
                     # every launched frame is a real one: the two-target epilogue of the 2-D layers applies per frame (interior
                     # straight into dX, only the pad ring into the scratch tensor; then the border-only fold)
-                    self.wino_dgrad_geom[18:25] = (Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi)
+                    self.wino_dgrad_geom[WG.Y2_SN:WG.EXT_X + 1] = (Cin * in_sc, in_sc, Wi, 1, 1, Hi, Wi)
             # weight gradient: the 2-D Winograd wgrad kernel over images (sample, frame) and virtual channels (kt, ci)
             wrows = 32 if Cout <= 32 else 64
             wg_tiles = _cdiv(3 * Cin, 32) * _cdiv(Cout, wrows)
@@ -817,29 +821,29 @@ class _ConvPlan:
                               out_st=Ho * Wo, out_sh=Wo, out_sw=1, out_off=0, reflect=int(reflect), is3d=is3d, ns=ns,
                               in_sc=in_sc, splits=self.fwd_splits, slab_stride=N * Cout * osp,
                               x_bytes=4 * N * Cin * in_sc)
-        self.fwd_geom[[28, 29, 30]] = (Cin, taps, ntg)
+        self.fwd_geom[[G.CIN, G.TAPS, G.NTG]] = (Cin, taps, ntg)
         if kt == 1 and kh == kw and (st, sh, sw) == (1, 1, 1):
-            self.fwd_geom[35] = kw                # row-major square tap set, dx ascending (thin row-blocked kernel)
+            self.fwd_geom[G.SQUARE_KW] = kw                # row-major square tap set, dx ascending (thin row-blocked kernel)
         if self.fwd_patch:
             _set_patch(self.fwd_geom, -ph, -pw, (0, 1, 2), (0, 1, 2))
             if bf16:
-                self.fwd_geom[2] = _ceil(Cout, 128)       # lda = padded row count of the bf16 weight image
+                self.fwd_geom[G.LDA] = _ceil(Cout, 128)       # lda = padded row count of the bf16 weight image
         # ---- wgrad: same (chunk, tap group) row order + a ones group (bias gradient) + zero groups up to the tile
         self.J = L.c2m_conv_wgrad_rows(Cout, nk + 1)
         wtab, _, _ = _kstep_table(Cin, offs, in_sc, ck, extra_groups=self.J // 16 - nk - 1, ones_group=True)
         self.wg_tab = torch.from_numpy(wtab.reshape(-1)).to(device)
         self.wg_geom = self.fwd_geom.copy()
-        self.wg_geom[52] = 0
-        self.wg_geom[[0, 1, 16, 17]] = (Cout, self.J, Cout * osp, osp)
-        self.wg_geom[[28, 29, 30, 31]] = (Cin, taps, ntg, nk)
-        self.wg_geom[33] = 4 * N * Cout * osp
+        self.wg_geom[G.PATCH] = 0
+        self.wg_geom[[G.M, G.NK, G.OUT_SN, G.OUT_SC]] = (Cout, self.J, Cout * osp, osp)      # (wgrad: J rows, dY strides)
+        self.wg_geom[[G.CIN, G.TAPS, G.NTG, G.NGROUPS]] = (Cin, taps, ntg, nk)
+        self.wg_geom[G.DY_BYTES] = 4 * N * Cout * osp
         # bf16 data path: the 16-byte-load weight-gradient kernel (conv_wgrad_wide_bf16_kernel) takes layers whose 8-pixel
         # groups stay inside an input row up to one pad pixel: unit x stride, same-width output, |tap dx| <= 1
-        self.wg_geom[92] = int(bf16 and sw == 1 and Wi == Wo and Wo % 8 == 0 and Wi >= 8 and kw in (1, 3)
+        self.wg_geom[G.WGRAD_WIDE] = int(bf16 and sw == 1 and Wi == Wo and Wo % 8 == 0 and Wi >= 8 and kw in (1, 3)
                                and pw == (kw - 1) // 2 and osp % 8 == 0)
         # ... and its stride-2 form (4-wide taps, pad 1: dx = -1 .. 2; every second element of a 16-element run)
         if bf16 and _WGRAD_WIDE_S2 and sw == 2 and Wi == 2 * Wo and Wo % 8 == 0 and kw == 4 and pw == 1 and osp % 8 == 0:
-            self.wg_geom[92] = 2
+            self.wg_geom[G.WGRAD_WIDE] = 2
         self.wg_splits = L.c2m_conv_wgrad_splits(Cout, self.J, N * osp)
         # ---- dgrad: one launch per stride-parity class
         Tp, Hp, Wp = (Ti + 2 * pt, Hi + 2 * ph, Wi + 2 * pw) if reflect else (Ti, Hi, Wi)
@@ -889,14 +893,14 @@ class _ConvPlan:
                                  out_off=offt * Hp * Wp + offy * Wp + offx, reflect=0, is3d=is3d, ns=16 // cck,
                                  in_sc=osp, splits=1, slab_stride=tgt_numel, x_bytes=4 * N * Cout * osp)
                     # two-target epilogue (reflect): padded coord = q*stride + r per dim; interior = [pad, pad + extent)
-                    geom[36:52] = (st, sh, sw, offt, offy, offx, pt, ph, pw, Ti, Hi, Wi, Cin * in_sc, in_sc, Hi * Wi, Wi)
-                    geom[[28, 29, 30]] = (Cout, ctaps, cntg)
+                    geom[G.PS_T:G.Y2_SH + 1] = (st, sh, sw, offt, offy, offx, pt, ph, pw, Ti, Hi, Wi, Cin * in_sc, in_sc, Hi * Wi, Wi)
+                    geom[[G.CIN, G.TAPS, G.NTG]] = (Cout, ctaps, cntg)
                     if At == 1 and Ay == Ax and (st, sh, sw) == (1, 1, 1):
-                        geom[35] = -Ax            # data gradient: tap offsets run q - arange(A): dx descending
+                        geom[G.SQUARE_KW] = -Ax            # data gradient: tap offsets run q - arange(A): dx descending
                     if cpatch:
                         _set_patch(geom, qy - 2, qx - 2, (2, 1, 0), (2, 1, 0))
                         if bf16:
-                            geom[2] = _ceil(dM, 128)
+                            geom[G.LDA] = _ceil(dM, 128)
                     self.classes.append(dict(r=(rt, ry, rx), taps=ctaps, ck=cck, nk=cnk, npix=npix, patch=cpatch,
                                              tab=torch.from_numpy(ctab.reshape(-1)).to(device), geom=geom, offs=coffs))
         # common split count for all classes (they share one slab set); fall back to 1 if they cannot agree
@@ -910,7 +914,7 @@ class _ConvPlan:
             S = _patch_splits(L, dM, Cout, self.classes[0]["npix"], bf16)
         self.dgrad_splits = S
         for c in self.classes:
-            c["geom"][26] = S
+            c["geom"][G.SPLITS] = S
         # Algorithmic FLOPs (roofline bookkeeping): the data gradient of a convolution has the MACs of its forward
         # (2 * Cout * K * output pixels -- FlopCounterMode's count).  Reflect-padded layers LAUNCH over the
         # padded domain; every launch is credited with its share of the forward count, not with the padded volume.
@@ -929,7 +933,7 @@ class _ConvPlan:
         if 1 < ncls <= 8 and len(cl) == ncls and kt % st == 0 and kh % sh == 0 and kw % sw == 0 and \
                 not self.dgrad_needs_zero and not any(c["patch"] for c in cl) and \
                 len({(c["nk"], c["ck"], c["taps"]) for c in cl}) == 1:
-            key = lambda c: (c["npix"],) + tuple(int(v) for v in c["geom"][4:7])
+            key = lambda c: (c["npix"],) + tuple(int(v) for v in c["geom"][G.TO:G.WO + 1])
             runs, i = [], 0
             while i < ncls:                       # maximal runs of consecutive classes with identical extents
                 j = i
@@ -942,11 +946,13 @@ class _ConvPlan:
             groups = []
             for a, b in runs:
                 g = cl[a]["geom"].copy()
-                g[26] = SB
-                g[61], g[62], g[63] = b - a, Cin * nk0 * 16, nk0 * (1 + 16 // ck0)
+                g[G.SPLITS] = SB
+                g[G.NCLS], g[G.A_CLS], g[G.KTAB_CLS] = b - a, Cin * nk0 * 16, nk0 * (1 + 16 // ck0)
+                assert b - a <= 8                     # C2M_G_MAX_CLS (checked against the flag entries in c2m_geom.h)
                 for i in range(a, b):
-                    g[64 + i - a] = cl[i]["geom"][21]
-                    g[96 + 3 * (i - a):99 + 3 * (i - a)] = cl[i]["geom"][39:42]      # (not 72 + 3c: class 6 sat on geom[90..92], the element-type flags)
+                    g[G.CLS_OUT_OFF + i - a] = cl[i]["geom"][G.OUT_OFF]
+                    po = G.CLS_PO + 3 * (i - a)
+                    g[po:po + 3] = cl[i]["geom"][G.PO_T:G.PO_X + 1]
                 groups.append(dict(geom=g, tab=torch.cat([c["tab"] for c in cl[a:b]]), ncls=b - a, first=a,
                                    npix=cl[a]["npix"]))
             if len(groups) < ncls:
@@ -983,7 +989,7 @@ class _ConvPlan:
                 c["g8tab"] = _g8_taps(c["offs"], device)
             for grp in (self.cls_batch["groups"] if self.cls_batch else ()):
                 grp["g8"] = _g8_geom(grp["geom"], Cout, ctaps, S8)
-                grp["g8"][62], grp["g8"][63] = 0, 0
+                grp["g8"][G.A_CLS], grp["g8"][G.KTAB_CLS] = 0, 0
                 grp["g8tab"] = torch.cat([c["g8tab"] for c in cl[grp["first"]:grp["first"] + grp["ncls"]]])
 
 
@@ -1063,11 +1069,11 @@ def _plan(x, w, stride, pad, reflect, dgrad_rows=None):
         pl = _geom_cache[key] = _ConvPlan(tuple(x.shape), tuple(w.shape), stride, pad, reflect, x.device, _conv_bf16,
                                           dgrad_rows)
         if _conv_bf16:                     # geom[34] = operand precision, read by c2m_conv_igemm / c2m_conv_wgrad
-            pl.fwd_geom[34] = pl.wg_geom[34] = 1
+            pl.fwd_geom[G.PRECISION] = pl.wg_geom[G.PRECISION] = 1
             for c in pl.classes:
-                c["geom"][34] = 1
+                c["geom"][G.PRECISION] = 1
             for grp in (pl.cls_batch["groups"] if pl.cls_batch else ()):
-                grp["geom"][34] = 1
+                grp["geom"][G.PRECISION] = 1
     return pl
 
 
@@ -1204,9 +1210,9 @@ def refresh_trainable_packs(params=None):
 
 def _set_io(geom, x, ydt):
     """Per-call element types / bounds of a c2m_conv_igemm geom: X bytes (buffer range check), X type, Y type."""
-    geom[32] = x.numel() * x.element_size()
-    geom[90] = _dt(x)
-    geom[91] = 1 if ydt == BF16 else 0
+    geom[G.X_BYTES] = x.numel() * x.element_size()
+    geom[G.X_TYPE] = _dt(x)
+    geom[G.Y_TYPE] = 1 if ydt == BF16 else 0
     return geom
 
 
@@ -1231,7 +1237,7 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
         tgt = torch.empty(pl.wino_dgrad_target, device=dev, dtype=torch.float32) if pl.reflect else gx
         g3 = pl.wino_dgrad_geom
-        npix = int(g3[2] * g3[5] * g3[6])
+        npix = int(g3[WG.NIMG] * g3[WG.HO] * g3[WG.WO])
         tag = ("dgrad", Cin, Cout * 27, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino")
         two = pl.reflect and pl.wino3d_pairs
         _lib.check(_timed("wino", pl.dgrad_flops,
@@ -1253,7 +1259,7 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
             _packed(w, frozen_w, ("wino-dgrad",), lambda: _wino_filter(w, Cout, Cin, 1))
         conv_wino = L.c2m_conv_wino4 if w4 else L.c2m_conv_wino
         gx = torch.empty(xshape, device=dev, dtype=torch.float32)
-        npix = int(pl.wino_dgrad_geom[2] * pl.wino_dgrad_geom[5] * pl.wino_dgrad_geom[6])
+        npix = int(pl.wino_dgrad_geom[WG.NIMG] * pl.wino_dgrad_geom[WG.HO] * pl.wino_dgrad_geom[WG.WO])
         tag = ("dgrad", Cin, Cout * 9, npix, pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
         if pl.ring_dgrad:
             # reflect, exact domain: the interior term straight into gx, then the pad ring added in place (conv_ring.hip) -- both
@@ -1435,8 +1441,8 @@ class _ConvFn(torch.autograd.Function):
             conv_wino = L.c2m_conv_wino4 if (pl.wino4_fwd and not pl.wino3d) else L.c2m_conv_wino
             y = torch.empty(pl.out_shape, device=x.device, dtype=torch.float32)
             w4 = pl.wino4_fwd and not pl.wino3d           # F(4x4,3x3): its own roofline family (executed = algorithmic / 4)
-            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
-            _lib.check(_timed("wino4" if w4 else "wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "wino4" if w4 else "wino")
+            _lib.check(_timed("wino4" if w4 else "wino", 2.0 * Cout * pl.K * int(pl.fwd_geom[G.NPIX]),
                               lambda: conv_wino(_p(U), _p(x), _p(y), None, _p(b), _gp(pl.wino_fwd_geom), ACT[act],
                                                 slope, _stream()), tag,
                               4 * (x.numel() + w.numel() + y.numel())), "conv_wino fwd")
@@ -1448,14 +1454,14 @@ class _ConvFn(torch.autograd.Function):
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-k333",), lambda: _pack_bf16_k333(w, Cout, Cin))
             y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
             Ti_, Hi_, Wi_ = pl.dims[3:6]
-            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
             ctx.nc8_keep = {} if (pl.k333_wgrad_nc8 and ctx.needs_input_grad[1]) else None
 
             def run_k333():
                 xn = _to_nc8(x, ctx.nc8_keep)
                 return L.c2m_conv3d_nc8(_p(A), _p(xn), _p(y), _p(b), Cout, Cin, N, Ti_, Hi_, Wi_, int(pl.reflect), 1, ACT[act], slope,
                                         _stream())
-            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_k333, tag,
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[G.NPIX]), run_k333, tag,
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv3d_nc8 fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
@@ -1465,7 +1471,7 @@ class _ConvFn(torch.autograd.Function):
             A = _packed(w, ctx.frozen_w, ("fwd-bf16-s2",), lambda: _pack_bf16_patch(w, Cout, Cin, pl.K, 16, 2))
             y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
             Hi_, Wi_ = pl.dims[4:6]
-            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
 
             ctx.nc8_keep = {} if (pl.s2_wgrad_nc8 and ctx.needs_input_grad[1]) else None
 
@@ -1473,7 +1479,7 @@ class _ConvFn(torch.autograd.Function):
                 xn = _to_nc8(x, ctx.nc8_keep)
                 return L.c2m_conv_s2_nc8(_p(A), _p(xn), _p(y), _p(b), Cout, Cin, N, Hi_, Wi_, int(pl.reflect), 1, ACT[act], slope,
                                          _stream())
-            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_s2, tag,
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[G.NPIX]), run_s2, tag,
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_s2_nc8 fwd")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
@@ -1485,17 +1491,17 @@ class _ConvFn(torch.autograd.Function):
             S = pl.g8_fwd_splits
             y = torch.empty(pl.out_shape, device=x.device, dtype=BF16)
             dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
-            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S, "nc8g")
+            tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, S, "nc8g")
 
             def run_g8():
                 xn = _to_nc8(x)
                 _set_io(pl.g8_fwd_geom, xn, BF16)
                 return L.c2m_conv_igemm(_p(A), _p(xn), _p(dst), None, _p(b), _p(pl.g8_fwd_tab), _gp(pl.g8_fwd_geom), ACT[act], slope,
                                         _stream())
-            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]), run_g8, tag,
+            _lib.check(_timed("igemm_bf16", 2.0 * Cout * pl.K * int(pl.fwd_geom[G.NPIX]), run_g8, tag,
                               2 * (x.numel() + y.numel()) + 4 * w.numel()), "conv_igemm fwd (NC8 gather)")
             if S > 1:
-                _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
+                _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[G.OUT_SC]), Cout, ACT[act],
                                                slope, _dt(y), _stream()), "splitk_reduce")
             ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
             ctx.save_for_backward(x, w, y if ACT[act] else None)
@@ -1509,24 +1515,24 @@ class _ConvFn(torch.autograd.Function):
         if pl.bf16:
             # bf16 data path: bf16 in (an fp32 input is cast once), bf16 out -- except the <= 4-channel heads (flow, occlusion,
             # RGB), which stay fp32 and run on the fp32 vector-ALU kernels when the launch is big enough for them
-            if _thin(Cout, S, int(pl.fwd_geom[3])):
+            if _thin(Cout, S, int(pl.fwd_geom[G.NPIX])):
                 x = _as(x, torch.float32)
             else:
                 x = _as(x, BF16)
                 ydt = BF16 if Cout > 4 else torch.float32
         y = torch.empty(pl.out_shape, device=x.device, dtype=ydt)
         dst = y if S == 1 else torch.empty(S * y.numel(), device=x.device, dtype=torch.float32)
-        tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, S)
+        tag = ("fwd", Cout, pl.K, int(pl.fwd_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, S)
         _set_io(pl.fwd_geom, x, ydt)
         nc8 = pl.fwd_patch and pl.bf16 and pl.nc8
         ctx.nc8_keep = {} if (nc8 and pl.wgrad_nc8 and ctx.needs_input_grad[1]) else None      # X in NC8 form, for the weight gradient
-        _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[3]),
+        _lib.check(_timed("igemm_bf16" if pl.bf16 else "igemm", 2.0 * Cout * pl.K * int(pl.fwd_geom[G.NPIX]),
                           (lambda: _nc8_launch(L, A, x, dst, None, b, pl.fwd_geom, ACT[act], slope, ctx.nc8_keep)) if nc8 else
                           (lambda: L.c2m_conv_igemm(_p(A), _p(x), _p(dst), None, _p(b), _p(pl.fwd_tab), _gp(pl.fwd_geom),
                                                     ACT[act], slope, _stream())), tag + (("nc8",) if nc8 else ()),
                           x.element_size() * x.numel() + 4 * w.numel() + y.element_size() * y.numel()), "conv_igemm fwd")
         if S > 1:
-            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[17]), Cout, ACT[act],
+            _lib.check(L.c2m_splitk_reduce(_p(dst), _p(y), _p(b), y.numel(), S, int(pl.fwd_geom[G.OUT_SC]), Cout, ACT[act],
                                            slope, _dt(y), _stream()), "splitk_reduce")
         ctx.pl, ctx.act, ctx.has_bias = pl, act, b is not None
         ctx.save_for_backward(x, w, y if ACT[act] else None)
@@ -1601,8 +1607,8 @@ class _ConvFn(torch.autograd.Function):
             slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N * Ti, Hi, Wi, 0), device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
-            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
-            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[G.NPIX]),
                               lambda: L.c2m_conv_wgrad3d_nc8(_p(gyn), _p(xn), _p(slab), _p(gw), _p(gb_t), Cout, Cin, N, Ti, Hi, Wi,
                                                              int(pl.reflect), _stream()), tag,
                               2 * (gyn.numel() + xn.numel()) + 4 * w.numel()), "conv_wgrad3d_nc8")
@@ -1616,8 +1622,8 @@ class _ConvFn(torch.autograd.Function):
             slab = torch.empty(L.c2m_conv_wgrad_nc8_slab_floats(Cout, Cin, N, Hi, Wi, s2), device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
-            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
-            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "nc8")
+            _lib.check(_timed("wgrad_bf16", 2.0 * Cout * pl.K * int(pl.wg_geom[G.NPIX]),
                               lambda: L.c2m_conv_wgrad_nc8(_p(gyn), _p(xn), _p(slab), _p(gw), _p(gb_t), Cout, Cin, N, Hi, Wi,
                                                            int(pl.reflect), s2, _stream()), tag,
                               2 * (gyn.numel() + xn.numel()) + 4 * w.numel()), "conv_wgrad_nc8")
@@ -1629,8 +1635,8 @@ class _ConvFn(torch.autograd.Function):
             dbslab = torch.empty(S * Cout, device=x.device, dtype=torch.float32)
             gw3 = torch.empty(Cout, 3, Cin, 3, 3, device=x.device, dtype=torch.float32)      # (time tap, channel) order
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
-            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[G.NPIX]),
                               lambda: L.c2m_conv_wino_wgrad3d(_p(gy), _p(x), _p(slab), _p(dbslab), _p(gw3), _p(gb_t), Cout,
                                                               Cin, N, Ti, Hi, Wi, int(pl.reflect), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wino_wgrad3d")
@@ -1643,8 +1649,8 @@ class _ConvFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
             Hi, Wi = pl.dims[4:6]
-            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
-            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, "wino")
+            _lib.check(_timed("wino_wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[G.NPIX]),
                               lambda: L.c2m_conv_wino_wgrad(_p(gy), _p(x), _p(slab), _p(dbslab), _p(gw), _p(gb_t), Cout,
                                                             Cin, N, Hi, Wi, int(pl.reflect), _stream()), tag,
                               4 * (gy.numel() + x.numel() + w.numel())), "conv_wino_wgrad")
@@ -1653,14 +1659,14 @@ class _ConvFn(torch.autograd.Function):
             slab = torch.empty(pl.wg_splits * Cout * pl.J, device=x.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             gb_t = torch.empty(Cout, device=x.device, dtype=torch.float32)
-            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[3]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
+            tag = ("wgrad", Cout, pl.K, int(pl.wg_geom[G.NPIX]), pl.dims[9:12], pl.stride, pl.reflect, pl.wg_splits)
             # bf16 data path: the MFMA kernel gathers bf16 dY and X; the <= 4-output-channel heads run on the fp32 vector-ALU
             # kernels (c2m_conv_wgrad's own rule: M <= 4 and >= 16384 pixels)
-            wdt = BF16 if (pl.bf16 and not (Cout <= 4 and int(pl.wg_geom[3]) >= 16384)) else torch.float32
+            wdt = BF16 if (pl.bf16 and not (Cout <= 4 and int(pl.wg_geom[G.NPIX]) >= 16384)) else torch.float32
             xg, gyw = _as(x, wdt), _as(gy, wdt)
-            pl.wg_geom[32], pl.wg_geom[33] = xg.numel() * xg.element_size(), gyw.numel() * gyw.element_size()
-            pl.wg_geom[90] = _dt(xg)
-            _lib.check(_timed("wgrad_bf16" if pl.bf16 else "wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[3]),
+            pl.wg_geom[G.X_BYTES], pl.wg_geom[G.DY_BYTES] = xg.numel() * xg.element_size(), gyw.numel() * gyw.element_size()
+            pl.wg_geom[G.X_TYPE] = _dt(xg)
+            _lib.check(_timed("wgrad_bf16" if pl.bf16 else "wgrad", 2.0 * Cout * pl.K * int(pl.wg_geom[G.NPIX]),
                               lambda: L.c2m_conv_wgrad(_p(gyw), _p(xg), _p(slab), _p(gw), _p(gb_t), _p(pl.wg_tab),
                                                        _gp(pl.wg_geom), _stream()), tag,
                               xg.element_size() * (gyw.numel() + xg.numel()) + 4 * w.numel()), "conv_wgrad")
@@ -1796,11 +1802,11 @@ def conv_transpose2d(x, w, b=None, stride=2, padding=1, act=None, slope=LRELU_SL
     if pl is None:
         pl = _geom_cache[key] = _ConvPlan((N, Co, Ho, Wo), tuple(w.shape), s3, p3, False, x.device, _conv_bf16, None)
         if _conv_bf16:
-            pl.fwd_geom[34] = pl.wg_geom[34] = 1
+            pl.fwd_geom[G.PRECISION] = pl.wg_geom[G.PRECISION] = 1
             for c in pl.classes:
-                c["geom"][34] = 1
+                c["geom"][G.PRECISION] = 1
             for grp in (pl.cls_batch["groups"] if pl.cls_batch else ()):
-                grp["geom"][34] = 1
+                grp["geom"][G.PRECISION] = 1
     if pl.out_shape != (N, Ci, H, W):
         raise ValueError(f"conv_transpose2d: inconsistent geometry {tuple(x.shape)} vs {pl.out_shape}")
     with torch.no_grad():

@@ -21,6 +21,14 @@ extern "C" {
 
 enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LRELU = 2, C2M_ACT_SIGMOID = 3 };
 
+/* Names of the geom[] entries of the convolution entry points (enum c2m_geom_index, enum c2m_wino_geom_index) and the ABI version
+ * of this header.  A binding checks at load time that the library was built from the same header:
+ *   c2m_abi_version() == C2M_ABI_VERSION, c2m_geom_len() == C2M_G_LEN, c2m_wino_geom_len() == C2M_WG_LEN.                      */
+#include "c2m_geom.h"
+int c2m_abi_version(void);
+int c2m_geom_len(void);
+int c2m_wino_geom_len(void);
+
 /* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 (conv_igemm.hip) -------------------------------------
  * Replaces nn.Conv2d / nn.Conv3d (+ ReflectionPad2d/3d, bias, LeakyReLU/ReLU/Sigmoid) at:
  *   modules/layers/down_block.py:14-23,35-47   same_block.py:14-23,36-46,55-67   up_block.py:9-13

@@ -117,7 +117,7 @@ def test_gather_nc8_tile_variants(variant):
     Cout = 24 if variant in (1, 7) else 168
     case = ((3, 40, 12, 16), Cout, (1, 4, 4), (1, 2, 2), (0, 1, 1), "reflect")
     pl, y, yr, xg, xr, wg, wr, bg, br = _run_case(case)
-    assert pl.g8_fwd and pl.g8_dgrad and int(pl.g8_fwd_geom[95]) == variant
+    assert pl.g8_fwd and pl.g8_dgrad and int(pl.g8_fwd_geom[ops.G.G8_VARIANT]) == variant
     rel_close(y.float(), yr, 4e-3, "forward")
     rel_close(xg.grad, xr.grad, 5e-5, "data gradient")
 

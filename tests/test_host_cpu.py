@@ -215,3 +215,26 @@ def test_time_pair_table_is_the_adjoint_of_reflect_pad_plus_three_taps(T):
             to, ublock = int(tab[t, 1 + 2 * j]), int(tab[t, 2 + 2 * j])
             got[t] += gy[0, 0, to] * w[0, 0, 2 - ublock]          # U block = flipped time tap
     assert torch.allclose(got, x.grad[0, 0], rtol=0, atol=1e-14)
+
+
+def test_geom_names_one_definition_for_kernels_and_host():
+    """the geom[] blocks of the convolution entry points are addressed by NAME -- include/c2m_geom.h is compiled
+    into the library (csrc/common.h) and parsed by the ctypes host; the loaded library must report the header's ABI version and
+    block lengths, no two names may share an index, and the per-class ranges may not run into the flag entries (the round-3 bug:
+    class 6's pad offsets on geom[90..92]; now also a static_assert of the header)."""
+    from c2m_amd import _lib, ops
+    L = _lib.lib()
+    G, WG = _lib.GEOM, _lib.WINO_GEOM
+    assert (L.c2m_abi_version(), L.c2m_geom_len(), L.c2m_wino_geom_len()) == (_lib.ABI_VERSION, G.LEN, WG.LEN) == (5, 120, 34)
+    assert len(set(G.values())) == len(G) and len(set(WG.values())) == len(WG)
+    assert G.CLS_OUT_OFF + 8 <= G.X_TYPE and G.G8_VARIANT < G.CLS_PO and G.CLS_PO + 24 == G.LEN
+    assert G.PATCH_TY + 3 == G.PATCH_TX and G.PS_T + 16 == G.PATCH        # the two-target block is 16 consecutive entries
+    with pytest.raises(AttributeError):
+        G.NO_SUCH_ENTRY
+    # the host builds its blocks with these names: a class-batched plan (8 stride-parity classes of a 4x4x4 stride-2 layer)
+    import torch
+    pl = ops._ConvPlan((2, 16, 4, 16, 32), (32, 16, 4, 4, 4), (2, 2, 2), (1, 1, 1), True, torch.device("cpu"))
+    g = pl.cls_batch["groups"][0]["geom"]
+    assert len(g) == G.LEN and int(g[G.NCLS]) == 8 and int(g[G.X_TYPE]) == 0 and int(g[G.Y_TYPE]) == 0 and int(g[G.WGRAD_WIDE]) == 0
+    assert [tuple(int(v) for v in g[G.CLS_PO + 3 * c:G.CLS_PO + 3 * c + 3]) for c in range(8)] == \
+        [(a, b, c) for a in range(2) for b in range(2) for c in range(2)]

@@ -61,5 +61,19 @@ def test_routing_rule():
     assert not plan((40, 32, 128, 256), 64).wino4_fwd       # K < 64
     assert not plan((40, 128, 64, 128), 96).wino4_fwd       # M not a multiple of 64
     assert not plan((40, 128, 64, 128), 128, bf16=True).wino4_fwd
-    assert not big.wino4_dgrad                              # padded 66 x 130 domain: 67 % fill of its regions
+    # reflect data gradient (round 5): the exact 64 x 128 domain on F(4x4) + the pad ring (conv_ring.hip), not the padded 66 x 130
+    # domain (67 % fill of its regions), which stays the C2M_RING=off route
+    assert big.wino4_dgrad and big.ring_dgrad
     assert plan((40, 128, 64, 128), 128, reflect=False).wino4_dgrad
+    small = plan((40, 128, 32, 64), 128)                    # <= 32 x 64 maps: F(2x2) over the exact domain + ring
+    assert small.ring_dgrad and not small.wino4_dgrad
+    wide = plan((40, 32, 128, 256), 32)                     # F(2x2) on >= 64 x 128 maps: the padded domain (fill 0.8-0.9) stays
+    assert wide.wino_dgrad and not wide.ring_dgrad
+    assert not plan((40, 256, 16, 32), 256).ring_dgrad      # 16 x 32 maps (< 1024 pixels): the ring launch costs what the domain saves
+    monkey = ops._RING
+    try:
+        ops._RING = "off"
+        off = plan((40, 128, 64, 128), 128)
+        assert off.wino_dgrad and not off.ring_dgrad and not off.wino4_dgrad
+    finally:
+        ops._RING = monkey

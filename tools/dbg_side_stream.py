@@ -18,8 +18,8 @@ side = ops._side_stream(dev)
 main = torch.cuda.current_stream()
 def wgrad_on(stream, gyw, slab, gw, gb):
     with torch.cuda.stream(stream):
-        pl.wg_geom[32], pl.wg_geom[33] = x.numel() * 4, gyw.numel() * 4
-        pl.wg_geom[90] = 0
+        pl.wg_geom[ops.G.X_BYTES], pl.wg_geom[ops.G.DY_BYTES] = x.numel() * 4, gyw.numel() * 4
+        pl.wg_geom[ops.G.X_TYPE] = 0
         _lib.check(L.c2m_conv_wgrad(ops._p(gyw), ops._p(x), ops._p(slab), ops._p(gw), ops._p(gb), ops._p(pl.wg_tab),
                                     ops._gp(pl.wg_geom), ops._stream()), "wgrad")
 gyw = gy.float().contiguous()
