@@ -9,19 +9,19 @@ mkdir -p $O
 python3 bench.py --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err || tail -3 $O/bench_final.err
 echo "bench done"
 rm -rf $O/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --event-every 1 --no-cpu-baseline --conv-table $O/conv_shape_table.txt > $O/trace.log 2>&1 || tail -5 $O/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --event-every 1 --no-cpu-baseline --side-configs '' --conv-table $O/conv_shape_table.txt > $O/trace.log 2>&1 || tail -5 $O/trace.log
 cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
 cp $O/trace/*/*kernel_trace.csv $O/kernel_trace.csv
 rm -rf $O/trace
 echo "trace done"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$C $O/cal_$C
-  rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$C.log 2>&1 || tail -5 $O/pmc_$C.log
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --side-configs '' > $O/pmc_$C.log 2>&1 || tail -5 $O/pmc_$C.log
   rocprofv3 --pmc $C --output-format csv -d $O/cal_$C -- python3 tools/pmc_calib.py > $O/cal_$C.log 2>&1 || tail -5 $O/cal_$C.log
   echo "pmc $C done"
 done
 rm -rf $O/pmc_MFMA
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_MFMA -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_MFMA.log 2>&1 || tail -5 $O/pmc_MFMA.log
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_MFMA -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --side-configs '' > $O/pmc_MFMA.log 2>&1 || tail -5 $O/pmc_MFMA.log
 echo "pmc mfma done"
 python3 tools/prof_round2_post.py $O
 rm -f $O/kernel_trace.csv
