@@ -7,6 +7,7 @@ GROUPS = collections.OrderedDict([
     ("conv MFMA fwd / dgrad, NC8 (patch, stride-2, 3x3x3, gather)", r"conv_patch_nc8_kernel|conv_s2_dgrad_nc8|conv_gather_nc8"),
     ("conv MFMA wgrad, NC8", r"conv_wgrad_nc8_kernel"),
     ("conv MFMA fwd / dgrad, NCHW (igemm, patch3x3, Winograd)", r"conv_igemm_kernel|conv_patch3x3|conv_wino_kernel|conv_wino4_kernel"),
+    ("reflect pad-ring GEMMs of the data gradient (conv_ring.hip, round 5)", r"reflect_ring_dgrad"),
     ("conv MFMA wgrad, NCHW (direct, wide bf16, Winograd)", r"conv_wgrad_wide|conv_wgrad_kernel|conv_wino_wgrad_kernel"),
     ("thin <= 4-channel heads (vector ALU)", r"conv_thin"),
     ("NCHW -> NC8 layout pass", r"nchw_to_nc8"),
@@ -14,7 +15,7 @@ GROUPS = collections.OrderedDict([
     ("norm statistics / apply / backward", r"norm_"),
     ("reflect folds", r"reflect_"),
     ("x2 up-sampling / resize / pooling", r"upsample|resize|maxpool"),
-    ("weight packing, filter transforms, Adam", r"pack_|adam|wino_filter|wino4_filter"),
+    ("weight packing, filter transforms, Adam", r"pack_|adam|wino_filter|wino4_filter|ring_pack"),
     ("act_bwd, tap backward, losses", r"act_bwd|relu_tap|grad_to_nc8|l1_|ssim|final_sum"),
     ("warp / raster / splat / RoI", r"flow_warp|warp_inv|splat|raster|roi_"),
     ("hipBLASLt / rocBLAS GEMMs", r"Cijk|rocblas"),
