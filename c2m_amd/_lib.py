@@ -53,6 +53,7 @@ _SIGS = {
     "c2m_ring_pack_floats": (c_long, [c_int, c_int]),
     "c2m_ring_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "c2m_reflect_ring_dgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "c2m_reflect_ring_buffer": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "c2m_wino_wgrad_splits": (c_int, [c_int] * 5),
     "c2m_conv_wino_wgrad": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "c2m_conv_wino_wgrad3d": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

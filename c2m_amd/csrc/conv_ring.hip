@@ -40,7 +40,9 @@ constexpr int RG_PX = 64;            // pixels (line positions x images) per wor
 struct RingP {
     const float* A;                  // c2m_ring_pack: [side 4][chunk][tap 3][m-tile of 32][lane 64][8]
     const float* dY;                 // [N][C][H][W]
-    float* dX;                       // [N][M][H][W], already holds the interior term
+    float* dX;                       // [N][M][H][W], already holds the interior term (in-place mode)
+    float* R;                        // buffer mode (c2m_reflect_ring_buffer): [N][M][4 sides][r_l] ring terms for the Winograd epilogue
+    int r_l;
     int N, C, M, H, W;
     int nchunks, mt32, mgroups;      // 16-channel chunks, 32-row tiles, row groups of 128 * MTW rows
     int pt[4];                       // pixel tiles of 64 per side
@@ -172,12 +174,17 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
     const long a_tap = (long)p.mt32 * 512, a_chunk = 3 * a_tap;
     const float* __restrict__ abase = p.A + ((long)side * p.nchunks) * a_chunk + lane * 8;
     // line-end masks of this lane's two pixels: tap 0 reads the NEXT line position, tap 2 the previous one
-    bool m_next[2], m_prev[2];
+    // Buffer mode, row sides: the TRUE corners of the padded gradient (row 0 | H+1, column 0 | W+1: one tap each) mirror onto the
+    // line positions 1 and L-2 -- tap 0 at i = 1 also takes the element at i - 1, tap 2 at i = L-2 the one at i + 1 -- so the row
+    // terms of those positions are complete and the Winograd epilogue adds row and column terms independently (no corner part).
+    bool m_next[2], m_prev[2], fix_lo[2], fix_hi[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const long g = p0 + t * 32 + (lane & 31);
         const int i = (int)(g % L);
         m_next[t] = i != L - 1; m_prev[t] = i != 0;
+        fix_lo[t] = p.R != nullptr && rowside && i == 1;
+        fix_hi[t] = p.R != nullptr && rowside && i == L - 2;
     }
 
     float sraw[4], hraw = 0.f;
@@ -233,19 +240,23 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         const float* __restrict__ bb = &sS[lane >> 5][(lane & 31) + 2];
         if (p.diag & 2) continue;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int e = 0; e < 8; ++e) {
+            const float* __restrict__ be = bb + 2 * e * RG_SP;
+            const float n0 = be[0], o0 = be[-1], q0 = be[-2];             // next / own / previous line position, first half
+            const float n1 = rowside ? be[32] : 0.f, o1 = rowside ? be[31] : 0.f, q1 = rowside ? be[30] : 0.f;
+            float b[3][2];
+            b[0][0] = (m_next[0] ? n0 : 0.f) + (fix_lo[0] ? q0 : 0.f); b[0][1] = (m_next[1] ? n1 : 0.f) + (fix_lo[1] ? q1 : 0.f);
+            b[1][0] = o0; b[1][1] = o1;
+            b[2][0] = (m_prev[0] ? q0 : 0.f) + (fix_hi[0] ? n0 : 0.f); b[2][1] = (m_prev[1] ? q1 : 0.f) + (fix_hi[1] ? n1 : 0.f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float b0 = bb[2 * e * RG_SP - j], b1 = bb[2 * e * RG_SP - j + 32];
-                if (j == 0) { b0 = m_next[0] ? b0 : 0.f; b1 = m_next[1] ? b1 : 0.f; }
-                if (j == 2) { b0 = m_prev[0] ? b0 : 0.f; b1 = m_prev[1] ? b1 : 0.f; }
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int k = 0; k < MTW; ++k) {
                     const float av = e < 4 ? a[k][j][0][e & 3] : a[k][j][1][e & 3];
-                    acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[k][0], 0, 0, 0);
-                    if (rowside) acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[k][1], 0, 0, 0);
+                    acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][0], acc[k][0], 0, 0, 0);
+                    if (rowside) acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][1], acc[k][1], 0, 0, 0);
                 }
-            }
+        }
     }
     if (p.diag & 1) return;
     // ---- dX[target] += acc: lane owns pixel column (lane & 31) of each half, rows 4 (lane >> 5) + (r & 3) + 8 (r >> 2)
@@ -254,6 +265,18 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         const long pp = p0 + t * 32 + (lane & 31);
         if (t >= nhalf || pp >= npix) continue;
         const int n = (int)(pp / L), i = (int)(pp - (long)n * L);
+        if (p.R) {                                             // buffer mode: plain coalesced stores, every line position
+#pragma unroll
+            for (int k = 0; k < MTW; ++k) {
+                if (t32_0 + k >= p.mt32) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (t32_0 + k) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) p.R[(((long)n * p.M + m) * 4 + side) * p.r_l + i] = acc[k][t][r];
+                }
+            }
+            continue;
+        }
         if (i == 1 || i == L - 2) continue;                    // the corner targets of the plane: the corner part's
         const int ty = side == 0 ? 1 : (side == 1 ? H - 2 : i), tx = side == 2 ? 1 : (side == 3 ? W - 2 : i);
         float* __restrict__ d = p.dX + (long)n * p.M * HW + (long)ty * W + tx;
@@ -272,17 +295,16 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
 // dX [N][M][H][W] += the ring terms of the reflect-pad-1 data gradient (see the head of this file); dX must already hold the
 // zero-padded "same" data gradient.  apack = c2m_ring_pack(w); dY [N][C][H][W]; w native [C][M][3][3] (unused since the corner
 // part reads the packed fragments too; kept in the signature for the reference-side binding).  H, W >= 4.
-C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const float* dY, float* dX, int N, int C, int M, int H,
-                                   int W, void* stream) {
-    C2M_ENTER();
-    (void)w;
+static int ring_launch(const float* apack, const float* dY, float* dX, float* R, int r_l, int N, int C, int M, int H, int W,
+                       void* stream) {
     if (N <= 0 || C <= 0 || M <= 0) return 0;
     if (H < 4 || W < 4) return (int)hipErrorInvalidValue;
     const long dy_bytes = 4L * N * C * H * W, dx_bytes = 4L * N * M * H * W;
     if (dy_bytes >= 0x80000000L || dx_bytes >= 0x80000000L) return (int)hipErrorInvalidValue;
     if ((((uintptr_t)apack) & 15) != 0) return (int)hipErrorInvalidValue;
+    if (R && (r_l < H || r_l < W || (r_l & 3) || (((uintptr_t)R) & 15))) return (int)hipErrorInvalidValue;
     RingP p;
-    p.A = apack; p.dY = dY; p.dX = dX;
+    p.A = apack; p.dY = dY; p.dX = dX; p.R = R; p.r_l = r_l;
     p.N = N; p.C = C; p.M = M; p.H = H; p.W = W;
     p.nchunks = c2m_cdiv(C, RG_CK); p.mt32 = c2m_cdiv(M, 32);
     // 128 rows per workgroup (MTW = 1): the column sides are bound by their divergent gathers and read-modify-writes (one 128-byte
@@ -292,7 +314,7 @@ C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const flo
     p.pt[0] = p.pt[1] = c2m_cdiv((long)N * W, 64);
     p.pt[2] = p.pt[3] = c2m_cdiv((long)N * H, 32);
     p.gemm_blocks = (p.pt[0] + p.pt[1] + p.pt[2] + p.pt[3]) * p.mgroups;
-    p.corner_blocks = N * 4;
+    p.corner_blocks = R ? 0 : N * 4;                            // buffer mode: the row terms carry the corners (see the kernel)
     p.dy_bytes = (unsigned)dy_bytes;
     static const int diag = [] { const char* e = getenv("C2M_RING_DIAG"); return e ? atoi(e) : 0; }();
     p.diag = diag;
@@ -304,4 +326,23 @@ C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const flo
     if (mtw == 1) hipLaunchKernelGGL(reflect_ring_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else          hipLaunchKernelGGL(reflect_ring_dgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+C2M_API int c2m_reflect_ring_dgrad(const float* apack, const float* w, const float* dY, float* dX, int N, int C, int M, int H,
+                                   int W, void* stream) {
+    C2M_ENTER();
+    (void)w;
+    return ring_launch(apack, dY, dX, nullptr, 0, N, C, M, H, W, stream);
+}
+
+// Buffer mode (round 5, second form): the ring terms are WRITTEN (coalesced, no read-modify-write, no corner part) into
+// R [N][M][4][r_l] -- side 0 / 1: what to add to row 1 / H-2 at column x; side 2 / 3: to column 1 / W-2 at row y; r_l >= max(H, W),
+// r_l % 4 == 0 -- and the Winograd launch that FOLLOWS on the same stream adds them in its epilogue (c2m_conv_wino / c2m_conv_wino4:
+// geom[C2M_WG_RING], geom[C2M_WG_RING_L]).  The in-place form spent 19 of its 50 us reading and re-writing one float per 128-byte
+// line of dX along the two columns.
+C2M_API int c2m_reflect_ring_buffer(const float* apack, const float* dY, float* R, int N, int C, int M, int H, int W, int r_l,
+                                    void* stream) {
+    C2M_ENTER();
+    if (!R) return (int)hipErrorInvalidValue;
+    return ring_launch(apack, dY, nullptr, R, r_l, N, C, M, H, W, stream);
 }

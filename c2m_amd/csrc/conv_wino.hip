@@ -58,6 +58,10 @@ struct WinoP {
     // launch for two frames that only feed a fold).  ptab[t][11] = {npairs, (source frame, U block) x 5}; cpk = cin / 8.
     const int* ptab;
     int cpk;
+    // pad-ring terms of a reflect data gradient computed over the EXACT domain (conv_ring.hip, buffer mode): R [nimg][M][4][r_l],
+    // added to rows 1 / Ho-2 (sides 0 / 1, indexed by column) and columns 1 / Wo-2 (sides 2 / 3, indexed by row); or NULL
+    const float* R;
+    int r_l;
 };
 
 constexpr int WR = 8, WC = 16;               // output region rows / cols
@@ -459,6 +463,17 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
                         v[dx] = top ? (rx + r1) + r2 : (r1 - r2) - rx;
                     }
                     if (inb && cout < p.M) {
+                        if (p.R) {                             // uniform: ring terms of the reflect data gradient (2-D: img = smp)
+                            const float* __restrict__ rb = p.R + ((long)img * p.M + cout) * 4 * p.r_l;
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                if (ox + dx >= p.Wo) continue;
+                                if (oy == 1) v[dx] += rb[ox + dx];
+                                if (oy == p.Ho - 2) v[dx] += rb[p.r_l + ox + dx];
+                                if (ox + dx == 1) v[dx] += rb[2 * p.r_l + oy];
+                                if (ox + dx == p.Wo - 2) v[dx] += rb[3 * p.r_l + oy];
+                            }
+                        }
                         const float bb = p.bias ? p.bias[cout] : 0.f;
                         v[0] = c2m_act(v[0] + bb, p.act, p.slope); v[1] = c2m_act(v[1] + bb, p.act, p.slope);
                         if (mode == 2) {
@@ -526,6 +541,24 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void conv_wino_kernel(const W
                         v[dx] = top ? (rx + r1) + r2 : (r1 - r2) - rx;
                     }
                     if (inb && cout < p.M) {
+                        if (p.R) {                             // uniform: ring terms of the reflect data gradient (2-D: img = smp)
+                            const float* __restrict__ rb = p.R + ((long)img * p.M + cout) * 4 * p.r_l;
+                            if (oy == 1 || oy == p.Ho - 2) {
+                                const float* __restrict__ rr = rb + (oy == 1 ? 0 : p.r_l) + ox;
+#pragma unroll
+                                for (int dx = 0; dx < 4; ++dx) if (ox + dx < p.Wo) v[dx] += rr[dx];
+                            }
+                            if (ox <= 1 && ox + 3 >= 1) {
+                                const float q = rb[2 * p.r_l + oy];
+#pragma unroll
+                                for (int dx = 0; dx < 4; ++dx) if (ox + dx == 1) v[dx] += q;
+                            }
+                            if (ox <= p.Wo - 2 && ox + 3 >= p.Wo - 2) {
+                                const float q = rb[3 * p.r_l + oy];
+#pragma unroll
+                                for (int dx = 0; dx < 4; ++dx) if (ox + dx == p.Wo - 2) v[dx] += q;
+                            }
+                        }
                         const float bb = p.bias ? p.bias[cout] : 0.f;
 #pragma unroll
                         for (int dx = 0; dx < 4; ++dx) v[dx] = c2m_act(v[dx] + bb, p.act, p.slope);
@@ -661,6 +694,9 @@ C2M_API int c2m_conv_wino(const float* upack, const float* X, float* Y, float* Y
     p.To = (int)g[C2M_WG_TO]; p.in_st = g[C2M_WG_IN_ST]; p.out_st = g[C2M_WG_OUT_ST]; p.cin = (int)g[C2M_WG_CIN]; p.nkt = (int)g[C2M_WG_NKT]; p.toff = (int)g[C2M_WG_TOFF];
     p.Ti = (int)g[C2M_WG_TI]; p.treflect = (int)g[C2M_WG_TREFLECT];
     p.ptab = (const int*)(uintptr_t)g[C2M_WG_PTAB]; p.cpk = 0;
+    p.R = (const float*)(uintptr_t)g[C2M_WG_RING]; p.r_l = (int)g[C2M_WG_RING_L];
+    if (p.R && (Y_interior || p.reflect || g[C2M_WG_NKT] != 0 || p.Ho < 4 || p.Wo < 4 || p.r_l < p.Ho || p.r_l < p.Wo || p.out_off != 0))
+        return (int)hipErrorInvalidValue;
     if (p.nkt) {
         if (p.To <= 0 || p.Ti <= 0 || p.cin <= 0 || p.nkt * p.cin != p.K || p.nimg % p.To) return (int)hipErrorInvalidValue;
         if (Y_interior) p.y2_st = (long)p.ext_y * p.y2_sh;      // frames of the interior target are dense [ext_y][y2_sh] planes

@@ -49,6 +49,10 @@ struct Wino4P {
     int nchunks, mtiles;
     int act;
     float slope;
+    // pad-ring terms of a reflect data gradient computed over the EXACT domain (conv_ring.hip, buffer mode): R [nimg][M][4][r_l],
+    // added to rows 1 / Ho-2 (sides 0 / 1, indexed by column) and columns 1 / Wo-2 (sides 2 / 3, indexed by row); or NULL
+    const float* R;
+    int r_l;
 };
 
 // W4_FUSED (default): every wave interleaves the transform of chunk n + 1 and the patch DMA of chunk n + 2 with its OWN MFMAs of
@@ -464,10 +468,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4P p) {
         }
         if (cout < p.M) {
             const float bb = bias4[pass];
+            const float* __restrict__ rb = p.R ? p.R + ((long)img * p.M + cout) * 4 * p.r_l : nullptr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = oyb + r;
                 if (oy >= p.Ho) continue;
+                if (rb) {                                      // uniform: the ring terms of the reflect data gradient
+                    if (oy == 1 || oy == p.Ho - 2) {
+                        const float* __restrict__ rr = rb + (oy == 1 ? 0 : p.r_l) + oxb;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (oxb + c < p.Wo) y[r][c] += rr[c];
+                    }
+                    if (oxb <= 1 && oxb + 3 >= 1) {
+                        const float v = rb[2 * p.r_l + oy];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (oxb + c == 1) y[r][c] += v;
+                    }
+                    if (oxb <= p.Wo - 2 && oxb + 3 >= p.Wo - 2) {
+                        const float v = rb[3 * p.r_l + oy];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (oxb + c == p.Wo - 2) y[r][c] += v;
+                    }
+                }
                 if (p.act == C2M_ACT_NONE) {                   // one uniform branch per row instead of a switch per element
 #pragma unroll
                     for (int c = 0; c < 4; ++c) y[r][c] += bb;
@@ -612,6 +634,8 @@ C2M_API int c2m_conv_wino4(const float* upack, const float* X, float* Y, float* 
     if (g[C2M_WG_X_BYTES] <= 0 || g[C2M_WG_X_BYTES] >= 0x80000000LL) return (int)hipErrorInvalidValue;
     p.x_bytes = (unsigned)g[C2M_WG_X_BYTES];
     if (g[C2M_WG_NKT] != 0 || g[C2M_WG_PTAB] != 0) return (int)hipErrorInvalidValue;
+    p.R = (const float*)(uintptr_t)g[C2M_WG_RING]; p.r_l = (int)g[C2M_WG_RING_L];
+    if (p.R && (Y_interior || p.reflect || p.Ho < 4 || p.Wo < 4 || p.r_l < p.Ho || p.r_l < p.Wo || p.out_off != 0)) return (int)hipErrorInvalidValue;
     p.act = act; p.slope = slope;
     if (p.M <= 0 || p.K <= 0 || p.nimg <= 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
     if ((((uintptr_t)upack) & 15) != 0) return (int)hipErrorInvalidValue;

@@ -90,6 +90,7 @@ _WINO_TPAIRS = os.environ.get("C2M_WINO_TPAIRS", "1") != "0"    # 3x3x3 reflect 
 # reflect-padded 3x3 data gradients as interior (exact domain, Winograd) + pad ring (conv_ring.hip): "auto" (maps of >= C2M_RING_MIN_PIX
 # pixels) | "off" (padded domain + two-target epilogue + fold, rounds 1-4) | "force" (tests: every eligible layer with H, W >= 4)
 _RING = os.environ.get("C2M_RING", "auto")
+_RING_BUFFER = os.environ.get("C2M_RING_BUFFER", "1") != "0"     # ring terms through a compact buffer added by the Winograd epilogue (0: in place)
 _RING_MIN_PIX = int(os.environ.get("C2M_RING_MIN_PIX", "1024"))
 _RING_F2_MAX_PIX = int(os.environ.get("C2M_RING_F2_MAX_PIX", "4096"))      # largest map on which an F(2x2) interior + ring beats the padded domain
 _WINO4 = os.environ.get("C2M_WINO4", "auto")       # F(4x4,3x3) for the 2-D Winograd layers: "off" | "auto" (rule: _wino4_pays) | "force" (tests: every eligible 2-D Winograd launch)
@@ -1266,10 +1267,24 @@ def _conv_dgrad(pl, w, gy, frozen_w, out_dtype=torch.float32, keep=None):
             # launches inside the timed region of this layer's data gradient
             Ar = _packed(w, frozen_w, ("ring-dgrad",), lambda: _ring_pack(w, Cout, Cin))
             Hi_, Wi_ = pl.dims[4:6]
+            g_ = pl.wino_dgrad_geom
+            if _RING_BUFFER:
+                # buffer form: the ring launch WRITES its terms (coalesced, no read-modify-write of dX, no corner part) and the
+                # Winograd launch behind it adds them in its epilogue
+                r_l = _ceil(max(Hi_, Wi_), 4)
+                R = torch.empty(N * Cin * 4 * r_l, device=dev, dtype=torch.float32)
 
-            def run_ring():
-                rc = conv_wino(_p(U), _p(gy), _p(gx), None, None, _gp(pl.wino_dgrad_geom), 0, 0.0, _stream())
-                return rc or L.c2m_reflect_ring_dgrad(_p(Ar), _p(w), _p(gy), _p(gx), N, Cout, Cin, Hi_, Wi_, _stream())
+                def run_ring():
+                    rc = L.c2m_reflect_ring_buffer(_p(Ar), _p(gy), _p(R), N, Cout, Cin, Hi_, Wi_, r_l, _stream())
+                    g_[WG.RING], g_[WG.RING_L] = R.data_ptr(), r_l
+                    try:
+                        return rc or conv_wino(_p(U), _p(gy), _p(gx), None, None, _gp(g_), 0, 0.0, _stream())
+                    finally:
+                        g_[WG.RING], g_[WG.RING_L] = 0, 0
+            else:
+                def run_ring():
+                    rc = conv_wino(_p(U), _p(gy), _p(gx), None, None, _gp(g_), 0, 0.0, _stream())
+                    return rc or L.c2m_reflect_ring_dgrad(_p(Ar), _p(w), _p(gy), _p(gx), N, Cout, Cin, Hi_, Wi_, _stream())
             _lib.check(_timed("wino4" if w4 else "wino", pl.fwd_flops, run_ring, tag + ("ring",),
                               4 * (gy.numel() + w.numel() + xnumel)), "conv_wino dgrad + reflect ring")
             return gx if gx.dtype == out_dtype else gx.to(out_dtype)

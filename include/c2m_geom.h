@@ -7,7 +7,7 @@
  * ranges are checked against each other at compile time.  Meaning of every entry: include/c2m_hip.h, at the entry point. */
 #pragma once
 
-#define C2M_ABI_VERSION 5          /* bump when an entry is added, moved or changes meaning */
+#define C2M_ABI_VERSION 6          /* bump when an entry is added, moved or changes meaning */
 
 /* geom[] of c2m_conv_igemm / c2m_conv_wgrad / c2m_conv_patch_nc8 */
 enum c2m_geom_index {
@@ -49,12 +49,14 @@ enum c2m_wino_geom_index {
     C2M_WG_TO = 25, C2M_WG_IN_ST = 26, C2M_WG_OUT_ST = 27, C2M_WG_CIN = 28, C2M_WG_NKT = 29, C2M_WG_TOFF = 30, C2M_WG_TI = 31,
     C2M_WG_TREFLECT = 32,
     C2M_WG_PTAB = 33,                /* device pointer of the temporal pair table, or 0 */
-    C2M_WG_LEN = 34
+    C2M_WG_RING = 34,                /* device pointer of the pad-ring terms R [N][M][4][RING_L] (c2m_reflect_ring_buffer), or 0: added */
+    C2M_WG_RING_L = 35,              /* to rows 1 / Ho-2 and columns 1 / Wo-2 of the output by the epilogue (2-D, single target only)  */
+    C2M_WG_LEN = 36
 };
 
 #ifdef __cplusplus
 static_assert(C2M_G_PATCH_TY + 3 == C2M_G_PATCH_TX && C2M_G_PATCH_TX + 3 == C2M_G_NCLS, "patch tap rows / columns");
 static_assert(C2M_G_CLS_OUT_OFF + C2M_G_MAX_CLS <= C2M_G_X_TYPE, "per-class output offsets run into the element-type flags");
 static_assert(C2M_G_G8_VARIANT < C2M_G_CLS_PO && C2M_G_CLS_PO + 3 * C2M_G_MAX_CLS == C2M_G_LEN, "per-class pad offsets");
-static_assert(C2M_WG_PTAB + 1 == C2M_WG_LEN, "wino geom length");
+static_assert(C2M_WG_RING_L + 1 == C2M_WG_LEN, "wino geom length");
 #endif

@@ -221,6 +221,13 @@ long c2m_ring_pack_floats(int C, int M);
 int c2m_ring_pack(const float* w, float* apack, int C, int M, void* stream);
 int c2m_reflect_ring_dgrad(const float* apack, const float* w, const float* dY, float* dX, int N, int C, int M, int H, int W,
                            void* stream);
+/* Buffer form (the one the product runs): the ring terms are WRITTEN -- coalesced, no read-modify-write of dX, corners carried by
+ * the row terms -- into R [N][M][4][r_l] (sides 0 / 1: added to row 1 / H-2 at column x; 2 / 3: to column 1 / W-2 at row y;
+ * r_l >= max(H, W), r_l % 4 == 0, 16-byte aligned), and the c2m_conv_wino / c2m_conv_wino4 launch that FOLLOWS on the same stream
+ * over the exact domain adds them in its epilogue: geom[C2M_WG_RING] = R, geom[C2M_WG_RING_L] = r_l (2-D, single target,
+ * out_off 0).  The in-place form spent 19 of its ~50 us per launch on one-float-per-128-byte-line accesses to dX's two columns. */
+int c2m_reflect_ring_buffer(const float* apack, const float* dY, float* R, int N, int C, int M, int H, int W, int r_l,
+                            void* stream);
 
 /* Adjoint of reflection padding: folds a gradient over the padded domain back (ReflectionPad2d/3d backward);
  * _border_add is the in-place form used after a two-target dgrad (dX already holds the direct term).          */

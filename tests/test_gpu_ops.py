@@ -244,9 +244,10 @@ RING_CASES = [c for c in WINO4_CASES if c[5] == "reflect" and min(c[0][2:]) >= 4
 ]
 
 
+@pytest.mark.parametrize("form", ["buffer", "inplace"])
 @pytest.mark.parametrize("w4", ["F(2x2)", "F(4x4)"])
 @pytest.mark.parametrize("case", RING_CASES, ids=lambda c: f"x{c[0]}_co{c[1]}")
-def test_conv_reflect_ring_dgrad(case, w4, monkeypatch):
+def test_conv_reflect_ring_dgrad(case, w4, form, monkeypatch):
     """Reflect-pad data gradient as interior + ring (round 5): the Winograd kernels run the zero-padded "same" data gradient over
     the EXACT H x W domain and c2m_reflect_ring_dgrad (conv_ring.hip) adds what the pad ring of the padded gradient mirrors onto
     rows 1, H-2 / columns 1, W-2 -- against torch's reflection_pad2d + conv2d autograd on the CPU at the data-gradient gate, the
@@ -254,6 +255,9 @@ def test_conv_reflect_ring_dgrad(case, w4, monkeypatch):
     monkeypatch.setattr(ops, "_WINO", "force")
     monkeypatch.setattr(ops, "_WINO4", "force" if w4 == "F(4x4)" else "off")
     monkeypatch.setattr(ops, "_RING", "force")
+    # "buffer" (product): ring terms written to a compact buffer, added by the Winograd epilogue; "inplace": the first form of the
+    # round (ring launch read-modify-writes dX + corner part) -- same sums up to the order of three additions at the corner targets
+    monkeypatch.setattr(ops, "_RING_BUFFER", form == "buffer")
     ops._geom_cache.clear()
     try:
         xs, cout, k, stride, pad, mode = case

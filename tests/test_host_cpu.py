@@ -225,7 +225,7 @@ def test_geom_names_one_definition_for_kernels_and_host():
     from c2m_amd import _lib, ops
     L = _lib.lib()
     G, WG = _lib.GEOM, _lib.WINO_GEOM
-    assert (L.c2m_abi_version(), L.c2m_geom_len(), L.c2m_wino_geom_len()) == (_lib.ABI_VERSION, G.LEN, WG.LEN) == (5, 120, 34)
+    assert (L.c2m_abi_version(), L.c2m_geom_len(), L.c2m_wino_geom_len()) == (_lib.ABI_VERSION, G.LEN, WG.LEN) == (6, 120, 36)
     assert len(set(G.values())) == len(G) and len(set(WG.values())) == len(WG)
     assert G.CLS_OUT_OFF + 8 <= G.X_TYPE and G.G8_VARIANT < G.CLS_PO and G.CLS_PO + 24 == G.LEN
     assert G.PATCH_TY + 3 == G.PATCH_TX and G.PS_T + 16 == G.PATCH        # the two-target block is 16 consecutive entries

@@ -36,7 +36,18 @@ def run(mode, shape, min_pix=None):
     e1.record()
     torch.cuda.synchronize()
     total_us = e0.elapsed_time(e1) / reps * 1000.0
-    if pl.ring_dgrad:                       # the ring launch alone
+    if pl.ring_dgrad and ops._RING_BUFFER:  # the ring launch alone (buffer form)
+        L = ops._lib.lib()
+        Ar = ops._ring_pack(w, Cout, Cin)
+        r_l = (max(H, W) + 3) // 4 * 4
+        R = torch.empty(N * Cin * 4 * r_l, device=dev)
+        e0.record()
+        for _ in range(reps):
+            L.c2m_reflect_ring_buffer(ops._p(Ar), ops._p(gy), ops._p(R), N, Cout, Cin, H, W, r_l, ops._stream())
+        e1.record()
+        torch.cuda.synchronize()
+        run.ring_us = e0.elapsed_time(e1) / reps * 1000.0
+    elif pl.ring_dgrad:                     # the ring launch alone
         L = ops._lib.lib()
         Ar = ops._ring_pack(w, Cout, Cin)
         e0.record()
