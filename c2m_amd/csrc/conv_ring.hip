@@ -85,7 +85,7 @@ constexpr int RG_SP = 72;            // LDS pitch of a channel's 66-element slic
 // MTW = 32-row tiles per wave: the workgroup's four waves cover 128 * MTW rows of ALL 64 pixels
 template <int MTW>
 __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kernel(const RingP p) {
-    __shared__ float sS[RG_CK][RG_SP];               // 16 channels x (pixel p0 - 1 .. p0 + 64) of the side's line(s)
+    __shared__ float sS[2][RG_CK][RG_SP];            // 2 x 16 channels x (pixel p0 - 1 .. p0 + 64) of the side's line(s)
     __shared__ float sD[7][RG_CK];                   // corner part: the seven dY elements of 16 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,29 +187,40 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         fix_hi[t] = p.R != nullptr && rowside && i == L - 2;
     }
 
-    float sraw[4], hraw = 0.f;
-    f32x4 araw[MTW][3][2];
-    auto fetch = [&](int q) __attribute__((always_inline)) {
+    // Two 16-channel chunks per loop iteration (one barrier pair and one prefetch round trip per 32 channels: with one chunk per
+    // iteration the 24-48 MFMAs of a chunk were shorter than the latency of the next chunk's divergent gathers)
+    constexpr int NSUB = 2;
+    float sraw[NSUB][4], hraw[NSUB] = {0.f, 0.f};
+    f32x4 araw[NSUB][MTW][3][2];
+    auto fetch = [&](int q2) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (p.diag & 4) break;
-            const int c = q * RG_CK + cg * 4 + e;             // wave-uniform
-            sraw[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, c < p.C ? voff_main : RING_OOB, c * HW * 4, 0));
-        }
-        if (wave == 0 && !(p.diag & 4)) {
-            const int c = q * RG_CK + (tid & 15);
-            hraw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                rsy, (c < p.C && voff_halo != RING_OOB) ? voff_halo + (unsigned)(c * HW * 4) : RING_OOB, 0, 0));
-        }
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int q = q2 * NSUB + sub;
 #pragma unroll
-        for (int k = 0; k < MTW; ++k)
-            if (t32_0 + k < p.mt32 && !(p.diag & 8)) {
+            for (int e = 0; e < 4; ++e) {
+                if (p.diag & 4) break;
+                const int c = q * RG_CK + cg * 4 + e;         // wave-uniform; chunks past the end: c >= C -> zeros
+                sraw[sub][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, c < p.C ? voff_main : RING_OOB, c * HW * 4, 0));
+            }
+            if (wave == 0 && !(p.diag & 4)) {
+                const int c = q * RG_CK + (tid & 15);
+                hraw[sub] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rsy, (c < p.C && voff_halo != RING_OOB) ? voff_halo + (unsigned)(c * HW * 4) : RING_OOB, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < MTW; ++k) {
+                const bool live = t32_0 + k < p.mt32 && q < p.nchunks && !(p.diag & 8);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(abase + q * a_chunk + j * a_tap + (long)(t32_0 + k) * 512);
-                    araw[k][j][0] = a[0]; araw[k][j][1] = a[1];
+                    if (live) {
+                        const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(abase + q * a_chunk + j * a_tap + (long)(t32_0 + k) * 512);
+                        araw[sub][k][j][0] = a[0]; araw[sub][k][j][1] = a[1];
+                    } else {
+                        araw[sub][k][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; araw[sub][k][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
+        }
     };
     f32x16 acc[MTW][2];
 #pragma unroll
@@ -218,44 +229,49 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void reflect_ring_dgrad_kern
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][t][r] = 0.f;
-#pragma unroll
-    for (int k = 0; k < MTW; ++k)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { araw[k][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; araw[k][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    const int niter = (p.nchunks + NSUB - 1) / NSUB;
     fetch(0);
-    for (int q = 0; q < p.nchunks; ++q) {
-        __syncthreads();                                       // the previous chunk's fragment reads are done
+    for (int q2 = 0; q2 < niter; ++q2) {
+        __syncthreads();                                       // the previous iteration's fragment reads are done
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if ((tid & 63) < tpx) sS[cg * 4 + e][1 + (tid & 63)] = sraw[e];      // (column sides: 32 live lanes; index tpx + 1 is the neighbour element's)
-        if (tid < 32) sS[tid & 15][tid < 16 ? 0 : tpx + 1] = hraw;
-        f32x4 a[MTW][3][2];
+        for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-        for (int k = 0; k < MTW; ++k)
+            for (int e = 0; e < 4; ++e)
+                if ((tid & 63) < tpx) sS[sub][cg * 4 + e][1 + (tid & 63)] = sraw[sub][e];   // (column sides: 32 live lanes; index tpx + 1 is the neighbour element's)
+            if (tid < 32) sS[sub][tid & 15][tid < 16 ? 0 : tpx + 1] = hraw[sub];
+        }
+        f32x4 a[NSUB][MTW][3][2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { a[k][j][0] = araw[k][j][0]; a[k][j][1] = araw[k][j][1]; }
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int k = 0; k < MTW; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { a[sub][k][j][0] = araw[sub][k][j][0]; a[sub][k][j][1] = araw[sub][k][j][1]; }
         __syncthreads();
-        if (q + 1 < p.nchunks) fetch(q + 1);                   // in flight during this chunk's MFMAs
-        const float* __restrict__ bb = &sS[lane >> 5][(lane & 31) + 2];
+        if (q2 + 1 < niter) fetch(q2 + 1);                     // in flight during this iteration's MFMAs
         if (p.diag & 2) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float* __restrict__ be = bb + 2 * e * RG_SP;
-            const float n0 = be[0], o0 = be[-1], q0 = be[-2];             // next / own / previous line position, first half
-            const float n1 = rowside ? be[32] : 0.f, o1 = rowside ? be[31] : 0.f, q1 = rowside ? be[30] : 0.f;
-            float b[3][2];
-            b[0][0] = (m_next[0] ? n0 : 0.f) + (fix_lo[0] ? q0 : 0.f); b[0][1] = (m_next[1] ? n1 : 0.f) + (fix_lo[1] ? q1 : 0.f);
-            b[1][0] = o0; b[1][1] = o1;
-            b[2][0] = (m_prev[0] ? q0 : 0.f) + (fix_hi[0] ? n0 : 0.f); b[2][1] = (m_prev[1] ? q1 : 0.f) + (fix_hi[1] ? n1 : 0.f);
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const float* __restrict__ bb = &sS[sub][lane >> 5][(lane & 31) + 2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int e = 0; e < 8; ++e) {
+                const float* __restrict__ be = bb + 2 * e * RG_SP;
+                const float n0 = be[0], o0 = be[-1], q0 = be[-2];             // next / own / previous line position, first half
+                const float n1 = rowside ? be[32] : 0.f, o1 = rowside ? be[31] : 0.f, q1 = rowside ? be[30] : 0.f;
+                float b[3][2];
+                b[0][0] = (m_next[0] ? n0 : 0.f) + (fix_lo[0] ? q0 : 0.f); b[0][1] = (m_next[1] ? n1 : 0.f) + (fix_lo[1] ? q1 : 0.f);
+                b[1][0] = o0; b[1][1] = o1;
+                b[2][0] = (m_prev[0] ? q0 : 0.f) + (fix_hi[0] ? n0 : 0.f); b[2][1] = (m_prev[1] ? q1 : 0.f) + (fix_hi[1] ? n1 : 0.f);
 #pragma unroll
-                for (int k = 0; k < MTW; ++k) {
-                    const float av = e < 4 ? a[k][j][0][e & 3] : a[k][j][1][e & 3];
-                    acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][0], acc[k][0], 0, 0, 0);
-                    if (rowside) acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][1], acc[k][1], 0, 0, 0);
-                }
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int k = 0; k < MTW; ++k) {
+                        const float av = e < 4 ? a[sub][k][j][0][e & 3] : a[sub][k][j][1][e & 3];
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][0], acc[k][0], 0, 0, 0);
+                        if (rowside) acc[k][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][1], acc[k][1], 0, 0, 0);
+                    }
+            }
         }
     }
     if (p.diag & 1) return;
