@@ -412,6 +412,63 @@ __global__ __launch_bounds__(256) void norm_inst_fused_kernel(const ApplyP<T> p,
     }
 }
 
+// Batch norm (mode 1) of SMALL channel volumes in one launch (round 5): the deep encoder / bottleneck levels (16x32 maps and
+// below, 40 folded frames: N * S <= 32768 elements per channel) ran partial + finalize + apply as three launches of a few
+// microseconds each.  One workgroup owns a channel: its N planes are walked as ONE index range (coalesced inside a plane), kept in
+// registers (NE elements per thread), two-pass statistics (mean, then centred squares: cancellation-safe like the chunked path),
+// running-statistics update, apply.  Same for the backward up to 8192 elements per channel (x-hat and g' in registers).
+template <class T, int NE>
+__global__ __launch_bounds__(256) void norm_bn_small_fused_kernel(const ApplyP<T> p, float* __restrict__ mean_out,
+                                                                  float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float eps, float momentum) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    const int S = (int)p.S, total = p.N * S;
+    const long cstride = (long)p.C * p.S;                   // from plane (n, c) to plane (n + 1, c)
+    const T* __restrict__ xc = p.x + (long)c * p.S;
+    float keep[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * 256;
+        keep[k] = 0.f;
+        if (e < total) {
+            const int n = e / S, q = e - n * S;
+            keep[k] = c2m_ld(xc, (long)n * cstride + q);
+            s += keep[k];
+        }
+    }
+    s = block_sum_256(s, sm);
+    const float mean = s / (float)total;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < total) { const float d = keep[k] - mean; m2 += d * d; }
+    }
+    m2 = block_sum_256(m2, sm);
+    const double var = (double)m2 / (double)total;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean; invstd_out[c] = invstd;
+        if (running_mean) {
+            const double unbiased = total > 1 ? (double)m2 / (double)(total - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (double)mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    T* __restrict__ yc = p.y + (long)c * p.S;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < total) {
+            const int n = e / S, q = e - n * S;
+            c2m_st(yc, (long)n * cstride + q, c2m_act((keep[k] - mean) * invstd * ga + be, p.act, p.slope));
+        }
+    }
+}
+
 static int norm_fused_on = [] { const char* e = getenv("C2M_NORM_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();      // A/B knob
 // tests / A/B runs: 0 = every norm on the three-launch path, 1 = the one-launch instance-norm kernels where eligible; returns the old value
 C2M_API int c2m_norm_set_fused(int on) { const int old = norm_fused_on; norm_fused_on = on ? 1 : 0; return old; }
@@ -430,6 +487,18 @@ C2M_API int c2m_norm_fwd(const void* x, float* mean, float* invstd, float* runni
                 hipLaunchKernelGGL((norm_inst_fused_kernel<T, 8>), dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, eps);
             else
                 hipLaunchKernelGGL((norm_inst_fused_kernel<T, 32>), dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, eps););
+        return (int)hipGetLastError();
+    }
+    if (norm_fused_on && mode == 1 && !gb && (long)N * S <= 32768) {
+        const long tot = (long)N * S;
+        C2M_DISPATCH_DT(dt,
+            ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, nullptr, (T*)y, N, C, S, mode, act, slope};
+            if (tot <= 2048)
+                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 8>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum);
+            else if (tot <= 8192)
+                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 32>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum);
+            else
+                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 128>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum););
         return (int)hipGetLastError();
     }
     const int rc = c2m_norm_stats(x, mean, invstd, running_mean, running_var, workspace, N, C, S, mode, eps, momentum, dt, stream);
@@ -777,6 +846,50 @@ __global__ __launch_bounds__(256) void norm_inst_bwd_fused_kernel(const BwdP<T> 
     }
 }
 
+// Batch-norm backward of a small channel volume (N * S <= 8192) in one launch: see norm_bn_small_fused_kernel.
+template <class T, int NE>
+__global__ __launch_bounds__(256) void norm_bn_small_bwd_fused_kernel(const BwdP<T> p) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    const int S = (int)p.S, total = p.N * S;
+    const long cstride = (long)p.C * p.S;
+    const float mean = p.mean[c], invstd = p.invstd[c];
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
+    const T* __restrict__ xc = p.x + (long)c * p.S;
+    const T* __restrict__ gc = p.gy + (long)c * p.S;
+    float xh[NE], g[NE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * 256;
+        xh[k] = 0.f; g[k] = 0.f;
+        if (e < total) {
+            const int n = e / S, q = e - n * S;
+            const long i = (long)n * cstride + q;
+            xh[k] = (c2m_ld(xc, i) - mean) * invstd;
+            g[k] = c2m_ld(gc, i) * act_grad(xh[k] * ga + be, p.act, p.slope);
+            s1 += g[k]; s2 += g[k] * xh[k];
+        }
+    }
+    s1 = block_sum_256(s1, sm);
+    s2 = block_sum_256(s2, sm);
+    const double cnt = (double)total;
+    const float c1 = (float)((double)ga * (double)s1 / cnt), c2 = (float)((double)ga * (double)s2 / cnt);
+    if (threadIdx.x == 0) {
+        p.coef[c * 2 + 0] = c1; p.coef[c * 2 + 1] = c2;
+        if (p.dgamma) { p.dgamma[c] = s2; p.dbeta[c] = s1; }
+    }
+    T* __restrict__ dc = p.dx + (long)c * p.S;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < total) {
+            const int n = e / S, q = e - n * S;
+            c2m_st(dc, (long)n * cstride + q, invstd * (g[k] * ga - c1 - xh[k] * c2));
+        }
+    }
+}
+
 // workspace floats: N*C*chunks*2 (partials) + nstat*2 (coefficients)  <= c2m_norm_workspace_floats(N, C, S)
 // dx_nc8 (optional, bf16 tensors with S % 8 == 0 only): dx in the channel-blocked layout as well (see c2m_norm_apply).
 C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const float* invstd, const float* gamma,
@@ -799,6 +912,11 @@ C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const
         if (norm_fused_on && mode == 0 && !dgamma && !dx_nc8 && dx && vec && p.chunks == 1 &&
             (!gb || ((((uintptr_t)gb) | ((uintptr_t)ggb)) & C2mVec4<T>::mask) == 0)) {
             hipLaunchKernelGGL(norm_inst_bwd_fused_kernel<T>, dim3((unsigned)((long)N * C)), dim3(256), 0, s, p);
+            return (int)hipGetLastError();
+        }
+        if (norm_fused_on && mode == 1 && !gb && !dx_nc8 && dx && (long)N * S <= 8192) {
+            if ((long)N * S <= 2048) hipLaunchKernelGGL((norm_bn_small_bwd_fused_kernel<T, 8>), dim3((unsigned)C), dim3(256), 0, s, p);
+            else                     hipLaunchKernelGGL((norm_bn_small_bwd_fused_kernel<T, 32>), dim3((unsigned)C), dim3(256), 0, s, p);
             return (int)hipGetLastError();
         }
         hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3((unsigned)((long)N * C * p.chunks)), dim3(256), 0, s, p);

@@ -544,6 +544,43 @@ def test_instance_norm_one_launch_kernels(shape, kind):
             close(a, b.cpu(), 1e-4, 1e-5, "one-launch vs three-launch path")
 
 
+@pytest.mark.parametrize("shape", [(40, 6, 4, 8), (40, 5, 16, 32), (8, 7, 5, 8, 16), (24, 9), (3, 4, 50, 50), (40, 3, 8, 16)])
+@pytest.mark.parametrize("act", ["lrelu", "relu"])
+def test_batch_norm_small_volume_one_launch(shape, act):
+    """Round 5: batch norm of a small channel volume (N * S <= 32768 elements per channel forward, <= 8192 backward -- the deep
+    encoder / bottleneck levels) runs as ONE launch per direction (norm_bn_small_fused_kernel / _bwd_): against torch on the CPU
+    and against the three-launch path of the same library (different summation order: within rounding), running statistics too."""
+    from c2m_amd import _lib
+    x = rnd(21, *shape) * 1.5 + 2.0
+    C = shape[1]
+    gam, bet = 1 + 0.1 * rnd(22, C), 0.1 * rnd(23, C)
+    rm, rv = 0.1 * rnd(24, C), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(25))
+    go = rnd(26, *shape)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    yr = F.leaky_relu(yr, 0.2) if act == "lrelu" else F.relu(yr)
+    (yr * go).sum().backward()
+
+    def run():
+        xg, gg, bg = (g(t).requires_grad_(True) for t in (x, gam, bet))
+        rmg, rvg = g(rm), g(rv)
+        y = ops.batch_norm_act(xg, gg, bg, rmg, rvg, act)
+        (y * g(go)).sum().backward()
+        return [y.detach(), xg.grad, gg.grad, bg.grad, rmg, rvg]
+    fused = run()
+    old = _lib.lib().c2m_norm_set_fused(0)
+    try:
+        three = run()
+    finally:
+        _lib.lib().c2m_norm_set_fused(old)
+    for a, ref, tol, what in zip(fused, (yr, xr.grad, gr.grad, br.grad, rmr, rvr), (1e-4, 1e-3, 1e-4, 1e-4, 1e-5, 1e-4),
+                                 ("fwd", "dx", "dgamma", "dbeta", "running_mean", "running_var")):
+        close(a, ref, tol, 1e-4 if what in ("dgamma", "dbeta") else 1e-5, f"one-launch bn {what}")
+    for a, b, what in zip(fused, three, ("fwd", "dx", "dgamma", "dbeta", "running_mean", "running_var")):
+        close(a, b.cpu(), 1e-4, 1e-4 if what in ("dx", "dgamma", "dbeta") else 1e-5, f"one-launch vs three-launch bn {what}")
+
+
 # ----------------------------------------------------------------------------------------------- warping / resampling
 @pytest.mark.parametrize("name", names("op_resample"))
 def test_flow_warp_golden(name):

@@ -10,7 +10,7 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 x = torch.randn(N, Cin, H, W, device="cuda:0"); w = torch.randn(Cout, Cin, 3, 3, device="cuda:0") / (Cin * 9) ** 0.5
 b = torch.zeros(Cout, device="cuda:0"); y = torch.empty(N, Cout, H, W, device="cuda:0")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-g = np.zeros(34, dtype=np.int64)
+g = np.zeros(_lib.WINO_GEOM.LEN, dtype=np.int64)      # include/c2m_geom.h: C2M_WG_LEN (a shorter block would hand the kernel a garbage ring pointer)
 g[:18] = [Cout, Cin, N, H, W, H, W, -1, -1, 0, Cin * H * W, H * W, W, Cout * H * W, H * W, W, 0, 4 * N * Cin * H * W]
 L.c2m_wino4_upack_floats.restype = ctypes.c_long
 U = torch.empty(L.c2m_wino4_upack_floats(Cout, Cin), device="cuda:0")
