@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256) void norm_inst_fused_kernel(const ApplyP<T> p,
     }
 }
 
-// Batch norm (mode 1) of SMALL channel volumes in one launch (round 5): the deep encoder / bottleneck levels (16x32 maps and
-// below, 40 folded frames: N * S <= 32768 elements per channel) ran partial + finalize + apply as three launches of a few
+// Batch norm (mode 1) of SMALL channel volumes in one launch (round 5): the deep encoder levels (8x16 maps and
+// below, 40 folded frames: N * S <= 8192 elements per channel) ran partial + finalize + apply as three launches of a few
 // microseconds each.  One workgroup owns a channel: its N planes are walked as ONE index range (coalesced inside a plane), kept in
 // registers (NE elements per thread), two-pass statistics (mean, then centred squares: cancellation-safe like the chunked path),
 // running-statistics update, apply.  Same for the backward up to 8192 elements per channel (x-hat and g' in registers).
@@ -425,6 +425,9 @@ __global__ __launch_bounds__(256) void norm_bn_small_fused_kernel(const ApplyP<T
     const int c = blockIdx.x;
     const int S = (int)p.S, total = p.N * S;
     const long cstride = (long)p.C * p.S;                   // from plane (n, c) to plane (n + 1, c)
+    // e / S by multiply-high (exact for e < 2^32 / S: e, S <= 32768): a hardware integer division is ~35 VALU instructions, and
+    // 3 x NE of them per thread made the first form of this kernel slower than the three launches it replaces
+    const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)S - 1) / (unsigned)S);
     const T* __restrict__ xc = p.x + (long)c * p.S;
     float keep[NE];
     float s = 0.f;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void norm_bn_small_fused_kernel(const ApplyP<T
         const int e = threadIdx.x + k * 256;
         keep[k] = 0.f;
         if (e < total) {
-            const int n = e / S, q = e - n * S;
+            const int n = S == 1 ? e : (int)__umulhi((unsigned)e, magic), q = e - n * S;
             keep[k] = c2m_ld(xc, (long)n * cstride + q);
             s += keep[k];
         }
@@ -463,15 +466,16 @@ __global__ __launch_bounds__(256) void norm_bn_small_fused_kernel(const ApplyP<T
     for (int k = 0; k < NE; ++k) {
         const int e = threadIdx.x + k * 256;
         if (e < total) {
-            const int n = e / S, q = e - n * S;
+            const int n = S == 1 ? e : (int)__umulhi((unsigned)e, magic), q = e - n * S;
             c2m_st(yc, (long)n * cstride + q, c2m_act((keep[k] - mean) * invstd * ga + be, p.act, p.slope));
         }
     }
 }
 
-static int norm_fused_on = [] { const char* e = getenv("C2M_NORM_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();      // A/B knob
-// tests / A/B runs: 0 = every norm on the three-launch path, 1 = the one-launch instance-norm kernels where eligible; returns the old value
-C2M_API int c2m_norm_set_fused(int on) { const int old = norm_fused_on; norm_fused_on = on ? 1 : 0; return old; }
+// A/B knob, bit mask: 1 = one-launch instance norm, 2 = one-launch small batch norm (C2M_NORM_FUSED=0 / 1 / 2 / 3; default 3)
+static int norm_fused_on = [] { const char* e = getenv("C2M_NORM_FUSED"); return e ? atoi(e) & 3 : 3; }();
+// tests / A/B runs: 0 = every norm on the three-launch path; returns the old mask
+C2M_API int c2m_norm_set_fused(int mask) { const int old = norm_fused_on; norm_fused_on = mask & 3; return old; }
 
 // Statistics + apply in one call (c2m_norm_stats followed by c2m_norm_apply, without the NC8 side output): instance-norm planes of
 // 1024 ... 32768 elements take the one-launch kernel above, everything else the three launches.
@@ -480,7 +484,7 @@ C2M_API int c2m_norm_fwd(const void* x, float* mean, float* invstd, float* runni
                          float eps, float momentum, int act, float slope, int dt, void* stream) {
     C2M_ENTER();
     if ((long)N * C * S <= 0) return 0;
-    if (norm_fused_on && mode == 0 && S <= 32768 && norm_vec_ok(S, x, y, gb, nullptr, dt)) {
+    if ((norm_fused_on & 1) && mode == 0 && S <= 32768 && norm_vec_ok(S, x, y, gb, nullptr, dt)) {
         C2M_DISPATCH_DT(dt,
             ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, (const T*)gb, (T*)y, N, C, S, mode, act, slope};
             if (S <= 8192)
@@ -489,16 +493,16 @@ C2M_API int c2m_norm_fwd(const void* x, float* mean, float* invstd, float* runni
                 hipLaunchKernelGGL((norm_inst_fused_kernel<T, 32>), dim3((unsigned)((long)N * C)), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, eps););
         return (int)hipGetLastError();
     }
-    if (norm_fused_on && mode == 1 && !gb && (long)N * S <= 32768) {
+    // (<= 8192 elements per channel: a 128-elements-per-thread variant for the 16 x 32 maps -- 20480 per channel, C workgroups --
+    // measured 47 us against ~30 for the three launches it replaced, profiles/r05_norm_one_launch_kernel_times.txt)
+    if ((norm_fused_on & 2) && mode == 1 && !gb && (long)N * S <= 8192) {
         const long tot = (long)N * S;
         C2M_DISPATCH_DT(dt,
             ApplyP<T> p{(const T*)x, mean, invstd, gamma, beta, nullptr, (T*)y, N, C, S, mode, act, slope};
             if (tot <= 2048)
                 hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 8>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum);
-            else if (tot <= 8192)
-                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 32>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum);
             else
-                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 128>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum););
+                hipLaunchKernelGGL((norm_bn_small_fused_kernel<T, 32>), dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, p, mean, invstd, running_mean, running_var, eps, momentum););
         return (int)hipGetLastError();
     }
     const int rc = c2m_norm_stats(x, mean, invstd, running_mean, running_var, workspace, N, C, S, mode, eps, momentum, dt, stream);
@@ -853,6 +857,7 @@ __global__ __launch_bounds__(256) void norm_bn_small_bwd_fused_kernel(const BwdP
     const int c = blockIdx.x;
     const int S = (int)p.S, total = p.N * S;
     const long cstride = (long)p.C * p.S;
+    const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)S - 1) / (unsigned)S);      // e / S by multiply-high (see the forward kernel)
     const float mean = p.mean[c], invstd = p.invstd[c];
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.gamma ? p.beta[c] : 0.f;
     const T* __restrict__ xc = p.x + (long)c * p.S;
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(256) void norm_bn_small_bwd_fused_kernel(const BwdP
         const int e = threadIdx.x + k * 256;
         xh[k] = 0.f; g[k] = 0.f;
         if (e < total) {
-            const int n = e / S, q = e - n * S;
+            const int n = S == 1 ? e : (int)__umulhi((unsigned)e, magic), q = e - n * S;
             const long i = (long)n * cstride + q;
             xh[k] = (c2m_ld(xc, i) - mean) * invstd;
             g[k] = c2m_ld(gc, i) * act_grad(xh[k] * ga + be, p.act, p.slope);
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256) void norm_bn_small_bwd_fused_kernel(const BwdP
     for (int k = 0; k < NE; ++k) {
         const int e = threadIdx.x + k * 256;
         if (e < total) {
-            const int n = e / S, q = e - n * S;
+            const int n = S == 1 ? e : (int)__umulhi((unsigned)e, magic), q = e - n * S;
             c2m_st(dc, (long)n * cstride + q, invstd * (g[k] * ga - c1 - xh[k] * c2));
         }
     }
@@ -909,12 +914,12 @@ C2M_API int c2m_norm_bwd(const void* x, const void* gy, const float* mean, const
         p.coef = workspace + (long)N * C * p.chunks * 2;
         p.dgamma = dgamma; p.dbeta = dbeta; p.dx = (T*)dx;
         p.N = N; p.C = C; p.S = S; p.mode = mode; p.act = act; p.slope = slope;
-        if (norm_fused_on && mode == 0 && !dgamma && !dx_nc8 && dx && vec && p.chunks == 1 &&
+        if ((norm_fused_on & 1) && mode == 0 && !dgamma && !dx_nc8 && dx && vec && p.chunks == 1 &&
             (!gb || ((((uintptr_t)gb) | ((uintptr_t)ggb)) & C2mVec4<T>::mask) == 0)) {
             hipLaunchKernelGGL(norm_inst_bwd_fused_kernel<T>, dim3((unsigned)((long)N * C)), dim3(256), 0, s, p);
             return (int)hipGetLastError();
         }
-        if (norm_fused_on && mode == 1 && !gb && !dx_nc8 && dx && (long)N * S <= 8192) {
+        if ((norm_fused_on & 2) && mode == 1 && !gb && !dx_nc8 && dx && (long)N * S <= 8192) {
             if ((long)N * S <= 2048) hipLaunchKernelGGL((norm_bn_small_bwd_fused_kernel<T, 8>), dim3((unsigned)C), dim3(256), 0, s, p);
             else                     hipLaunchKernelGGL((norm_bn_small_bwd_fused_kernel<T, 32>), dim3((unsigned)C), dim3(256), 0, s, p);
             return (int)hipGetLastError();

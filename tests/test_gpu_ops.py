@@ -547,8 +547,8 @@ def test_instance_norm_one_launch_kernels(shape, kind):
 @pytest.mark.parametrize("shape", [(40, 6, 4, 8), (40, 5, 16, 32), (8, 7, 5, 8, 16), (24, 9), (3, 4, 50, 50), (40, 3, 8, 16)])
 @pytest.mark.parametrize("act", ["lrelu", "relu"])
 def test_batch_norm_small_volume_one_launch(shape, act):
-    """Round 5: batch norm of a small channel volume (N * S <= 32768 elements per channel forward, <= 8192 backward -- the deep
-    encoder / bottleneck levels) runs as ONE launch per direction (norm_bn_small_fused_kernel / _bwd_): against torch on the CPU
+    """Round 5: batch norm of a small channel volume (N * S <= 8192 elements per channel -- the deep encoder levels; the larger
+    shapes of the list stay on the three-launch path) runs as ONE launch per direction (norm_bn_small_fused_kernel / _bwd_): against torch on the CPU
     and against the three-launch path of the same library (different summation order: within rounding), running statistics too."""
     from c2m_amd import _lib
     x = rnd(21, *shape) * 1.5 + 2.0
