@@ -12,6 +12,17 @@ from c2m_amd import ops
 from gpu_util import rel_close, rnd
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _three_launch_norms():
+    """The tests of this file compare hand-over MODES (NCHW tensors against NC8-only tensors) bit for bit.  The NCHW hand-over is
+    eligible for the one-launch norm kernels of round 5 (another summation order than the three-launch path, which is the only one
+    that can write an NC8-only result): bit-identity is a statement about the LAYOUT, so every mode runs the same norm here."""
+    from c2m_amd import _lib
+    old = _lib.lib().c2m_norm_set_fused(0)
+    yield
+    _lib.lib().c2m_norm_set_fused(old)
 DEV = "cuda:0"
 
 
