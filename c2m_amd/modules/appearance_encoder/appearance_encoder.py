@@ -55,14 +55,19 @@ class AppearanceEncoder(nn.Module):
         for i, blk in enumerate(self.down_blocks):
             x = blk(x)
             out["app_encoded" if i == last else f"enco{i}"] = x
-        boxes = torch.cat([gnn.batch.unsqueeze(1).repeat_interleave(t_in, dim=0),
-                           torch.cat(torch.unbind(gnn.source_frames_nodes_roi_padded, dim=1), dim=0)], dim=1)
-        pooled_src = torch.cat(out[f"enco{self.pooling_after - 1}"].chunk(t_in, 1), dim=0)
-        obj = ops.roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
-        obj = self.roi_align_regressor(self.roi_align_blocks(obj))
-        # == torch.repeat_interleave(app_encoded.flatten(1), gnn.num_real_nodes * t_in, dim=0) of the reference (:63) for
-        # the sorted per-node batch vector, without the host sync a tensor of repeat counts costs (HIP-graph capturable)
-        scene = out["app_encoded"].flatten(1).index_select(0, gnn.batch.repeat_interleave(t_in))
-        fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))
-        out["objects_feature"] = torch.cat(fused.unsqueeze(1).chunk(t_in, 0), 1)
+        # the RoI head -- a dozen small launches whose only consumer is the object GNN -- goes to the auxiliary stream in training
+        # (ops.aux_branch: it runs next to the motion encoders' convolutions; the GNN continues on that stream, the model joins it in
+        # front of the losses or the raster)
+        feat, enc = out[f"enco{self.pooling_after - 1}"], out["app_encoded"]
+        with ops.aux_branch(*((feat, enc) if self.training and torch.is_grad_enabled() else ()), part="roi"):
+            boxes = torch.cat([gnn.batch.unsqueeze(1).repeat_interleave(t_in, dim=0),
+                               torch.cat(torch.unbind(gnn.source_frames_nodes_roi_padded, dim=1), dim=0)], dim=1)
+            pooled_src = torch.cat(feat.chunk(t_in, 1), dim=0)
+            obj = ops.roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
+            obj = self.roi_align_regressor(self.roi_align_blocks(obj))
+            # == torch.repeat_interleave(app_encoded.flatten(1), gnn.num_real_nodes * t_in, dim=0) of the reference (:63) for
+            # the sorted per-node batch vector, without the host sync a tensor of repeat counts costs (HIP-graph capturable)
+            scene = enc.flatten(1).index_select(0, gnn.batch.repeat_interleave(t_in))
+            fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))
+            out["objects_feature"] = torch.cat(fused.unsqueeze(1).chunk(t_in, 0), 1)
         return out

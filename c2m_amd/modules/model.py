@@ -173,6 +173,7 @@ class GeneratorFullModel(nn.Module):
         out = {}
         out.update(self.motion_encoder(app, motion_input))
         out = self._generate(v, out)
+        ops.aux_join(*[t for k, t in out.items() if k.startswith("theta_")])      # the object branch (ops.aux_branch) meets the main stream
         loss_dict = self.objective_func(data_batch["video"], v["frames"], target_bw_of, target_fw_of, target_bw_occ,
                                         target_fw_occ, out, gnn)
         loss_d_image, loss_d_video = {}, {}

@@ -131,8 +131,14 @@ class DenseMotionNetwork(nn.Module):
         out = {"mu": torch.cat([bg_out["mu"], fg_out["mu"]], 1),
                "logvar": torch.cat([bg_out["logvar"], fg_out["logvar"]], 1)}
         z_m = self.reparameterize(out["mu"], out["logvar"], model_input.get("eps"))
-        thetas = self.sparse_motion_estimator(model_input["tracking_gnn"], app_features["objects_feature"],
-                                              model_input["latent"], model_input.get("click_index"))
+        # object GNN on the auxiliary stream (ops.aux_branch): with gt thetas its outputs feed only the theta losses, so it runs next
+        # to the encoders / decoder / generator and is joined in front of the losses (GeneratorFullModel._forward); with predicted
+        # thetas the raster below needs them: joined here
+        with ops.aux_branch(*((app_features["objects_feature"], model_input["latent"]) if self.training and torch.is_grad_enabled() else ()), part="gnn"):
+            thetas = self.sparse_motion_estimator(model_input["tracking_gnn"], app_features["objects_feature"],
+                                                  model_input["latent"], model_input.get("click_index"))
+        if not tp["use_gt_training"]:
+            ops.aux_join(*thetas.values())
         out.update(thetas)
         sparse, fw = self.generate_sparse_motion(model_input["tracking_gnn"], thetas,
                                                  model_input["instance"][:, :, t_in - 1].to(frames.dtype),

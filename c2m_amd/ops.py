@@ -211,6 +211,72 @@ def _side_stream(device):
     return s
 
 
+# ---- auxiliary stream for the object branch (round 5).  The RoI head of the appearance encoder and the object GNN are ~600 launches
+# of a few microseconds on [24, 1024]-sized tensors per step (Linear layers, GATv2 attention, theta losses): ~4 ms of GPU time that
+# uses a sliver of the chip and, with gt thetas (use_gt_training: True), feeds nothing but the theta losses.  Run on a second stream
+# they execute NEXT TO the convolutions of the motion encoders / decoder / generator instead of between them -- forward, and
+# backward too: autograd runs every backward node on the stream of its forward and orders the streams itself.  No arithmetic
+# changes; every kernel pairing is one the concurrency stress test covers.  C2M_AUX_STREAM=0 switches it off (A/B).
+_AUX = os.environ.get("C2M_AUX_STREAM", "1")          # 1 | 0 | roi | gnn (one part only: diagnosis)
+_aux_streams = {}
+_aux_open = {}           # device index -> the aux stream has work the main stream has not joined yet
+
+
+class aux_branch:
+    """`with ops.aux_branch(*input_tensors): ...` -- the body's launches go to the device's auxiliary stream, ordered behind
+    everything the current stream has been given so far.  The results may only be used on the main stream after `aux_join`."""
+
+    def __init__(self, *inputs, part=""):
+        self.inputs = [t for t in inputs if torch.is_tensor(t) and t.is_cuda]
+        self.ctx = None
+        self.on = _AUX == "1" or _AUX == part
+
+    def __enter__(self):
+        if not self.on or not self.inputs:
+            if self.inputs:
+                aux_join(*self.inputs)            # (diagnosis mode, an earlier part on the aux stream: this one reads its results)
+            return self
+        dev = self.inputs[0].device
+        aux = _aux_streams.get(dev.index)
+        if aux is None:
+            aux = _aux_streams[dev.index] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        if aux == main:
+            return self
+        aux.wait_stream(main)                     # (a second block of the same branch: aux order kept, the new dependencies added)
+        for t in self.inputs:
+            t.record_stream(aux)                  # allocated on the main stream's pool, read by aux-stream kernels
+        _aux_open[dev.index] = True
+        self.ctx = torch.cuda.stream(aux)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _on_aux_stream(dev):
+    aux = _aux_streams.get(dev.index)
+    return aux is not None and torch.cuda.current_stream(dev) == aux
+
+
+def aux_join(*outputs):
+    """The current stream waits for the auxiliary stream's work; `outputs` (tensors made on it) may be used from here on."""
+    for dev_index, is_open in list(_aux_open.items()):
+        if not is_open:
+            continue
+        aux = _aux_streams[dev_index]
+        main = torch.cuda.current_stream(aux.device)
+        if aux != main:
+            main.wait_stream(aux)
+            for t in outputs:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+        _aux_open[dev_index] = False
+
+
 def _timed(kind, flops, fn, tag=(), nbytes=0):
     prof = ConvProfiler.active
     if prof is None:
@@ -1583,7 +1649,9 @@ class _ConvFn(torch.autograd.Function):
         # behind MFMA kernels.  Fork / join are events, so a HIP-graph capture records the same parallel branches.
         # (inside a capture for both precisions: fp32 configs[1] as a replay 66.6 -> 66.1 ms on one box, `bench.py --graph`)
         side_on = _WGRAD_SIDE == "1" or (_WGRAD_SIDE == "auto" and torch.cuda.is_current_stream_capturing())
-        side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0]) else None
+        # (not from the auxiliary stream of the object branch: its one small convolution gains nothing, and a side stream that two
+        # captured streams fork into and join from takes capture_end down on ROCm 7.2 -- tools/aux_capture_probe.py)
+        side = _side_stream(x.device) if (side_on and need_w and ctx.needs_input_grad[0] and not _on_aux_stream(x.device)) else None
         # NC8 form of dY: one layout pass shared by the data gradient and the weight gradient of this node (made on the main
         # stream BEFORE a fork, so the side stream's launch is ordered behind it)
         keep = {} if (pl.bf16 and (pl.nc8 or pl.k333_wgrad_nc8 or pl.k333_dgrad_nc8)) else None
