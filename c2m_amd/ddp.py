@@ -26,6 +26,8 @@ On CPU tensors (gloo, used by the tests) the same logic runs synchronously.
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 class _Bucket:
     def __init__(self, params, device, comm_dtype):
@@ -75,6 +77,7 @@ class GradientReducer:
         self.comm_dtype = comm_dtype
         self.device = uniq[0].device
         self.on_gpu = self.device.type == "cuda"
+        self._main = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(uniq):                      # gradients become ready roughly in reverse creation order
@@ -139,6 +142,7 @@ class GradientReducer:
         self.armed = True
         self.fired_final.clear()
         self._fire_seq = []
+        self._main = torch.cuda.current_stream(self.device) if self.on_gpu else None    # the stream backward() is called on
         if self.measure and self.collectives:         # time base of the per-bucket exposure (always before every bucket event)
             self._base_ev = torch.cuda.Event(enable_timing=True)
             self._base_ev.record(torch.cuda.current_stream(self.device))
@@ -202,7 +206,13 @@ class GradientReducer:
         if not self.collectives:
             return
         if self.on_gpu:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            # the bucket's gradients were accumulated by backward nodes on the stream of THIS hook -- and, for parameters of the
+            # object branch, on its auxiliary stream (ops.aux_branch: AccumulateGrad runs where the parameter was used): wait for all
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            for s in [self._main] + ops.branch_streams(self.device):
+                if s is not None and s != cur:
+                    self.stream.wait_stream(s)
             with torch.cuda.stream(self.stream):
                 b.work = self._collective(b)
                 if b.comm is not None:           # stream-ordered behind the collective on the side stream

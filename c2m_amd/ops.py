@@ -4,6 +4,7 @@ PyTorch is used for device memory, streams and autograd bookkeeping only; every 
 gfx950 kernels from libc2m_hip.so on torch's current HIP stream.  There is no CPU or eager fallback: a tensor that is
 not on a HIP device raises (the oracle in oracle/ is test infrastructure and is never imported from here).
 """
+import collections
 import ctypes
 import os
 import weakref
@@ -255,6 +256,61 @@ class aux_branch:
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
         return False
+
+
+# ---- deferred weight gradients (round 5): see _ConvFn.backward
+_DEFER_WGRAD = os.environ.get("C2M_DEFER_WGRAD", "1") != "0"
+_defer = {"on": False, "devs": set(), "seen": set(), "hold": collections.deque()}
+
+
+class deferred_wgrads:
+    """`with ops.deferred_wgrads(): loss.backward()` -- weight gradients of the convolutions are computed on the side stream and
+    joined once, when the block exits (on the stream that is current then).  Parameter gradients must not be read inside the block."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and _DEFER_WGRAD
+
+    def __enter__(self):
+        _defer["on"] = self.enabled
+        _defer["seen"].clear()
+        return self
+
+    def __exit__(self, *exc):
+        _defer["on"] = False
+        for idx in _defer["devs"]:
+            side = _side_streams[idx]
+            torch.cuda.current_stream(side.device).wait_stream(side)
+        _defer["devs"].clear()
+        _defer["hold"].clear()            # (the joined stream orders every later write behind the side stream's reads)
+        return False
+
+
+def _record_stream_all(stream, *objs):
+    """Every device tensor in objs (tensors, NC8 placeholders and their forms, dicts / tuples of them) is in use on `stream`."""
+    for o in objs:
+        if o is None:
+            continue
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                o.record_stream(stream)
+                form = getattr(o, "_c2m_nc8", None)               # (version, NC8 form) riding on the tensor object
+                if form is not None and torch.is_tensor(form[1]):
+                    form[1].record_stream(stream)
+                ent = _nc8_only.get(o.data_ptr()) if getattr(o, "_c2m_nc8_only", False) else None
+                if ent is not None and torch.is_tensor(ent[2]):
+                    ent[2].record_stream(stream)
+        elif isinstance(o, dict):
+            _record_stream_all(stream, *o.values())
+        elif isinstance(o, (tuple, list)):
+            _record_stream_all(stream, *o)
+
+
+def branch_streams(device):
+    """The streams -- besides the one backward() is called on -- that backward nodes of this package run on (the object branch's
+    auxiliary stream, the weight-gradient side stream).  Whoever consumes gradients from ANOTHER stream before backward() has
+    returned (the gradient reducer's communication stream) has to wait for these as well."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [s for s in (_aux_streams.get(idx), _side_streams.get(idx)) if s is not None]
 
 
 def _on_aux_stream(dev):
@@ -1658,6 +1714,48 @@ class _ConvFn(torch.autograd.Function):
         if keep is not None and need_w and (pl.wgrad_nc8 or pl.s2_wgrad_nc8 or pl.k333_wgrad_nc8):
             gy = _as(gy, BF16)
             _to_nc8(gy, keep)
+        if need_w and _defer["on"]:
+            # `with ops.deferred_wgrads():` around backward (TrainStep): the weight gradient of a leaf weight that has no gradient
+            # yet goes to the side stream and is NOT joined here -- nothing reads it before the optimizer (AccumulateGrad adopts the
+            # tensor, no kernel) -- so its split reductions and its tail run under the data-gradient chain of the layers below.
+            # The context's exit joins.  A weight that already has a gradient (a second backward) would be summed by a kernel on
+            # this stream: it joins first and takes the ordinary path.  Limit of the scheme: a convolution weight that ALSO feeds a
+            # non-convolution op in the same graph (none in this model) has the two gradients summed without that join -- run such a
+            # model with C2M_DEFER_WGRAD=0.
+            # (a weight applied twice in one graph -- the sparse-feature encoder with use_fw_of -- has its two gradients summed by
+            # the engine before AccumulateGrad runs, on this stream: the second one joins as well)
+            first_use = w.data_ptr() not in _defer["seen"]
+            _defer["seen"].add(w.data_ptr())
+            if first_use and w.is_leaf and w.grad is None and ConvProfiler.active is None and not _on_aux_stream(x.device):
+                main = torch.cuda.current_stream(x.device)
+                dside = _side_stream(x.device)
+                dside.wait_stream(main)
+                _record_stream_all(dside, x, gy, keep, ctx.nc8_keep)    # freed by autograd right after this node; still being read
+                with torch.cuda.stream(dside):
+                    gw, gb = _ConvFn._wgrad(ctx, pl, x, w, gy, keep)
+                for t in (gw, gb):
+                    if t is not None:
+                        t.record_stream(main)
+                _defer["devs"].add(x.device.index)
+                # dY may be shared with the identity path of a residual block (AddBackward hands ONE tensor to both branches): the
+                # engine sums the other branch's gradient into it IN PLACE once nobody else holds it -- while the side stream still
+                # reads it (found by test_branch_streams_do_not_change_a_step: conv2 of the residual blocks).  A second owner makes
+                # that sum out of place; the reference is dropped when the side stream has passed this launch.
+                # (inside a HIP-graph capture events cannot be queried: held until the join)
+                hold = _defer["hold"]
+                if torch.cuda.is_current_stream_capturing():
+                    hold.append((None, gy))
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record(dside)
+                    hold.append((ev, gy))
+                    while hold and hold[0][0] is not None and hold[0][0].query():
+                        hold.popleft()
+                if ctx.needs_input_grad[0]:
+                    gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype, keep)
+                return gx, gw, gb, None, None, None, None, None, None
+            if x.device.index in _defer["devs"]:
+                torch.cuda.current_stream(x.device).wait_stream(_side_stream(x.device))
         if side is not None:
             main = torch.cuda.current_stream(x.device)
             side.wait_stream(main)

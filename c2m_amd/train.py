@@ -192,7 +192,10 @@ class TrainStep:
             losses_d["total_video_dis"].backward()
         if self.reducer is not None and not in_capture:
             self.reducer.arm()
-        total.backward()
+        # weight gradients on the side stream, joined once after the backward (ops.deferred_wgrads); with the gradient reducer the
+        # gradients are summed into the flat buckets by kernels on the backward's stream as they appear: not deferred there
+        with ops.deferred_wgrads(enabled=self.reducer is None):
+            total.backward()
         if self.reducer is not None and not in_capture:
             self.reducer.finish()
         if self.run_optimizers:

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from c2m_amd import ops
 from c2m_amd.optim import Adam
 from c2m_amd.config import default_config, normalize_config
 from c2m_amd.modules.model import GeneratorFullModel
@@ -491,6 +492,47 @@ def test_config4_rank_shard():
     finally:
         ops._chunks_for_2gib = orig
     assert max(chunked) >= 2, "configs[4]'s shard must exercise the >= 2 GiB batch-chunk path"
+
+
+@pytest.mark.parametrize("use_fw_of", [False, True])
+def test_branch_streams_do_not_change_a_step(use_fw_of, monkeypatch):
+    """Round 5: the object branch (RoI head + GNN) on the auxiliary stream and the weight gradients deferred to the side stream
+    (ops.aux_branch / ops.deferred_wgrads) are scheduling only.  Four full steps with optimizers -- both discriminators (spectral
+    norm: non-leaf weights, gradients from separate backward() calls), with use_fw_of the sparse-feature encoder applied twice (its
+    second weight gradient is summed into the first: the joining path) -- give bit-identical losses, gradients and weights with
+    both switched off and on; memory handed back to the allocator while the other stream still reads it would show up here."""
+    cfg = _tiny_cfg()
+    cfg["train_params"]["use_fw_of"] = use_fw_of
+    tp = cfg["train_params"]
+
+    def run(aux, defer):
+        monkeypatch.setattr(ops, "_AUX", aux)
+        monkeypatch.setattr(ops, "_DEFER_WGRAD", defer)
+        torch.manual_seed(0)
+        model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
+                                   dataset="cityscapes").to(DEV).train()
+        step = TrainStep(model, run_optimizers=True, distributed=False)
+        totals, grads = [], None
+        for it in range(4):
+            batch = batch_to(make_batch(2, 128, 256, 2, seed=60 + it, use_fw_of=use_fw_of), DEV)
+            rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=it)
+            batch["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+            _, lg, _ = step(batch)
+            totals.append(float(lg["total_gen"].detach()))
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        return totals, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    t0, g0, w0 = run("0", False)
+    t1, g1, w1 = run("1", True)
+    assert t0 == t1, f"losses differ: {t0} vs {t1}"
+    assert g0.keys() == g1.keys()
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, f"gradients differ with the branch streams on: {bad[:5]}"
+    bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert not bad, f"weights differ after 4 steps: {bad[:5]}"
+    assert ops._side_streams and ops._aux_streams, "the second run must really have used both streams"
 
 
 def test_hip_graph_replay_matches_eager_steps():
