@@ -162,6 +162,9 @@ class GeneratorFullModel(nn.Module):
         target_bw_occ = U.resize_video(data_batch.get("target_bw_occ"), sf, mode="bilinear")
         target_fw_of = U.resize_video(data_batch.get("target_fw_of"), sf, mode="bilinear", is_flow=True)
         target_fw_occ = U.resize_video(data_batch.get("target_fw_occ"), sf, mode="bilinear")
+        pl = getattr(self.objective_func, "perceptual_loss", None)
+        if pl is not None:
+            pl.prefetch(v["frames"][:, :, t_in:])          # ground-truth VGG features: auxiliary stream, joined before the losses
         gnn = data_batch["tracking_gnn"]
         rng = data_batch.get("rng") or {}
         latent = rng["latent_traj"] if "latent_traj" in rng else self._draw_latent(gnn, gnn.x.device)
@@ -173,7 +176,8 @@ class GeneratorFullModel(nn.Module):
         out = {}
         out.update(self.motion_encoder(app, motion_input))
         out = self._generate(v, out)
-        ops.aux_join(*[t for k, t in out.items() if k.startswith("theta_")])      # the object branch (ops.aux_branch) meets the main stream
+        # the object branch and the ground-truth VGG pass (ops.aux_branch) meet the main stream
+        ops.aux_join(*[t for k, t in out.items() if k.startswith("theta_")], *(pl.prefetched_tensors() if pl is not None else []))
         loss_dict = self.objective_func(data_batch["video"], v["frames"], target_bw_of, target_fw_of, target_bw_occ,
                                         target_fw_occ, out, gnn)
         loss_d_image, loss_d_video = {}, {}

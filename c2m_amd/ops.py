@@ -218,36 +218,39 @@ def _side_stream(device):
 # they execute NEXT TO the convolutions of the motion encoders / decoder / generator instead of between them -- forward, and
 # backward too: autograd runs every backward node on the stream of its forward and orders the streams itself.  No arithmetic
 # changes; every kernel pairing is one the concurrency stress test covers.  C2M_AUX_STREAM=0 switches it off (A/B).
-_AUX = os.environ.get("C2M_AUX_STREAM", "1")          # 1 | 0 | roi | gnn (one part only: diagnosis)
-_aux_streams = {}
-_aux_open = {}           # device index -> the aux stream has work the main stream has not joined yet
+_AUX = os.environ.get("C2M_AUX_STREAM", "1")          # 1 | 0 | obj (= roi + gnn) | novgg | roi | gnn | vgg (parts: diagnosis, A/B)
+_aux_streams = {}        # (device index, lane) -> stream.  Lane 0: the object branch; lane 1: the ground-truth VGG pass (losses.py)
+_aux_open = {}           # (device index, lane) -> the lane has work the main stream has not joined yet
 
 
 class aux_branch:
-    """`with ops.aux_branch(*input_tensors): ...` -- the body's launches go to the device's auxiliary stream, ordered behind
+    """`with ops.aux_branch(*input_tensors): ...` -- the body's launches go to an auxiliary stream of the device, ordered behind
     everything the current stream has been given so far.  The results may only be used on the main stream after `aux_join`."""
 
-    def __init__(self, *inputs, part=""):
+    def __init__(self, *inputs, part="", lane=0):
         self.inputs = [t for t in inputs if torch.is_tensor(t) and t.is_cuda]
         self.ctx = None
-        self.on = _AUX == "1" or _AUX == part
+        self.lane = lane
+        self.on = _AUX == "1" or _AUX == part or (_AUX == "obj" and part in ("roi", "gnn")) or \
+            (_AUX.startswith("no") and _AUX[2:] != part)
 
     def __enter__(self):
         if not self.on or not self.inputs:
             if self.inputs:
-                aux_join(*self.inputs)            # (diagnosis mode, an earlier part on the aux stream: this one reads its results)
+                aux_join(*self.inputs, lanes=(self.lane,))    # (diagnosis mode, an earlier part on this lane: this one reads its results)
             return self
         dev = self.inputs[0].device
-        aux = _aux_streams.get(dev.index)
+        key = (dev.index, self.lane)
+        aux = _aux_streams.get(key)
         if aux is None:
-            aux = _aux_streams[dev.index] = torch.cuda.Stream(device=dev)
+            aux = _aux_streams[key] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         if aux == main:
             return self
         aux.wait_stream(main)                     # (a second block of the same branch: aux order kept, the new dependencies added)
         for t in self.inputs:
             t.record_stream(aux)                  # allocated on the main stream's pool, read by aux-stream kernels
-        _aux_open[dev.index] = True
+        _aux_open[key] = True
         self.ctx = torch.cuda.stream(aux)
         self.ctx.__enter__()
         return self
@@ -310,27 +313,31 @@ def branch_streams(device):
     auxiliary stream, the weight-gradient side stream).  Whoever consumes gradients from ANOTHER stream before backward() has
     returned (the gradient reducer's communication stream) has to wait for these as well."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    return [s for s in (_aux_streams.get(idx), _side_streams.get(idx)) if s is not None]
+    return [s for (i, _), s in _aux_streams.items() if i == idx] + ([_side_streams[idx]] if idx in _side_streams else [])
 
 
 def _on_aux_stream(dev):
-    aux = _aux_streams.get(dev.index)
-    return aux is not None and torch.cuda.current_stream(dev) == aux
+    cur = None
+    for (i, _), s in _aux_streams.items():
+        if i == dev.index:
+            cur = torch.cuda.current_stream(dev) if cur is None else cur
+            if s == cur:
+                return True
+    return False
 
 
-def aux_join(*outputs):
-    """The current stream waits for the auxiliary stream's work; `outputs` (tensors made on it) may be used from here on."""
-    for dev_index, is_open in list(_aux_open.items()):
-        if not is_open:
+def aux_join(*outputs, lanes=None):
+    """The current stream waits for the auxiliary streams' work (all lanes, or the given ones); `outputs` (tensors made there) may
+    be used from here on."""
+    for key, is_open in list(_aux_open.items()):
+        if not is_open or (lanes is not None and key[1] not in lanes):
             continue
-        aux = _aux_streams[dev_index]
+        aux = _aux_streams[key]
         main = torch.cuda.current_stream(aux.device)
         if aux != main:
             main.wait_stream(aux)
-            for t in outputs:
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(main)
-        _aux_open[dev_index] = False
+            _record_stream_all(main, *outputs)
+        _aux_open[key] = False
 
 
 def _timed(kind, flops, fn, tag=(), nbytes=0):

@@ -33,6 +33,7 @@ VIEW = ("view", "reshape", "_unsafe_view", "expand", "permute", "transpose", "sl
         "alias", "as_strided", "t", "split", "split_with_sizes", "unbind", "chunk", "empty", "empty_like", "empty_strided",
         "record_stream", "is_same_size", "_local_scalar_dense", "stride", "sym_size", "unfold", "narrow", "new_empty", "lift_fresh")
 stat = collections.defaultdict(lambda: [0, 0.0])
+shapes = collections.Counter()
 
 
 class Spy(TorchDispatchMode):
@@ -56,6 +57,10 @@ class Spy(TorchDispatchMode):
                 if fr.filename.endswith("ops.py"):
                     src = f"ops.py:{fr.lineno} ({fr.name})"
                     break
+        if kb >= 4096:
+            shp = [tuple(t.shape) if torch.is_tensor(t) else "." for t in args[:3]]
+            contig = [t.is_contiguous() if torch.is_tensor(t) else "." for t in args[:3]]
+            shapes[(name, src, str(shp), str(contig))] += kb / 1024
         e = stat[(name, src, "big" if kb >= a.min_kb else "small")]
         e[0] += 1; e[1] += kb / 1024
         return out
@@ -70,3 +75,6 @@ for (name, src, size), (n, mb) in stat.items():
 print(f"ATen device ops in one step: {cnt['big']} with >= {a.min_kb:.0f} KB outputs ({tot['big']:.0f} MB written), {cnt['small']} smaller")
 for (name, src, size), (n, mb) in sorted(stat.items(), key=lambda kv: -kv[1][1])[:a.top]:
     print(f"{mb:9.1f} MB {n:5d}x  {name:28s} {src or '(autograd thread)'}")
+print("-- single big ops (>= 4 MB out): MB, op, source, arg shapes, contiguous?")
+for (name, src, shp, contig), mb in shapes.most_common(70):
+    print(f"{mb:8.1f} MB  {name:12s} {src or '(autograd thread)':60s} {shp} {contig}")

@@ -13,7 +13,14 @@ from tests.test_gpu_optim import _tiny_cfg
 DEV = torch.device("cuda:0")
 repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-cfg = _tiny_cfg()
+BENCH = os.environ.get("DBG_BENCH_CONFIG")          # e.g. 1: the headline bench configuration instead of the tiny model
+if BENCH is not None:
+    import bench
+    c = bench.CONFIGS[int(BENCH)]
+    cfg = bench.bench_config(c["height"], c["width"], c["full_step"])
+    ops.set_conv_precision("bf16" if c["dtype"] == "bf16" else "fp32")
+else:
+    cfg = _tiny_cfg()
 tp = cfg["train_params"]
 
 
@@ -22,11 +29,16 @@ def run(aux, defer):
     torch.manual_seed(0)
     model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
                                dataset="cityscapes").to(DEV).train()
-    step = TrainStep(model, run_optimizers=True, distributed=False)
+    step = TrainStep(model, run_optimizers=True if BENCH is None else c["full_step"], distributed=False)
     out = []
     for it in range(steps):
-        batch = batch_to(make_batch(2, 128, 256, 2, seed=60 + it), DEV)
-        rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=it)
+        if BENCH is None:
+            batch = batch_to(make_batch(2, 128, 256, 2, seed=60 + it), DEV)
+            rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=it)
+        else:
+            from c2m_amd.synthetic import make_stream_batch
+            batch = batch_to(make_stream_batch(c["batch"], c["windows"], c["height"], c["width"], 2, seed=it), DEV)
+            rng = make_step_rng(batch, z_dim=1024, latent_dim=1024, seed=it)
         batch["rng"] = {k: v.to(DEV) for k, v in rng.items()}
         _, lg, _ = step(batch)
         if os.environ.get("DBG_SYNC", "0") == "1":
