@@ -308,9 +308,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-table", default=None, help="write a per-shape conv timing table to this file")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="the HIP events around every conv launch (roofline object) are recorded in every k-th step of the timed "
-                         "region: ~600 event records cost a step ~1 ms of GPU time (71.2 vs 72.2 ms with them in every step); 1 = every step")
+                         "region.  Those steps time ISOLATED launches: the branch streams of ops.aux_branch / ops.deferred_wgrads are "
+                         "off in them (one stream, ~3 ms more than a normal step) and ~600 event records cost ~1 ms; 1 = every step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="conv operand precision: f32 = BASELINE configs[1] (the bench line); bf16 = configs[2-4] mode")
     ap.add_argument("--full-step", action="store_true", default=None,
@@ -533,7 +534,7 @@ def main():
                 "share_of_step_time": round(ms_all / (1000.0 * ev_s), 3),
                 # steps are issued asynchronously, so an event step has no wall time of its own: the shares divide by the MEAN
                 # step time x event steps; an event step is ~1 ms (1.5 %) longer than a plain one, shares are biased up by that
-                "share_basis": "mean wall time per step x event steps (event steps run ~1 ms longer; shares biased up by <= 1.5 %)",
+                "share_basis": "mean wall time per step x event steps (event steps run on one stream and carry the events: ~4 ms longer than the mean step; shares biased up by <= 7 %)",
             }
         if prof is not None and args.conv_table:
             with open(args.conv_table, "w") as f:

@@ -233,6 +233,9 @@ class aux_branch:
         self.lane = lane
         self.on = _AUX == "1" or _AUX == part or (_AUX == "obj" and part in ("roi", "gnn")) or \
             (_AUX.startswith("no") and _AUX[2:] != part)
+        # bench.py's per-launch HIP events time ISOLATED launches: the steps that carry them run on one stream (a kernel that shares
+        # the chip with another stream's is stretched, in the events and in a rocprofv3 trace alike)
+        self.on = self.on and ConvProfiler.active is None
 
     def __enter__(self):
         if not self.on or not self.inputs:

@@ -9,7 +9,9 @@ mkdir -p $O
 python3 bench.py --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err || tail -3 $O/bench_final.err
 echo "bench done"
 rm -rf $O/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --event-every 1 --no-cpu-baseline --side-configs '' --conv-table $O/conv_shape_table.txt > $O/trace.log 2>&1 || tail -5 $O/trace.log
+# kernel durations of ISOLATED launches: the branch streams (ops.aux_branch / ops.deferred_wgrads) are off in event steps anyway; the
+# two warm-up steps would run them (a launch sharing the chip with another stream's is stretched 2-10x) -> switched off for this run
+C2M_AUX_STREAM=0 C2M_DEFER_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --event-every 1 --no-cpu-baseline --side-configs '' --conv-table $O/conv_shape_table.txt > $O/trace.log 2>&1 || tail -5 $O/trace.log
 cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
 cp $O/trace/*/*kernel_trace.csv $O/kernel_trace.csv
 rm -rf $O/trace
