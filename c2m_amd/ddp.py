@@ -47,7 +47,7 @@ class _Bucket:
 
 class GradientReducer:
     def __init__(self, params, bucket_mb=25.0, process_group=None, force_collectives=False, buffers=(),
-                 measure=False, comm_dtype=torch.float32, measure_buckets=False):
+                 measure=False, comm_dtype=torch.float32, measure_buckets=False, adopt_params=()):
         """params: ALL parameters of the model.  The trainable ones are bucketed; every parameter -- frozen ones (the
         VGG-19 of the perceptual loss, a flow net) included -- and every tensor of `buffers` (BatchNorm running
         statistics, spectral-norm u/v) is broadcast from rank 0 at construction, which is what DistributedDataParallel's
@@ -78,6 +78,11 @@ class GradientReducer:
         self.device = uniq[0].device
         self.on_gpu = self.device.type == "cuda"
         self._main = None
+        # adopt_params (round 5, ops.deferred_wgrads): parameters whose .grad is left None by zero_grad() -- AccumulateGrad then
+        # ADOPTS the incoming gradient without a kernel, and the hook copies it into the bucket view on the stream the gradient
+        # was produced on (the weight-gradient side stream for a deferred convolution).  With .grad bound to the view the
+        # engine's `view += grad` would run on the backward's stream, i.e. need the weight gradient joined on the spot.
+        self.adopt = {id(p) for p in adopt_params} if self.on_gpu else set()
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets, cur, n = [], [], 0
         for p in reversed(uniq):                      # gradients become ready roughly in reverse creation order
@@ -129,7 +134,7 @@ class GradientReducer:
             b.flat.zero_()
             b.work, b.launched, b.ready = None, False, False
             for p, v in zip(b.params, b.views):
-                p.grad = v
+                p.grad = None if id(p) in self.adopt else v
         self.fired_final.clear()
         self.fired_any.clear()
         self._fire_seq = []
@@ -156,7 +161,14 @@ class GradientReducer:
     def _on_grad(self, p):
         b, i = self.where[id(p)]
         if p.grad is not b.views[i] and p.grad.data_ptr() != b.views[i].data_ptr():
-            b.views[i].copy_(p.grad)              # someone reset .grad (e.g. zero_grad(set_to_none=True)): re-adopt
+            # .grad was None (an adopt parameter, or someone reset it -- zero_grad(set_to_none=True)): move the gradient into the
+            # bucket, on the stream that produced it
+            s = ops.deferred_grad_stream(p.grad) if self.on_gpu else None
+            if s is not None:
+                with torch.cuda.stream(s):
+                    b.views[i].copy_(p.grad)
+            else:
+                b.views[i].copy_(p.grad)
             p.grad = b.views[i]
         self.fired_any.add(id(p))
         if not self.armed:
@@ -307,6 +319,9 @@ class GradientReducer:
         for p in self.params:
             if id(p) not in self.fired_any and id(p) not in self.ever_fired:
                 p.grad = None
+            elif p.grad is None:                       # an adopt parameter that did not fire on THIS rank in this step: the
+                b, i = self.where[id(p)]               # bucket view holds the other ranks' mean (zeros when nobody fired)
+                p.grad = b.views[i]
 
     def exposed_ms(self):
         """Mean GPU time per step between the end of the backward kernels and the moment the compute stream may go on

@@ -266,7 +266,7 @@ class aux_branch:
 
 # ---- deferred weight gradients (round 5): see _ConvFn.backward
 _DEFER_WGRAD = os.environ.get("C2M_DEFER_WGRAD", "1") != "0"
-_defer = {"on": False, "devs": set(), "seen": set(), "hold": collections.deque()}
+_defer = {"on": False, "devs": set(), "seen": set(), "hold": collections.deque(), "grads": {}, "by_w": {}}
 
 
 class deferred_wgrads:
@@ -279,6 +279,8 @@ class deferred_wgrads:
     def __enter__(self):
         _defer["on"] = self.enabled
         _defer["seen"].clear()
+        _defer["grads"].clear()
+        _defer["by_w"].clear()
         return self
 
     def __exit__(self, *exc):
@@ -288,7 +290,14 @@ class deferred_wgrads:
             torch.cuda.current_stream(side.device).wait_stream(side)
         _defer["devs"].clear()
         _defer["hold"].clear()            # (the joined stream orders every later write behind the side stream's reads)
+        _defer["grads"].clear()
         return False
+
+
+def deferred_grad_stream(grad):
+    """The side stream if `grad` is a weight / bias gradient that a deferred launch of the current backward is still producing
+    (ops.deferred_wgrads), else None.  For whoever touches a parameter gradient INSIDE backward (the gradient reducer's hook)."""
+    return _defer["grads"].get(grad.data_ptr()) if _defer["grads"] else None
 
 
 def _record_stream_all(stream, *objs):
@@ -1746,6 +1755,8 @@ class _ConvFn(torch.autograd.Function):
                 for t in (gw, gb):
                     if t is not None:
                         t.record_stream(main)
+                        _defer["grads"][t.data_ptr()] = dside
+                _defer["by_w"][w.data_ptr()] = [t.data_ptr() for t in (gw, gb) if t is not None]
                 _defer["devs"].add(x.device.index)
                 # dY may be shared with the identity path of a residual block (AddBackward hands ONE tensor to both branches): the
                 # engine sums the other branch's gradient into it IN PLACE once nobody else holds it -- while the side stream still
@@ -1766,6 +1777,8 @@ class _ConvFn(torch.autograd.Function):
                 return gx, gw, gb, None, None, None, None, None, None
             if x.device.index in _defer["devs"]:
                 torch.cuda.current_stream(x.device).wait_stream(_side_stream(x.device))
+                for ptr in _defer["by_w"].pop(w.data_ptr(), ()):     # its first gradient is summed with this one on THIS stream:
+                    _defer["grads"].pop(ptr, None)                   # no longer "being produced on the side stream"
         if side is not None:
             main = torch.cuda.current_stream(x.device)
             side.wait_stream(main)

@@ -76,9 +76,13 @@ class TrainStep:
         if self.tp["use_video_discriminator"]:
             self.optimizers.append(c2m.d_optimizer_video)
         distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
+        # leaf weights / biases of the convolution modules: their gradients are deferred to the side stream (ops.deferred_wgrads),
+        # the reducer adopts them instead of summing them into its buckets on the backward's stream
+        conv_params = [p for m in c2m.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d))
+                       for p in (m._parameters.get("weight"), m._parameters.get("bias")) if p is not None and p.requires_grad]
         self.reducer = GradientReducer(list(c2m.parameters()), bucket_mb=bucket_mb, buffers=list(c2m.buffers()),
                                        force_collectives=force_collectives, measure=measure_comm, measure_buckets=measure_comm_buckets,
-                                       comm_dtype=comm_dtype) if distributed else None
+                                       comm_dtype=comm_dtype, adopt_params=conv_params) if distributed else None
         self._deferred_nan = []       # NaN checks recorded while capturing (utils.isnan), evaluated after every replay
 
     # ---- HIP-graph replay of zero_grad + forward + backward (single GPU, static batch) ---------------------------------------
@@ -193,8 +197,8 @@ class TrainStep:
         if self.reducer is not None and not in_capture:
             self.reducer.arm()
         # weight gradients on the side stream, joined once after the backward (ops.deferred_wgrads); with the gradient reducer the
-        # gradients are summed into the flat buckets by kernels on the backward's stream as they appear: not deferred there
-        with ops.deferred_wgrads(enabled=self.reducer is None):
+        # hook moves an adopted gradient into its bucket on that stream, and a bucket's all-reduce waits for every branch stream
+        with ops.deferred_wgrads():
             total.backward()
         if self.reducer is not None and not in_capture:
             self.reducer.finish()

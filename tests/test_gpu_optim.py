@@ -535,6 +535,43 @@ def test_branch_streams_do_not_change_a_step(use_fw_of, monkeypatch):
     assert ops._side_streams and ops._aux_streams, "the second run must really have used both streams"
 
 
+@pytest.mark.parametrize("use_fw_of", [False, True])
+def test_reducer_step_with_deferred_weight_gradients_matches_the_plain_step(use_fw_of):
+    """The gradient reducer's buckets with the branch streams on: convolution weights / biases are ADOPTED (zero_grad leaves .grad
+    None, the hook copies the deferred gradient into the bucket view on the side stream), everything else accumulates into its view
+    on the backward's stream.  One process, no collectives: every gradient and the weights after three optimizer steps must be
+    bit-identical to the step without a reducer."""
+    cfg = _tiny_cfg()
+    cfg["train_params"]["use_fw_of"] = use_fw_of
+    tp = cfg["train_params"]
+
+    def run(distributed):
+        torch.manual_seed(0)
+        model = GeneratorFullModel(train_params=copy.deepcopy(tp), model_params=copy.deepcopy(cfg["model_params"]),
+                                   dataset="cityscapes").to(DEV).train()
+        step = TrainStep(model, run_optimizers=True, distributed=distributed, bucket_mb=0.5)
+        if distributed:
+            assert step.reducer is not None and step.reducer.adopt and len(step.reducer.buckets) > 3
+        grads = None
+        for it in range(3):
+            batch = batch_to(make_batch(2, 128, 256, 2, seed=80 + it, use_fw_of=use_fw_of), DEV)
+            rng = make_step_rng(batch, z_dim=16, latent_dim=32, seed=it)
+            batch["rng"] = {k: v.to(DEV) for k, v in rng.items()}
+            step(batch)
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        return grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    g0, w0 = run(False)
+    g1, w1 = run(True)
+    assert g0.keys() == g1.keys(), sorted(set(g0) ^ set(g1))[:5]
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, f"gradients differ under the reducer: {bad[:5]}"
+    bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert not bad, f"weights differ after 3 steps: {bad[:5]}"
+
+
 def test_hip_graph_replay_matches_eager_steps():
     """zero_grad + forward + backward captured into a HIP graph (TrainStep.capture): replays are bit-identical to the eager
     step, the optimizers run eagerly after each replay, new data is fed by copying into the static batch.  Round 1's capture
