@@ -206,6 +206,8 @@ _side_streams = {}
 
 
 def _side_stream(device):
+    # (stream priorities measured, round 5: side stream high 62.9 vs 62.1 ms, low = default; the step on a prioritised non-default
+    # stream 62.1 (high) / 63.9 (normal) vs 62.2 on the default stream -- nothing to gain, default priorities everywhere)
     s = _side_streams.get(device.index)
     if s is None:
         s = _side_streams[device.index] = torch.cuda.Stream(device=device)
