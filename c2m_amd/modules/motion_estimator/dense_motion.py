@@ -92,11 +92,13 @@ class DenseMotionNetwork(nn.Module):
         return out, fw
 
     def _inputs_then_targets(self, x):
-        """cat([first t_in frames stacked into channels and repeated over T, the T target frames], 1) (:173-192)."""
+        """The two pieces of cat([first t_in frames stacked into channels and repeated over T, the T target frames], 1) (:173-192):
+        returned as a list, so that the encoder inputs below are ONE concatenation of views instead of a cat of cats (the
+        intermediate copies were 360 MB written and read again per configs[1] step)."""
         t_in, T = self.train_params["num_input_frames"], self.train_params["num_predicted_frames"]
         b, c, _, h, w = x.shape
         src = x[:, :, :t_in].permute(0, 2, 1, 3, 4).reshape(b, t_in * c, 1, h, w).expand(b, t_in * c, T, h, w)
-        return torch.cat([src, x[:, :, t_in:]], dim=1)
+        return [src, x[:, :, t_in:]]
 
     def _decode(self, app_features, sparse, sparse_fw, z_m, out):
         tp = self.train_params
@@ -124,10 +126,10 @@ class DenseMotionNetwork(nn.Module):
         frames = self._inputs_then_targets(model_input["frames"])
         bg = self._inputs_then_targets(model_input["bg_mask"])
         fg = self._inputs_then_targets(model_input["fg_mask"])
-        inst = self._inputs_then_targets(model_input["instance"].to(frames.dtype))
-        flows = torch.cat([model_input["target_bw_of"], model_input["target_bw_occ"]], dim=1)
-        bg_out = self.motion_encoder_bg(torch.cat([frames, bg, flows], 1))
-        fg_out = self.motion_encoder_fg(torch.cat([frames, fg, inst, flows], 1))
+        inst = self._inputs_then_targets(model_input["instance"].to(frames[1].dtype))
+        flows = [model_input["target_bw_of"], model_input["target_bw_occ"]]
+        bg_out = self.motion_encoder_bg(torch.cat(frames + bg + flows, 1))
+        fg_out = self.motion_encoder_fg(torch.cat(frames + fg + inst + flows, 1))
         out = {"mu": torch.cat([bg_out["mu"], fg_out["mu"]], 1),
                "logvar": torch.cat([bg_out["logvar"], fg_out["logvar"]], 1)}
         z_m = self.reparameterize(out["mu"], out["logvar"], model_input.get("eps"))
@@ -141,7 +143,7 @@ class DenseMotionNetwork(nn.Module):
             ops.aux_join(*thetas.values())
         out.update(thetas)
         sparse, fw = self.generate_sparse_motion(model_input["tracking_gnn"], thetas,
-                                                 model_input["instance"][:, :, t_in - 1].to(frames.dtype),
+                                                 model_input["instance"][:, :, t_in - 1].to(frames[1].dtype),
                                                  tp["use_gt_training"])
         return self._decode(app_features, sparse, fw, z_m, out)
 
