@@ -779,6 +779,13 @@ class _ConvPlan:
         nd = len(xs) - 2
         self.is3d = is3d = 1 if nd == 3 else 0
         N, Cin = xs[0], xs[1]
+        if ws[1] != Cin:
+            # torch.nn.functional.conv2d raises here too.  Without the check the pack kernels read Cin * taps weights per output
+            # row out of a tensor that holds ws[1] * taps: past its end -- harmless next to other cached blocks, a GPU page fault
+            # when the weight sits at the end of an allocator segment (the intermittent abort of round 5's suite: a test that
+            # passed a 32-channel input to a 16-channel weight)
+            raise RuntimeError(f"convolution: input of shape {tuple(xs)} has {Cin} channels, weight of shape {tuple(ws)} expects "
+                               f"{ws[1]} (groups are not on the C2M path)")
         Ti, Hi, Wi = (xs[2], xs[3], xs[4]) if nd == 3 else (1, xs[2], xs[3])
         Cout = ws[0]
         kt, kh, kw = (ws[2], ws[3], ws[4]) if nd == 3 else (1, ws[2], ws[3])

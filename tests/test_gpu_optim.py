@@ -140,7 +140,7 @@ def test_adam_step_refreshes_every_pack_in_one_launch_bit_identically():
         ops._frozen_pack_cache.clear(); ops._pack_jobs.clear(); ops._pack_tables.clear()
 
         def run():
-            loss = ops.conv(xs[1], frozen, None, 1, 1).float().square().mean()
+            loss = ops.conv(xs[0], frozen, None, 1, 1).float().square().mean()      # (xs[0]: the 16-channel input)
             for x, w, s_, p_ in zip(xs, ws, strides, pads):
                 loss = loss + ops.conv(x, w, None, s_, p_, padding_mode="reflect").float().square().mean()
             loss.backward()

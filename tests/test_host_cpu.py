@@ -217,6 +217,15 @@ def test_time_pair_table_is_the_adjoint_of_reflect_pad_plus_three_taps(T):
     assert torch.allclose(got, x.grad[0, 0], rtol=0, atol=1e-14)
 
 
+def test_conv_plan_rejects_a_channel_mismatch():
+    """torch.nn.functional.conv2d raises on an input whose channel count is not the weight's; so does the plan (the pack kernels
+    would otherwise read past the end of the weight tensor)."""
+    import torch
+    from c2m_amd import ops
+    with pytest.raises(RuntimeError, match="channels"):
+        ops._ConvPlan((2, 32, 16, 32), (16, 16, 3, 3), (1, 1, 1), (0, 1, 1), False, torch.device("cpu"))
+
+
 def test_geom_names_one_definition_for_kernels_and_host():
     """the geom[] blocks of the convolution entry points are addressed by NAME -- include/c2m_geom.h is compiled
     into the library (csrc/common.h) and parsed by the ctypes host; the loaded library must report the header's ABI version and
