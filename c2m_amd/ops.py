@@ -1590,6 +1590,8 @@ class _ConvFn(torch.autograd.Function):
         pl = _plan(x, w, stride, pad, reflect, dgrad_rows)
         L = _lib.lib()
         N, Cin, Cout = pl.dims[0:3]
+        if b is not None and b.numel() != Cout:
+            raise RuntimeError(f"convolution: bias of {b.numel()} elements for {Cout} output channels")
         ctx.frozen_w = not ctx.needs_input_grad[1]
         ctx.x_dtype = x.dtype
         ctx.nc8_keep = None
@@ -2066,6 +2068,11 @@ class _NormActFn(torch.autograd.Function):
         dt = _dt(x)
         N, C = x.shape[0], x.shape[1]
         S = x.numel() // (N * C)
+        # the kernels index these by channel: sizes checked here (torch's norm layers raise on the same mistakes)
+        for name, t, want in (("gamma", gamma, C), ("beta", beta, C), ("running_mean", running_mean, C), ("running_var", running_var, C),
+                              ("SPADE map", gb, 2 * x.numel())):
+            if t is not None and t.numel() != want:
+                raise RuntimeError(f"norm: {name} has {t.numel()} elements, expected {want} for an input of shape {tuple(x.shape)}")
         L = _lib.lib()
         nstat = N * C if mode == 0 else C
         mean = torch.empty(nstat, device=x.device, dtype=torch.float32)
