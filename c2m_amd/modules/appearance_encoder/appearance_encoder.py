@@ -45,6 +45,9 @@ class AppearanceEncoder(nn.Module):
         self.roi_align_blocks = nn.Sequential(*roi_blocks)
         self.spatial_scale = (1 / scale_factor) * 2 ** pooling_after
         self.pooling_after = pooling_after
+        # True (set by GeneratorFullModel): `objects_feature` is handed on WITHOUT joining the auxiliary stream -- its only reader, the
+        # object GNN, continues there, and the model joins in front of the losses (ops.aux_branch)
+        self.defer_aux_join = False
 
     def forward(self, input_dict):
         gnn = input_dict["tracking_gnn"]
@@ -70,4 +73,6 @@ class AppearanceEncoder(nn.Module):
             scene = enc.flatten(1).index_select(0, gnn.batch.repeat_interleave(t_in))
             fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))
             out["objects_feature"] = torch.cat(fused.unsqueeze(1).chunk(t_in, 0), 1)
+        if not self.defer_aux_join:                 # stand-alone use: the caller reads the result on its own stream
+            ops.aux_join(out["objects_feature"], lanes=(0,))
         return out

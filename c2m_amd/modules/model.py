@@ -60,6 +60,8 @@ class GeneratorFullModel(nn.Module):
         self.num_frames = tp["num_input_frames"] + tp["num_predicted_frames"]
         self.appearance_encoder = AppearanceEncoder(tp, **mp["appearance_encoder"], **mp["common_params"])
         self.motion_encoder = DenseMotionNetwork(tp, mp)
+        # the object branch (RoI head + GNN) stays on its auxiliary stream across the two modules; _forward joins it (ops.aux_branch)
+        self.appearance_encoder.defer_aux_join = self.motion_encoder.defer_aux_join = True
         self.criterionGAN = discriminator.GANLoss()
         self.criterionFeat = torch.nn.L1Loss()
         self.generator = OcclusionAwareGenerator(mp["generator"], mp["flow_embedder"],
@@ -206,6 +208,7 @@ class GeneratorFullModel(nn.Module):
                    input_occ=input_occ)
         v = self._resize_inputs(src.get)
         app = self.appearance_encoder({"first_frame": self._encoder_input(v), "tracking_gnn": tracking_gnn})
+        ops.aux_join(app["objects_feature"])        # (a no-op unless inference runs on a model in training mode with grad enabled)
         out = {}
         out.update(self.motion_encoder.inference(app, dict(instance=v["instance"], latent_traj=latent, z_m=z_m,
                                                            index_user_guidance=index_user_guidance,

@@ -20,6 +20,7 @@ class DenseMotionNetwork(nn.Module):
         super().__init__()
         self.train_params = train_params
         self.model_params = model_params
+        self.defer_aux_join = False      # True (GeneratorFullModel): gt thetas stay on the auxiliary stream until the model's join
         tp, mp, cp = train_params, model_params, model_params["common_params"]
         t_in = tp["num_input_frames"]
         self.num_frames = t_in + tp["num_predicted_frames"]
@@ -139,8 +140,8 @@ class DenseMotionNetwork(nn.Module):
         with ops.aux_branch(*((app_features["objects_feature"], model_input["latent"]) if self.training and torch.is_grad_enabled() else ()), part="gnn"):
             thetas = self.sparse_motion_estimator(model_input["tracking_gnn"], app_features["objects_feature"],
                                                   model_input["latent"], model_input.get("click_index"))
-        if not tp["use_gt_training"]:
-            ops.aux_join(*thetas.values())
+        if not tp["use_gt_training"] or not self.defer_aux_join:
+            ops.aux_join(*thetas.values(), lanes=(0,))
         out.update(thetas)
         sparse, fw = self.generate_sparse_motion(model_input["tracking_gnn"], thetas,
                                                  model_input["instance"][:, :, t_in - 1].to(frames[1].dtype),

@@ -215,7 +215,7 @@ def _side_stream(device):
 
 
 # ---- auxiliary stream for the object branch (round 5).  The RoI head of the appearance encoder and the object GNN are ~600 launches
-# of a few microseconds on [24, 1024]-sized tensors per step (Linear layers, GATv2 attention, theta losses): ~4 ms of GPU time that
+# of a few microseconds on [24, 1024]-sized tensors per step (Linear layers, GATv2 attention, theta losses): ~3 ms of GPU time that
 # uses a sliver of the chip and, with gt thetas (use_gt_training: True), feeds nothing but the theta losses.  Run on a second stream
 # they execute NEXT TO the convolutions of the motion encoders / decoder / generator instead of between them -- forward, and
 # backward too: autograd runs every backward node on the stream of its forward and orders the streams itself.  No arithmetic
