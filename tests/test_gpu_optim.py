@@ -494,8 +494,8 @@ def test_config4_rank_shard():
     assert max(chunked) >= 2, "configs[4]'s shard must exercise the >= 2 GiB batch-chunk path"
 
 
-@pytest.mark.parametrize("use_fw_of", [False, True])
-def test_branch_streams_do_not_change_a_step(use_fw_of, monkeypatch):
+@pytest.mark.parametrize("use_fw_of,gt_thetas", [(False, True), (True, True), (False, False)])
+def test_branch_streams_do_not_change_a_step(use_fw_of, gt_thetas, monkeypatch):
     """Round 5: the object branch (RoI head + GNN) on the auxiliary stream and the weight gradients deferred to the side stream
     (ops.aux_branch / ops.deferred_wgrads) are scheduling only.  Four full steps with optimizers -- both discriminators (spectral
     norm: non-leaf weights, gradients from separate backward() calls), with use_fw_of the sparse-feature encoder applied twice (its
@@ -503,6 +503,7 @@ def test_branch_streams_do_not_change_a_step(use_fw_of, monkeypatch):
     both switched off and on; memory handed back to the allocator while the other stream still reads it would show up here."""
     cfg = _tiny_cfg()
     cfg["train_params"]["use_fw_of"] = use_fw_of
+    cfg["train_params"]["use_gt_training"] = gt_thetas      # False: the raster reads the GNN's thetas -> the branch joins in front of it
     tp = cfg["train_params"]
 
     def run(aux, defer):
