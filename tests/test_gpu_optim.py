@@ -494,8 +494,9 @@ def test_config4_rank_shard():
     assert max(chunked) >= 2, "configs[4]'s shard must exercise the >= 2 GiB batch-chunk path"
 
 
-@pytest.mark.parametrize("use_fw_of,gt_thetas", [(False, True), (True, True), (False, False)])
-def test_branch_streams_do_not_change_a_step(use_fw_of, gt_thetas, monkeypatch):
+@pytest.mark.parametrize("use_fw_of,gt_thetas,precision", [(False, True, "fp32"), (True, True, "fp32"), (False, False, "fp32"),
+                                                          (False, True, "bf16")])
+def test_branch_streams_do_not_change_a_step(use_fw_of, gt_thetas, precision, monkeypatch):
     """Round 5: the object branch (RoI head + GNN) on the auxiliary stream and the weight gradients deferred to the side stream
     (ops.aux_branch / ops.deferred_wgrads) are scheduling only.  Four full steps with optimizers -- both discriminators (spectral
     norm: non-leaf weights, gradients from separate backward() calls), with use_fw_of the sparse-feature encoder applied twice (its
@@ -525,8 +526,9 @@ def test_branch_streams_do_not_change_a_step(use_fw_of, gt_thetas, monkeypatch):
         torch.cuda.synchronize()
         return totals, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
-    t0, g0, w0 = run("0", False)
-    t1, g1, w1 = run("1", True)
+    with ops.conv_precision(precision):          # bf16: the NC8 forms riding on x / dY are read by the side stream as well
+        t0, g0, w0 = run("0", False)
+        t1, g1, w1 = run("1", True)
     assert t0 == t1, f"losses differ: {t0} vs {t1}"
     assert g0.keys() == g1.keys()
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
