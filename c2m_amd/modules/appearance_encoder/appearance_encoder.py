@@ -69,8 +69,14 @@ class AppearanceEncoder(nn.Module):
             obj = ops.roi_align(pooled_src, boxes, self.pool_size, spatial_scale=1 / self.spatial_scale)
             obj = self.roi_align_regressor(self.roi_align_blocks(obj))
             # == torch.repeat_interleave(app_encoded.flatten(1), gnn.num_real_nodes * t_in, dim=0) of the reference (:63) for
-            # the sorted per-node batch vector, without the host sync a tensor of repeat counts costs (HIP-graph capturable)
-            scene = enc.flatten(1).index_select(0, gnn.batch.repeat_interleave(t_in))
+            # the sorted per-node batch vector, without the host sync a tensor of repeat counts costs (HIP-graph capturable).
+            # As a one-hot GEMM, not index_select: the values are the same bit for bit (one non-zero term per output), and the
+            # backward is a GEMM with a fixed summation order where index_select's is index_add_ with float atomics -- the rows of
+            # one image collide, and the appearance encoder's 24 gradients came out different from run to run (found in round 5
+            # by tools/dbg_branch_streams.py on configs[3])
+            rows = gnn.batch.repeat_interleave(t_in)
+            onehot = (rows.unsqueeze(1) == torch.arange(enc.shape[0], device=enc.device).unsqueeze(0)).to(enc.dtype)
+            scene = onehot @ enc.flatten(1)
             fused = self.fuse_appearance_roi(torch.cat([scene, obj], dim=1))
             out["objects_feature"] = torch.cat(fused.unsqueeze(1).chunk(t_in, 0), 1)
         if not self.defer_aux_join:                 # stand-alone use: the caller reads the result on its own stream

@@ -396,11 +396,15 @@ def test_step_is_deterministic():
     for _ in range(2):
         cfg, model, batch = _model_and_batch(c)
         out, lg, ld = TrainStep(model, run_optimizers=False, distributed=False)(batch)
-        losses.append(float(lg["total_gen"]))
-        grads.append(model.generator.first.conv.weight.grad.clone())
+        losses.append(float(lg["total_gen"].detach()))
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     assert losses[0] == losses[1]
-    # no float atomics anywhere in the library (warp / RoIAlign backward are fixed-order gathers since round 2)
-    assert torch.equal(grads[0], grads[1])
+    # no float atomics anywhere on the path: warp / RoIAlign backward are fixed-order gathers since round 2; the per-object copy of
+    # the scene feature is a one-hot GEMM since round 5 (index_select's backward is index_add_ with atomics: the 24 gradients of the
+    # appearance encoder differed from run to run on configs[3]) -- EVERY gradient must repeat bit for bit
+    assert grads[0].keys() == grads[1].keys()
+    bad = [k for k in grads[0] if not torch.equal(grads[0][k], grads[1][k])]
+    assert not bad, f"{len(bad)} gradients differ between two runs of the same step: {bad[:6]}"
 
 
 @pytest.mark.parametrize("name", names("inf_"))
