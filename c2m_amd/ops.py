@@ -1744,7 +1744,10 @@ class _ConvFn(torch.autograd.Function):
         if keep is not None and need_w and (pl.wgrad_nc8 or pl.s2_wgrad_nc8 or pl.k333_wgrad_nc8):
             gy = _as(gy, BF16)
             _to_nc8(gy, keep)
-        if need_w and _defer["on"]:
+        # (not while capturing a HIP graph: the graph executor runs the long side branch worse than the per-node fork + join below --
+        # replays of configs[3] / configs[2]: 42.7 / 63.9 ms deferred, 42.4 / 63.5 per node, 43.8 / 66.4 deferred without the object
+        # branch -- and a capture would have to hold every dY until its end)
+        if need_w and _defer["on"] and not torch.cuda.is_current_stream_capturing():
             # `with ops.deferred_wgrads():` around backward (TrainStep): the weight gradient of a leaf weight that has no gradient
             # yet goes to the side stream and is NOT joined here -- nothing reads it before the optimizer (AccumulateGrad adopts the
             # tensor, no kernel) -- so its split reductions and its tail run under the data-gradient chain of the layers below.
@@ -1773,16 +1776,12 @@ class _ConvFn(torch.autograd.Function):
                 # engine sums the other branch's gradient into it IN PLACE once nobody else holds it -- while the side stream still
                 # reads it (found by test_branch_streams_do_not_change_a_step: conv2 of the residual blocks).  A second owner makes
                 # that sum out of place; the reference is dropped when the side stream has passed this launch.
-                # (inside a HIP-graph capture events cannot be queried: held until the join)
+                ev = torch.cuda.Event()
+                ev.record(dside)
                 hold = _defer["hold"]
-                if torch.cuda.is_current_stream_capturing():
-                    hold.append((None, gy))
-                else:
-                    ev = torch.cuda.Event()
-                    ev.record(dside)
-                    hold.append((ev, gy))
-                    while hold and hold[0][0] is not None and hold[0][0].query():
-                        hold.popleft()
+                hold.append((ev, gy))
+                while hold and hold[0][0].query():
+                    hold.popleft()
                 if ctx.needs_input_grad[0]:
                     gx = _conv_dgrad(pl, w, gy, ctx.frozen_w, ctx.x_dtype, keep)
                 return gx, gw, gb, None, None, None, None, None, None
