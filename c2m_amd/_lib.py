@@ -85,6 +85,9 @@ _SIGS = {
     "c2m_resize_bilinear": (c_int, [c_void_p, c_void_p, c_long] + [c_int] * 5 + [c_double, c_int, c_void_p]),
     "c2m_upsample2x_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_upsample2x_nc8": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "c2m_gat_dense_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "c2m_gat_dense_bwd_workspace_floats": (c_long, [c_int, c_int, c_int]),
+    "c2m_gat_dense_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_void_p]),
     "c2m_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "c2m_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "c2m_roi_align_bwd": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_float, c_void_p]),

@@ -20,7 +20,7 @@ NOSLP = ["-fno-slp-vectorize"]
 SOURCES = {"conv_igemm.hip": NOSLP, "conv_nc8.hip": NOSLP, "conv_wino.hip": NOSLP, "conv_wino4.hip": NOSLP, "conv_ring.hip": NOSLP, "norm.hip": NOSLP, "losses.hip": NOSLP,
            "optim.hip": ["-ffp-contract=off"] + NOSLP, "data_prep.hip": ["-ffp-contract=off"] + NOSLP,
            "warp.hip": ["-ffp-contract=off"] + NOSLP, "motion_raster.hip": ["-ffp-contract=off"] + NOSLP, "events.hip": [],
-           "flownet_ops.hip": ["-ffp-contract=off"] + NOSLP}
+           "flownet_ops.hip": ["-ffp-contract=off"] + NOSLP, "gnn.hip": ["-ffp-contract=off"] + NOSLP}
 
 
 def _stale(target, deps):

@@ -2350,6 +2350,51 @@ def roi_align(feat, boxes, output_size, spatial_scale=1.0):
     return _RoiAlignFn.apply(feat, boxes.to(torch.float32), int(ph), int(pw), float(spatial_scale))
 
 
+# =============================================================================================== object GNN
+class _GatDenseFn(torch.autograd.Function):
+    """Attention of a GATv2 layer on a dense graph of <= 64 nodes (csrc/gnn.hip): one launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, xl, xr, att, A, slope):
+        _dev(xl, xr, att, A)
+        xl, xr, att, A = (_as(t, torch.float32) for t in (xl, xr, att, A))
+        N, H, C = xl.shape
+        assert xr.shape == (N, H, C) and att.shape == (H, C) and A.shape == (N, N)
+        out = torch.empty(N, C, device=xl.device, dtype=torch.float32)
+        alpha = torch.empty(N, N, H, device=xl.device, dtype=torch.float32)
+        _lib.check(_lib.lib().c2m_gat_dense_fwd(_p(xl), _p(xr), _p(att), _p(A), _p(out), _p(alpha), N, H, C, float(slope), _stream()),
+                   "gat_dense_fwd")
+        ctx.slope = float(slope)
+        ctx.save_for_backward(xl, xr, att, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, xr, att, alpha = ctx.saved_tensors
+        N, H, C = xl.shape
+        L = _lib.lib()
+        dxl, dxr, datt = torch.empty_like(xl), torch.empty_like(xr), torch.empty_like(att)
+        ws = torch.empty(L.c2m_gat_dense_bwd_workspace_floats(N, H, C), device=xl.device, dtype=torch.float32)
+        _lib.check(L.c2m_gat_dense_bwd(_p(xl), _p(xr), _p(att), _p(alpha), _p(_as(g, torch.float32)), _p(dxl), _p(dxr), _p(datt), _p(ws),
+                                       N, H, C, ctx.slope, _stream()), "gat_dense_bwd")
+        return dxl, dxr, datt, None, None
+
+
+GAT_DENSE_MAX_NODES, GAT_DENSE_MAX_CHANNELS = 64, 1024
+_GAT_FUSED = os.environ.get("C2M_GAT_FUSED", "1") != "0"
+
+
+def gatv2_dense_ok(xl, N, C):
+    return _GAT_FUSED and xl.is_cuda and xl.dtype == torch.float32 and N <= GAT_DENSE_MAX_NODES and C <= GAT_DENSE_MAX_CHANNELS
+
+
+def gatv2_dense(xl, xr, att, A, negative_slope=0.2):
+    """mean over heads of softmax_j(att . lrelu(xl[j] + xr[i]); weights A[i, j]) applied to xl -- the message passing of
+    GATv2Conv(concat=False, add_self_loops=False) for all ordered node pairs (thirdparty.GATv2Conv adds the bias).  xl, xr [N, H, C],
+    att [H, C], A [N, N] edge multiplicities; returns [N, C]."""
+    return _GatDenseFn.apply(xl, xr, att, A, negative_slope)
+
+
 # =============================================================================================== index / mask path
 def sparse_raster(instance, obj_id, obj_batch, thetas):
     """instance [B,H,W] float ids, obj_id/obj_batch [K], thetas [K,T,6] -> (bw [B,2,T,H,W], fw, bin [B,1,T,H,W])."""

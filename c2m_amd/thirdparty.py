@@ -115,6 +115,11 @@ class GATv2Conv(nn.Module):
             # independent of the edge-list restatement the oracle uses (oracle/thirdparty.py::gatv2_conv), so comparing the two
             # is a real check of both.
             A = _edge_multiplicity(edge_index, dst, src, N, x.dtype)
+            from . import ops
+            if ops.gatv2_dense_ok(xl, N, C):
+                # the chain below as one launch per direction (csrc/gnn.hip): ~18 forward and ~35 backward launches per layer on
+                # [N, N, H, C] temporaries otherwise -- five layers per step, most of the object branch's launches
+                return ops.gatv2_dense(xl, xr, self.att.view(H, C), A, self.negative_slope) + self.bias
             e = F.leaky_relu(xl.unsqueeze(0) + xr.unsqueeze(1), self.negative_slope)          # [i, j, H, C]
             logit = (e * self.att).sum(-1)                                                     # [i, j, H]
             logit = logit.masked_fill(A.unsqueeze(-1) == 0, float("-inf"))

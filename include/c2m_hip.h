@@ -343,6 +343,18 @@ int c2m_ssim_fwd(const float* x, const float* y, float* out, long NC, int H, int
 int c2m_ssim_bwd(const float* x, const float* y, const float* gscale, float* gx, float* coef, long NC, int H, int W,
                  void* stream);
 
+/* ---- object GNN (gnn.hip, round 5): the attention of torch_geometric's GATv2Conv(heads, concat=False, add_self_loops=False)
+ * on a dense graph of <= 64 nodes, src/modules/motion_estimator/sparse_motion_estimator.py:104-112 (one layer per predicted frame).
+ * xl = lin_l(x), xr = lin_r(x) [N][H][C]; att [H][C]; A [N][N] = number of edges j -> i at A[i][j] (mask and weight of the softmax
+ * over the incoming edges); out [N][C] = mean over heads of sum_j alpha[i][j][h] * xl[j][h][:] (the layer's bias is added by the
+ * caller); alpha [N][N][H] is kept for the backward.  One launch forward, two backward (per-target partials summed in index
+ * order: no atomics).  N <= 64, C <= 1024, fp32.                                                                                */
+int c2m_gat_dense_fwd(const float* xl, const float* xr, const float* att, const float* A, float* out, float* alpha, int N, int H,
+                      int C, float negative_slope, void* stream);
+long c2m_gat_dense_bwd_workspace_floats(int N, int H, int C);
+int c2m_gat_dense_bwd(const float* xl, const float* xr, const float* att, const float* alpha, const float* gout, float* dxl,
+                      float* dxr, float* datt, float* workspace, int N, int H, int C, float negative_slope, void* stream);
+
 /* ---- input pipeline stage upstream of the path (data_prep.hip): SURVEY §8f-3 -------------------------------------
  * src/datasets/cityscapes.py:30-70 (ToTensor of frames, label-id one-hot split 0..10 / 11..19), :212-265 (occlusion
  * PNG -> clip_mask, .flo HWC -> CHW): decoded uint8 / float arrays in, the batch-dict tensors of model.py:124 out.  */

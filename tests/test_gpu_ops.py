@@ -1012,3 +1012,40 @@ def test_reflect_border_add_pad1_kernel_matches_the_general_one_and_autograd(sha
     ref = base.double().cpu().reshape(NC * T, 1, H, W) + x.grad
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
     close(outs[0].double().cpu().reshape(NC * T, 1, H, W), ref, tol, tol, "border fold vs the adjoint of reflect padding")
+
+
+@pytest.mark.parametrize("N,H,C,empty_rows", [(24, 4, 512, False), (6, 4, 512, True), (64, 2, 1024, False), (13, 3, 96, True)])
+def test_gatv2_dense_attention_one_launch_vs_the_torch_form(N, H, C, empty_rows, monkeypatch):
+    """csrc/gnn.hip (the attention of thirdparty.GATv2Conv in one launch forward, two backward) against the layer's own chain of
+    torch device ops on the same inputs: multi-edges (multiplicity 2), nodes without incoming edges, forward and the gradients of
+    x, lin_l / lin_r, att and the bias; and bit-repeatable (no atomics)."""
+    from c2m_amd.thirdparty import GATv2Conv
+    g = torch.Generator().manual_seed(100 + N)
+    layer = GATv2Conv(C, C, heads=H, concat=False, add_self_loops=False).to(DEV)
+    E = 5 * N
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(1 if empty_rows else 0, N, (E,), generator=g)          # node 0 receives nothing when empty_rows
+    edge = torch.stack([torch.cat([src, src[:7]]), torch.cat([dst, dst[:7]])]).to(DEV)      # the first 7 edges twice
+    x0 = torch.randn(N, C, generator=g).to(DEV)
+    w = torch.randn(N, C, generator=g).to(DEV)
+
+    def run(fused):
+        monkeypatch.setattr(ops, "_GAT_FUSED", fused)
+        for p in layer.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = layer(x, edge)
+        (y * w).sum().backward()
+        return y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}
+
+    y0, gx0, gp0 = run(False)
+    y1, gx1, gp1 = run(True)
+    y2, gx2, gp2 = run(True)
+    scale = float(y0.abs().max())
+    assert (y1 - y0).abs().max() <= 2e-6 * scale + 1e-6, float((y1 - y0).abs().max())
+    assert (gx1 - gx0).abs().max() <= 1e-5 * float(gx0.abs().max()) + 1e-7
+    for k in gp0:
+        assert (gp1[k] - gp0[k]).abs().max() <= 1e-5 * float(gp0[k].abs().max()) + 1e-7, k
+    assert torch.equal(y1, y2) and torch.equal(gx1, gx2) and all(torch.equal(gp1[k], gp2[k]) for k in gp1)
+    if empty_rows:
+        assert torch.equal(y1[0], layer.bias.detach())                  # no incoming edges: the bias alone
