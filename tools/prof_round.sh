@@ -26,4 +26,5 @@ rm -rf $O/pmc_MFMA
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_MFMA -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --side-configs '' > $O/pmc_MFMA.log 2>&1 || tail -5 $O/pmc_MFMA.log
 echo "pmc mfma done"
 python3 tools/prof_round2_post.py $O
+python3 tools/timeline_occupancy.py $O/kernel_trace.csv 5 256 > $O/launches_per_step.txt 2>&1 || tail -2 $O/launches_per_step.txt   # exact launches per step (no one-off blits)
 rm -f $O/kernel_trace.csv
